@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    """npz fixture -> nested dict ('sd/ln.weight' -> d['sd']['ln.weight'])."""
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    out = {}
+    for k in z.files:
+        if '/' in k:
+            a, b = k.split('/', 1)
+            out.setdefault(a, {})[b] = z[k]
+        else:
+            out[k] = z[k]
+    return out
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

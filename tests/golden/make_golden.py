@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE's own classes.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).  The reference
+scripts load feature files / train at import time, so they are loaded by AST extraction: only
+class and function definitions, the `config = {...}` literal and torch/numpy/sklearn imports are
+kept and exec'd into a fresh module.  The fixtures hold DATA only: seeded
+inputs, the reference's state_dict values, and the outputs / loss / gradients / post-step
+parameters / train()-evaluate() aggregates the reference computes on them (CPU PyTorch fp32).
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+"""
+import ast
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference/DepressionCollected'
+OUT = os.path.dirname(os.path.abspath(__file__))
+OK_PKGS = {'torch', 'numpy', 'sklearn', 'os', 'itertools', 'random', 'pickle', 're'}
+
+
+def load_ref(relpath, name):
+    src = open(os.path.join(REF, relpath)).read()
+    tree = ast.parse(src)
+    keep = []
+    for n in tree.body:
+        if isinstance(n, (ast.ClassDef, ast.FunctionDef)):
+            keep.append(n)
+        elif isinstance(n, ast.Import):
+            if all(a.name.split('.')[0] in OK_PKGS for a in n.names):
+                keep.append(n)
+        elif isinstance(n, ast.ImportFrom):
+            if (n.module or '').split('.')[0] in OK_PKGS:
+                keep.append(n)
+        elif isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name) \
+                and n.targets[0].id == 'config':
+            keep.append(n)
+    mod = types.ModuleType(name)
+    exec(compile(ast.Module(keep, []), relpath, 'exec'), mod.__dict__)
+    return mod
+
+
+def sd_np(model):
+    return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in model.state_dict().items()
+            if v.dtype.is_floating_point}
+
+
+def grads_np(model):
+    return {k: p.grad.detach().numpy().astype(np.float32) for k, p in model.named_parameters()
+            if p.grad is not None}
+
+
+def save(name, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f'{k}/{kk}'] = np.asarray(vv)
+        else:
+            flat[k] = np.asarray(v)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **flat)
+    print(f'{name}: {os.path.getsize(path) / 1e6:.2f} MB, {len(flat)} arrays')
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def single_model(mod, cls, cfg_over, shape, kind, seed, optimizer, loss, steps=3, light=False, name=None):
+    """forward(eval) + loss/grads/optimizer steps (dropout 0) for one reference nn.Module."""
+    B, T, F, H = shape
+    torch.manual_seed(seed)
+    cfg = dict(mod.config); cfg.update(cfg_over)
+    cfg.update(embedding_size=F, hidden_dims=H, dropout=0.0)
+    model = getattr(mod, cls)(cfg)
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, T, F)).astype(np.float32)
+    if kind == 'clf':
+        y = rng.integers(0, 2, B).astype(np.int64); y[0] = 0; y[1] = 1
+    else:
+        y = rng.uniform(30, 70, B).astype(np.float32)
+    sd0 = sd_np(model)
+    model.eval()
+    with torch.no_grad():
+        out_eval = model(torch.from_numpy(x)).numpy()
+    extra = {}
+    if 'Text' in cls:
+        with torch.no_grad():
+            xt = torch.from_numpy(x).permute(1, 0, 2)
+            o, (hn, _) = model.lstm_net(xt)
+            extra['lstm_out'] = o.permute(1, 0, 2).numpy()
+            extra['h_n'] = hn.numpy()
+            extra['ctx'] = model.attention_net_with_w(o.permute(1, 0, 2), hn.permute(1, 0, 2)).numpy()
+    else:
+        with torch.no_grad():
+            xin = model.ln(torch.from_numpy(x)) if hasattr(model, 'ln') else torch.from_numpy(x)
+            o, _ = model.lstm_net_audio(xin)
+            extra['gru_out'] = o.numpy()
+    model.train()
+    if optimizer == 'adamw':
+        groups = mod.get_param_group(model)
+        opt = torch.optim.AdamW(groups, lr=cfg_over.get('lr', 1e-3))
+        extra['nodecay_names'] = np.array([n for n, _ in model.named_parameters() if 'ln' in n])
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=cfg_over.get('lr', 1e-3))
+    crit = {'ce': torch.nn.CrossEntropyLoss(), 'l1': torch.nn.L1Loss(), 'sl1': torch.nn.SmoothL1Loss()}[loss]
+    losses = []; g0 = None; after = {}
+    for s in range(steps):
+        opt.zero_grad()
+        xt = torch.from_numpy(x).requires_grad_(True)
+        out = model(xt)
+        yt = torch.from_numpy(y)
+        l = crit(out, yt) if kind == 'clf' else crit(out, yt.view_as(out))
+        l.backward()
+        if s == 0:
+            g0 = grads_np(model); out_train = out.detach().numpy(); dx0 = xt.grad.numpy().copy()
+        opt.step()
+        losses.append(l.item())
+        after[s + 1] = sd_np(model)
+    arrs = dict(shape=np.array(shape), x=x, y=y, sd=sd0, out_eval=out_eval, out_train=out_train,
+                losses=np.array(losses, np.float64), grads=g0, dx=dx0, lr=np.float64(cfg_over.get('lr', 1e-3)),
+                **extra)
+    arrs[f'after{steps}'] = after[steps]
+    if not light:
+        arrs['after1'] = after[1]
+    save(name, **arrs)
+
+
+def audio_clf_train_eval(mod):
+    """train()/evaluate() module-level functions of audio_gru_whole.py on synthetic features, dropout 0."""
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    N, T, F, H = 21, 3, 12, 16
+    cfg = dict(mod.config); cfg.update(embedding_size=F, hidden_dims=H, dropout=0.0, batch_size=8, learning_rate=1e-3)
+    mod.config = cfg
+    feats = rng.standard_normal((N, T, F)).astype(np.float64)      # npz features are float64 in general
+    targs = rng.integers(0, 2, N).astype(np.int64); targs[:2] = [0, 1]
+    model = mod.AudioBiLSTM(cfg)
+    sd0 = sd_np(model)
+    mod.model = model
+    mod.audio_features = feats; mod.audio_targets = targs
+    mod.optimizer = torch.optim.AdamW(mod.get_param_group(model), lr=cfg['learning_rate'])
+    mod.criterion = torch.nn.CrossEntropyLoss()
+    mod.max_f1 = mod.max_acc = mod.max_rec = mod.max_prec = 2.0      # thresholds unmet -> no save()
+    mod.train_acc = -1
+    train_idxs = list(range(0, 15)); test_idxs = list(range(15, 21))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mod.train(1, train_idxs)
+        acc1 = int(mod.train_acc)
+        mod.train(2, train_idxs)
+        acc2 = int(mod.train_acc)
+        tl = mod.evaluate(model, test_idxs, 1, train_idxs, train_idxs)
+    with torch.no_grad():
+        model.eval()
+        probs = model(torch.from_numpy(feats[test_idxs]).float()).numpy()
+    pred = probs.argmax(1)
+    cm = mod.standard_confusion_matrix(torch.from_numpy(targs[test_idxs]), pred)
+    save('audio_clf_train_eval', feats=feats, targs=targs, sd=sd0, train_idxs=np.array(train_idxs),
+         test_idxs=np.array(test_idxs), train_acc=np.array([acc1, acc2]), eval_loss=np.float64(tl),
+         probs=probs, conf=cm, after=sd_np(model), lr=np.float64(cfg['learning_rate']),
+         shape=np.array([N, T, F, H]), batch_size=np.int64(8),
+         printed=np.array(buf.getvalue()))
+
+
+def audio_reg_train_eval(mod):
+    torch.manual_seed(12)
+    rng = np.random.default_rng(12)
+    N, T, F, H = 17, 3, 10, 16
+    cfg = dict(mod.config); cfg.update(embedding_size=F, hidden_dims=H, dropout=0.0, batch_size=4, learning_rate=1e-3)
+    mod.config = cfg
+    feats = rng.standard_normal((N, T, F)).astype(np.float64)
+    targs = rng.uniform(30, 70, N).astype(np.float64)
+    model = mod.AudioBiLSTM(cfg)
+    sd0 = sd_np(model)
+    mod.model = model; mod.audio_features = feats; mod.audio_targets = targs
+    mod.optimizer = torch.optim.Adam(model.parameters(), lr=cfg['learning_rate'])
+    mod.criterion = torch.nn.L1Loss()
+    mod.train_dep_idxs = [0, 1, 2, 3, 4]; mod.train_non_idxs = [5, 6, 7, 8, 9, 10]
+    mod.test_dep_idxs = [11, 12]; mod.test_non_idxs = [13, 14, 15, 16]
+    mod.min_mae = -1.0; mod.min_rmse = -1.0       # threshold unmet -> no save()
+    with contextlib.redirect_stdout(io.StringIO()):
+        mae1 = mod.train(1)
+        mae2 = mod.train(2)
+        tl = mod.evaluate(0, model, mae2)
+    save('audio_reg_train_eval', feats=feats, targs=targs, sd=sd0, train_mae=np.array([mae1, mae2]),
+         eval_loss=np.float64(tl), after=sd_np(model), lr=np.float64(cfg['learning_rate']),
+         shape=np.array([N, T, F, H]), batch_size=np.int64(4))
+
+
+def fusion(mod, variant, seed, name):
+    """fusion_net.pretrained_feature / forward / MyLoss / Adam steps + train()/evaluate()."""
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    N, T, Fa, Ft, Ha, Ht = 10, 3, 12, 20, 16, 16
+    cfg = dict(mod.config)
+    cfg.update(audio_embed_size=Fa, text_embed_size=Ft, audio_hidden_dims=Ha, text_hidden_dims=Ht,
+               dropout=0.0, batch_size=4, learning_rate=1e-3)
+    mod.config = cfg
+    model = mod.fusion_net(cfg['text_embed_size'], cfg['text_hidden_dims'], cfg['rnn_layers'], cfg['dropout'],
+                           cfg['num_classes'], cfg['audio_hidden_dims'], cfg['audio_embed_size'])
+    for p in model.parameters():
+        p.requires_grad = False
+    model.fc_final[0].weight.requires_grad = True
+    sd0 = sd_np(model)
+    xa = rng.standard_normal((N, T, Fa)).astype(np.float32)
+    xt = rng.standard_normal((N, T, Ft)).astype(np.float32)
+    if variant == 'clf':
+        y = rng.integers(0, 2, N).astype(np.int64); y[:2] = [0, 1]
+    else:
+        y = rng.uniform(30, 70, N).astype(np.float32)
+    feats = [[xa[i], xt[i]] for i in range(N)]
+    model.eval()
+    tf, af = model.pretrained_feature(feats)
+    with torch.no_grad():
+        out = model(torch.cat((tf, af), dim=1)).numpy()
+    crit = mod.MyLoss()
+    opt = torch.optim.Adam(model.parameters(), lr=cfg['learning_rate'])
+    losses = []; g0 = None
+    for s in range(3):
+        opt.zero_grad()
+        if variant == 'clf':
+            l = crit(tf, af, list(y), model)
+        else:
+            l = crit(tf, af, torch.from_numpy(y).view(-1, 1), model)
+        l.backward()
+        if s == 0:
+            g0 = model.fc_final[0].weight.grad.numpy().copy()
+        opt.step(); losses.append(l.item())
+    W3 = model.fc_final[0].weight.detach().numpy().copy()
+    arrs = dict(xa=xa, xt=xt, y=y, sd=sd0, text_feature=tf.numpy(), audio_feature=af.numpy(), out=out,
+                losses=np.array(losses), gW=g0, W3=W3, lr=np.float64(cfg['learning_rate']),
+                dims=np.array([N, T, Fa, Ft, Ha, Ht]))
+    if variant == 'clf':
+        # module-level train()/evaluate() from a fresh copy of the same weights
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd0.items()}, strict=False)
+        mod.model = model
+        mod.optimizer = torch.optim.Adam(model.parameters(), lr=cfg['learning_rate'])
+        mod.criterion = mod.MyLoss()
+        mod.fuse_features = feats; mod.fuse_targets = y
+        mod.max_f1 = 2.0; mod.max_acc = 2.0; mod.max_train_acc = -1; mod.train_acc = -1
+        tr = list(range(0, 7)); te = list(range(6, 10))
+        with contextlib.redirect_stdout(io.StringIO()):
+            mod.train(1, tr)
+            acc = int(mod.train_acc)
+            tl = mod.evaluate(model, te, 1, tr)
+        arrs.update(train_idxs=np.array(tr), test_idxs=np.array(te), train_acc=np.int64(acc),
+                    eval_loss=np.float64(tl), W_after_train=model.fc_final[0].weight.detach().numpy().copy())
+    save(name, **arrs)
+
+
+def main():
+    torch.set_num_threads(4)
+    a_clf = load_ref('Classification/audio_gru_whole.py', 'ref_audio_clf')
+    t_clf = load_ref('Classification/text_bilstm_whole.py', 'ref_text_clf')
+    a_reg = load_ref('Regression/audio_bilstm_perm.py', 'ref_audio_reg')
+    t_reg = load_ref('Regression/text_bilstm_perm.py', 'ref_text_reg')
+    f_clf = load_ref('Classification/fuse_net_whole.py', 'ref_fuse_clf')
+    f_reg = load_ref('Regression/fuse_net.py', 'ref_fuse_reg')
+
+    tiny = (4, 6, 5, 8)        # H not a multiple of 16 -> exercises the generic kernels
+    mid = (6, 20, 24, 16)      # H % 16 == 0 -> exercises the MFMA sweep kernels
+    cfg1 = (8, 50, 39, 128)    # BASELINE.json configs[0]
+    single_model(a_clf, 'AudioBiLSTM', {}, tiny, 'clf', 1, 'adamw', 'ce', name='audio_clf_tiny')
+    single_model(a_clf, 'AudioBiLSTM', {}, mid, 'clf', 2, 'adamw', 'ce', name='audio_clf_mid')
+    single_model(a_clf, 'AudioBiLSTM', {}, cfg1, 'clf', 3, 'adamw', 'ce', light=True, name='audio_clf_cfg1')
+    single_model(a_reg, 'AudioBiLSTM', {}, tiny, 'reg', 4, 'adam', 'l1', name='audio_reg_tiny')
+    single_model(a_reg, 'AudioBiLSTM', {}, mid, 'reg', 5, 'adam', 'l1', name='audio_reg_mid')
+    single_model(t_clf, 'TextBiLSTM', {}, tiny, 'clf', 6, 'adamw', 'ce', name='text_clf_tiny')
+    single_model(t_clf, 'TextBiLSTM', {}, mid, 'clf', 7, 'adamw', 'ce', name='text_clf_mid')
+    single_model(t_reg, 'TextBiLSTM', {}, tiny, 'reg', 8, 'adam', 'sl1', name='text_reg_tiny')
+    single_model(t_reg, 'TextBiLSTM', {}, mid, 'reg', 9, 'adam', 'sl1', name='text_reg_mid')
+    audio_clf_train_eval(a_clf)
+    audio_reg_train_eval(a_reg)
+    fusion(f_clf, 'clf', 21, 'fuse_clf')
+    fusion(f_reg, 'reg', 22, 'fuse_reg')
+
+
+if __name__ == '__main__':
+    sys.exit(main())
