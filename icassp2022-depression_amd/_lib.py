@@ -1,0 +1,282 @@
+"""ctypes binding of libdep_rnn.so (include/dep_rnn.h).
+
+PyTorch-ROCm tensors are storage only: every wrapper passes `tensor.data_ptr()` and the current
+HIP stream.  There is NO fallback: if the library is missing or a call fails this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libdep_rnn.so')
+
+CELL_GRU, CELL_LSTM = 0, 1
+POOL_NONE, POOL_MEAN, POOL_SUM = 0, 1, 2
+LOSS_CE_ON_SOFTMAX, LOSS_L1_RELU, LOSS_SMOOTHL1_RELU, LOSS_CE_LOGITS, LOSS_SMOOTHL1 = 0, 1, 2, 3, 4
+SITE_FC0, SITE_FC1, SITE_FC2, SITE_FC3 = 1, 2, 3, 4
+
+
+class DepError(RuntimeError):
+    pass
+
+
+class RnnDesc(C.Structure):
+    _fields_ = [('cell', C.c_int32), ('B', C.c_int32), ('T', C.c_int32), ('F', C.c_int32), ('H', C.c_int32),
+                ('L', C.c_int32), ('dirs', C.c_int32), ('training', C.c_int32), ('dropout_p', C.c_float),
+                ('seed', C.c_uint64), ('pool', C.c_int32), ('impl', C.c_int32)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    'dep_last_error': (C.c_char_p, []),
+    'dep_version': (C.c_int, []),
+    'dep_arch': (C.c_char_p, []),
+    'dep_rnn_reserve_bytes': (C.c_size_t, [C.POINTER(RnnDesc)]),
+    'dep_rnn_workspace_bytes': (C.c_size_t, [C.POINTER(RnnDesc)]),
+    'dep_rnn_reserve_y_offset': (C.c_size_t, [C.POINTER(RnnDesc), C.c_int]),
+    'dep_rnn_reserve_ydrop_offset': (C.c_size_t, [C.POINTER(RnnDesc), C.c_int]),
+    'dep_rnn_forward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    'dep_rnn_backward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, C.POINTER(_P), _P, _P,
+                                   C.c_size_t, _P, C.c_size_t, _P]),
+    'dep_gemm_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
+    'dep_gemm_f32': (C.c_int, [C.c_int] * 5 + [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_float, C.c_int, C.c_int,
+                               _P, C.c_size_t, _P]),
+    'dep_layernorm_fwd': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
+    'dep_layernorm_bwd_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'dep_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    'dep_attn_fwd': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    'dep_attn_bwd_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'dep_attn_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P,
+                               C.c_size_t, _P]),
+    'dep_dropout': (C.c_int, [_P, _P, C.c_long, C.c_float, C.c_uint64, C.c_uint32, _P]),
+    'dep_dropout_mask': (C.c_int, [_P, C.c_long, C.c_float, C.c_uint64, C.c_uint32, _P]),
+    'dep_relu_dropout_fwd': (C.c_int, [_P, _P, C.c_long, C.c_float, C.c_uint64, C.c_uint32, _P]),
+    'dep_relu_dropout_bwd': (C.c_int, [_P, _P, _P, C.c_long, C.c_float, C.c_uint64, C.c_uint32, _P]),
+    'dep_colsum': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'dep_head_loss': (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
+    'dep_reduce_loss': (C.c_int, [_P, C.c_int, C.c_float, _P, C.c_int, _P]),
+    'dep_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_int, C.c_int, _P]),
+    'dep_fill': (C.c_int, [_P, C.c_long, C.c_float, _P]),
+    'dep_axpby': (C.c_int, [_P, _P, C.c_long, C.c_float, C.c_float, _P]),
+    'dep_sigmoid_gate': (C.c_int, [_P, _P, _P, C.c_long, _P]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises DepError loudly if it is absent -- no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DepError(f'{LIB_PATH} not found: build it with `python icassp2022-depression_amd/build_ext.py` '
+                       '(hipcc --offload-arch=gfx950). The HIP path has no fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    assert t.is_cuda, 'device tensor expected'
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DepError(f'{what} failed ({rc}): {load().dep_last_error().decode()}')
+
+
+def f32(t):
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    return t
+
+
+# ----------------------------------------------------------------------------- thin wrappers
+def gemm(transA, transB, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, beta=0.0, seq_T=0, shiftB=0, ws=None):
+    lib = load()
+    wsb = ws.numel() * ws.element_size() if ws is not None else 0
+    check(lib.dep_gemm_f32(transA, transB, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(Cm), ldc, _ptr(bias), beta,
+                           seq_T, shiftB, _ptr(ws), wsb, stream()), 'dep_gemm_f32')
+
+
+def gemm_ws(transA, transB, M, N, K, device):
+    n = load().dep_gemm_workspace_bytes(transA, transB, M, N, K)
+    return torch.empty(max(n, 16) // 4, dtype=torch.float32, device=device)
+
+
+def linear_fwd(x, W, b, out=None):
+    """out (M,N) = x (M,K) @ W (N,K)^T + b"""
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    gemm(0, 1, M, N, K, x, x.stride(0), W, W.stride(0), out, out.stride(0), bias=b)
+    return out
+
+
+def layernorm_fwd(x2d, gamma, beta, eps=1e-5, save=True):
+    rows, F = x2d.shape
+    y = torch.empty_like(x2d)
+    mr = torch.empty(rows, 2, dtype=torch.float32, device=x2d.device) if save else None
+    check(load().dep_layernorm_fwd(_ptr(x2d), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mr), rows, F, eps, stream()),
+          'dep_layernorm_fwd')
+    return y, mr
+
+
+def layernorm_bwd(dy2d, x2d, gamma, mr, dgamma, dbeta, want_dx=False):
+    rows, F = x2d.shape
+    lib = load()
+    ws = torch.empty(lib.dep_layernorm_bwd_workspace_bytes(rows, F) // 4, dtype=torch.float32, device=x2d.device)
+    dx = torch.empty_like(x2d) if want_dx else None
+    check(lib.dep_layernorm_bwd(_ptr(dy2d), _ptr(x2d), _ptr(gamma), _ptr(mr), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                rows, F, _ptr(ws), ws.numel() * 4, stream()), 'dep_layernorm_bwd')
+    return dx
+
+
+def dropout(x, y, p, seed, site):
+    check(load().dep_dropout(_ptr(x), _ptr(y), x.numel(), p, seed, site, stream()), 'dep_dropout')
+
+
+def dropout_mask(n, p, seed, site, device):
+    m = torch.empty(n, dtype=torch.float32, device=device)
+    check(load().dep_dropout_mask(_ptr(m), n, p, seed, site, stream()), 'dep_dropout_mask')
+    return m
+
+
+def relu_dropout_fwd(z, a, p, seed, site):
+    check(load().dep_relu_dropout_fwd(_ptr(z), _ptr(a), z.numel(), p, seed, site, stream()), 'dep_relu_dropout_fwd')
+
+
+def relu_dropout_bwd(da, z, dz, p, seed, site):
+    check(load().dep_relu_dropout_bwd(_ptr(da), _ptr(z), _ptr(dz), z.numel(), p, seed, site, stream()),
+          'dep_relu_dropout_bwd')
+
+
+def colsum(x2d, out):
+    M, N = x2d.shape
+    check(load().dep_colsum(_ptr(x2d), M, N, x2d.stride(0), _ptr(out), stream()), 'dep_colsum')
+
+
+def head_loss(kind, z, target, out, loss_rows, dz, norm):
+    B, Cc = z.shape
+    check(load().dep_head_loss(kind, _ptr(z), _ptr(target), _ptr(out), _ptr(loss_rows), _ptr(dz), B, Cc, float(norm),
+                               stream()), 'dep_head_loss')
+
+
+def reduce_loss(loss_rows, norm, loss_out, accumulate=False):
+    check(load().dep_reduce_loss(_ptr(loss_rows), loss_rows.numel(), float(norm), _ptr(loss_out), int(accumulate),
+                                 stream()), 'dep_reduce_loss')
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, wd, decoupled, step):
+    check(load().dep_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, b1, b2, eps, wd, int(decoupled),
+                               int(step), stream()), 'dep_adam_step')
+
+
+def fill(t, value):
+    check(load().dep_fill(_ptr(t), t.numel(), float(value), stream()), 'dep_fill')
+
+
+def axpby(x, y, a, b):
+    check(load().dep_axpby(_ptr(x), _ptr(y), x.numel(), float(a), float(b), stream()), 'dep_axpby')
+
+
+def sigmoid_gate(g, x, y):
+    check(load().dep_sigmoid_gate(_ptr(g), _ptr(x), _ptr(y), x.numel(), stream()), 'dep_sigmoid_gate')
+
+
+def attn_fwd(out, h_n, Wa, ba):
+    B, T, H2 = out.shape
+    H = H2 // 2
+    K = h_n.shape[0]
+    dev = out.device
+    ctx = torch.empty(B, H, dtype=torch.float32, device=dev)
+    alpha = torch.empty(B, T, dtype=torch.float32, device=dev)
+    pre = torch.empty(B, H, dtype=torch.float32, device=dev)
+    hsum = torch.empty(B, H, dtype=torch.float32, device=dev)
+    check(load().dep_attn_fwd(_ptr(out), _ptr(h_n), K, _ptr(Wa), _ptr(ba), _ptr(ctx), _ptr(alpha), _ptr(pre),
+                              _ptr(hsum), B, T, H, stream()), 'dep_attn_fwd')
+    return ctx, (alpha, pre, hsum)
+
+
+def attn_bwd(dctx, out, Wa, saved, K, dWa, dba):
+    alpha, pre, hsum = saved
+    B, T, H2 = out.shape
+    H = H2 // 2
+    lib = load()
+    dev = out.device
+    dout = torch.empty_like(out)
+    dh_n = torch.empty(K, B, H, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.dep_attn_bwd_workspace_bytes(B, T, H) // 4 + 64, dtype=torch.float32, device=dev)
+    check(lib.dep_attn_bwd(_ptr(dctx), _ptr(out), _ptr(Wa), _ptr(alpha), _ptr(pre), _ptr(hsum), K, _ptr(dout),
+                           _ptr(dh_n), _ptr(dWa), _ptr(dba), B, T, H, _ptr(ws), ws.numel() * 4, stream()),
+          'dep_attn_bwd')
+    return dout, dh_n
+
+
+class Rnn:
+    """One dep_rnn_desc + its reserve/workspace buffers (allocated once per shape, reused per step)."""
+
+    def __init__(self, cell, B, T, F, H, L, dirs, training, dropout_p, pool, device, impl=0):
+        self.lib = load()
+        self.desc = RnnDesc(cell, B, T, F, H, L, dirs, int(training), float(dropout_p), 0, pool, impl)
+        self.device = device
+        rb = self.lib.dep_rnn_reserve_bytes(C.byref(self.desc))
+        wb = self.lib.dep_rnn_workspace_bytes(C.byref(self.desc))
+        if rb == 0 or wb == 0:
+            raise DepError(f'bad rnn descriptor: {cell=} {B=} {T=} {F=} {H=} {L=} {dirs=}')
+        self.reserve = torch.empty(rb // 4, dtype=torch.float32, device=device)
+        self.workspace = torch.empty(wb // 4, dtype=torch.float32, device=device)
+        self.n_w = 4 * L * dirs
+        self._warr = (_P * self.n_w)()
+        self._garr = (_P * self.n_w)()
+
+    def layer_output(self, layer=None):
+        """Zero-copy view of a layer's output sequence (B,T,H*dirs) inside the reserve."""
+        d = self.desc
+        layer = d.L - 1 if layer is None else layer
+        off = self.lib.dep_rnn_reserve_y_offset(C.byref(d), layer) // 4
+        n = d.B * d.T * d.H * d.dirs
+        return self.reserve[off:off + n].view(d.B, d.T, d.H * d.dirs)
+
+    def layer_output_dropped(self, layer):
+        d = self.desc
+        off = self.lib.dep_rnn_reserve_ydrop_offset(C.byref(d), layer)
+        if off == C.c_size_t(-1).value:
+            return None
+        off //= 4
+        n = d.B * d.T * d.H * d.dirs
+        return self.reserve[off:off + n].view(d.B, d.T, d.H * d.dirs)
+
+    def forward(self, x, weights, seed=0, pooled=None, h_n=None, y=None):
+        for i, w in enumerate(weights):
+            self._warr[i] = w.data_ptr()
+        self.desc.seed = seed
+        check(self.lib.dep_rnn_forward(C.byref(self.desc), _ptr(x), self._warr, _ptr(y), _ptr(pooled), _ptr(h_n),
+                                       _ptr(self.reserve), self.reserve.numel() * 4, _ptr(self.workspace),
+                                       self.workspace.numel() * 4, stream()), 'dep_rnn_forward')
+
+    def backward(self, x, weights, dweights, dy=None, dpooled=None, dh_n=None, dx=None):
+        for i, (w, g) in enumerate(zip(weights, dweights)):
+            self._warr[i] = w.data_ptr()
+            self._garr[i] = g.data_ptr()
+        check(self.lib.dep_rnn_backward(C.byref(self.desc), _ptr(x), self._warr, _ptr(dy), _ptr(dpooled), _ptr(dh_n),
+                                        self._garr, _ptr(dx), _ptr(self.reserve), self.reserve.numel() * 4,
+                                        _ptr(self.workspace), self.workspace.numel() * 4, stream()),
+              'dep_rnn_backward')

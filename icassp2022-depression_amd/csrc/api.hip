@@ -1,0 +1,259 @@
+// C-ABI orchestration of the stacked GRU / BiLSTM operator (dep_rnn_forward / dep_rnn_backward):
+// per layer  [pack W_hh] -> input-projection GEMM -> persistent sweep ; backward mirrors it.
+// See include/dep_rnn.h for the contract and the reference call sites each entry replaces.
+#include <stdarg.h>
+#include <string.h>
+#include "dep_common.h"
+
+static thread_local char g_err[512] = "";
+
+void dep_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* dep_last_error(void) { return g_err; }
+extern "C" int dep_version(void) { return 100; }
+extern "C" const char* dep_arch(void) { return "gfx950"; }
+
+namespace {
+
+constexpr int MAXL = 8;
+
+struct Layout {
+    int G, D, L;
+    size_t BT;                       // B*T rows
+    // reserve (float offsets)
+    size_t y[MAXL], ydrop[MAXL], sv[MAXL][4], wp[MAXL][2], wpT[MAXL][2];
+    size_t reserve_floats;
+    // workspace (float offsets)
+    size_t gi, dghn, dx[2], dbpart, biastmp, gemm;
+    size_t gemm_bytes, ws_floats;
+    int nwg;
+    bool drop;
+};
+
+bool make_layout(const dep_rnn_desc* d, Layout& lo) {
+    if (!d || d->B <= 0 || d->T <= 0 || d->F <= 0 || d->H <= 0 || d->L < 1 || d->L > MAXL) return false;
+    if (d->cell == DEP_CELL_GRU) { if (d->dirs != 1) return false; }
+    else if (d->cell == DEP_CELL_LSTM) { if (d->dirs != 1 && d->dirs != 2) return false; }
+    else return false;
+    if (d->dropout_p < 0.f || d->dropout_p >= 1.f) return false;
+    lo.G = d->cell == DEP_CELL_GRU ? 3 : 4; lo.D = d->dirs; lo.L = d->L;
+    lo.BT = (size_t)d->B * d->T;
+    lo.drop = d->training && d->dropout_p > 0.f;
+    const size_t H = d->H, D = d->dirs, G = lo.G;
+    auto al = [](size_t f) { return (f + 63) / 64 * 64; };
+    size_t off = 0;
+    for (int l = 0; l < d->L; ++l) {
+        lo.y[l] = off; off += al(lo.BT * D * H);
+        lo.ydrop[l] = off; if (lo.drop && l < d->L - 1) off += al(lo.BT * D * H);
+        if (d->training) {
+            if (d->cell == DEP_CELL_GRU) { for (int k = 0; k < 4; ++k) { lo.sv[l][k] = off; off += al(lo.BT * H); } }
+            else { lo.sv[l][0] = off; off += al(lo.BT * D * 4 * H); lo.sv[l][1] = off; off += al(lo.BT * D * H); lo.sv[l][2] = lo.sv[l][3] = 0; }
+        }
+        for (size_t dd = 0; dd < D; ++dd) {
+            lo.wp[l][dd] = off; off += al(G * H * H);
+            lo.wpT[l][dd] = off; off += al(G * H * H);
+        }
+    }
+    lo.reserve_floats = off;
+    // workspace
+    lo.nwg = dep_sweep_num_wg(d->B, d->H, d->impl);
+    size_t w = 0;
+    lo.gi = w; w += al(lo.BT * D * G * H);                 // GI (fwd) / dGI (bwd)
+    lo.dghn = w; w += al(lo.BT * H);
+    const size_t maxin = D * H > (size_t)d->F ? D * H : (size_t)d->F;
+    lo.dx[0] = w; w += al(lo.BT * D * H);
+    lo.dx[1] = w; w += al(lo.BT * D * H);
+    (void)maxin;
+    lo.dbpart = w; w += al((size_t)D * lo.nwg * 4 * H);
+    lo.biastmp = w; w += al(G * H);
+    // split-K scratch: the largest weight-gradient contraction
+    size_t gb = 0;
+    {
+        const int Ks[2] = {d->F, (int)(D * H)};
+        for (int i = 0; i < 2; ++i) {
+            size_t b1 = dep_gemm_workspace_bytes(1, 0, (int)(G * H), Ks[i], (int)lo.BT);
+            if (b1 > gb) gb = b1;
+        }
+        size_t b2 = dep_gemm_workspace_bytes(1, 0, (int)(G * H), (int)H, (int)lo.BT);
+        if (b2 > gb) gb = b2;
+    }
+    lo.gemm = w; lo.gemm_bytes = gb; w += al(gb / sizeof(float) + 64);
+    lo.ws_floats = w;
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t dep_rnn_reserve_bytes(const dep_rnn_desc* d) {
+    Layout lo;
+    if (!make_layout(d, lo)) return 0;
+    return lo.reserve_floats * sizeof(float);
+}
+extern "C" size_t dep_rnn_workspace_bytes(const dep_rnn_desc* d) {
+    Layout lo;
+    if (!make_layout(d, lo)) return 0;
+    return lo.ws_floats * sizeof(float);
+}
+// byte offset of layer l's output sequence (B,T,H*dirs) inside the reserve (zero-copy access for the caller)
+extern "C" size_t dep_rnn_reserve_y_offset(const dep_rnn_desc* d, int layer) {
+    Layout lo;
+    if (!make_layout(d, lo) || layer < 0 || layer >= d->L) return (size_t)-1;
+    return lo.y[layer] * sizeof(float);
+}
+extern "C" size_t dep_rnn_reserve_ydrop_offset(const dep_rnn_desc* d, int layer) {
+    Layout lo;
+    if (!make_layout(d, lo) || layer < 0 || layer >= d->L - 1 || !lo.drop) return (size_t)-1;
+    return lo.ydrop[layer] * sizeof(float);
+}
+
+extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const float* const* weights, float* y,
+                               float* pooled, float* h_n, void* reserve, size_t reserve_bytes, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    Layout lo;
+    DEP_CHECK_ARG(make_layout(d, lo));
+    DEP_CHECK_ARG(x && weights && reserve && workspace);
+    DEP_CHECK_ARG(!(pooled && (d->cell != DEP_CELL_GRU || d->pool == DEP_POOL_NONE)));
+    if (reserve_bytes < lo.reserve_floats * sizeof(float) || workspace_bytes < lo.ws_floats * sizeof(float)) {
+        dep_set_error("dep_rnn_forward: reserve/workspace too small (%zu/%zu given, %zu/%zu needed)", reserve_bytes,
+                      workspace_bytes, lo.reserve_floats * sizeof(float), lo.ws_floats * sizeof(float));
+        return DEP_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* R = (float*)reserve; float* W = (float*)workspace;
+    const int B = d->B, T = d->T, H = d->H, D = d->dirs, G = lo.G, L = d->L;
+    const int BTr = (int)lo.BT;
+    const bool mfma = dep_sweep_use_mfma(H, d->impl);
+    int rc;
+    for (int l = 0; l < L; ++l) {
+        const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
+        const int Kl = l == 0 ? d->F : D * H;
+        float* gi = W + lo.gi;
+        for (int dd = 0; dd < D; ++dd) {
+            const float* const* wl = weights + (size_t)(l * D + dd) * 4;
+            DEP_CHECK_ARG(wl[0] && wl[1] && wl[2] && wl[3]);
+            if (mfma) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
+            const float* bias = wl[2];
+            if (d->cell == DEP_CELL_LSTM) {          // both biases fold into the projection
+                float* tb = W + lo.biastmp;
+                rc = dep_axpby(wl[2], tb, (long)G * H, 1.f, 0.f, s); if (rc) return rc;
+                rc = dep_axpby(wl[3], tb, (long)G * H, 1.f, 1.f, s); if (rc) return rc;
+                bias = tb;
+            }
+            rc = dep_gemm_internal(0, 1, BTr, G * H, Kl, in, Kl, wl[0], Kl, gi + (size_t)dd * G * H, D * G * H, bias,
+                                   0.f, 0, 0, nullptr, 0, s);
+            if (rc) return rc;
+            // the bias scratch is reused by the next direction: stream order keeps this safe
+        }
+        dep_sweep_args a{};
+        a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.training = d->training; a.impl = d->impl;
+        for (int dd = 0; dd < D; ++dd) {
+            const float* const* wl = weights + (size_t)(l * D + dd) * 4;
+            a.w_hh[dd] = wl[1]; a.b_hh[dd] = wl[3]; a.wp[dd] = R + lo.wp[l][dd];
+        }
+        a.gi = gi; a.y = R + lo.y[l]; a.ldy = D * H;
+        const bool dropl = lo.drop && l < L - 1;
+        a.ydrop = dropl ? R + lo.ydrop[l] : nullptr;
+        a.drop_p = dropl ? d->dropout_p : 0.f; a.seed = d->seed; a.site = DEP_SITE_RNN0 + l;
+        const bool top = l == L - 1;
+        a.pooled = (top && pooled) ? pooled : nullptr;
+        a.pool_scale = d->pool == DEP_POOL_MEAN ? 1.0f / (float)T : 1.0f;
+        a.h_n = h_n ? h_n + (size_t)l * D * B * H : nullptr;
+        if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
+        a.stream = s;
+        rc = dep_launch_sweep_fwd(a);
+        if (rc) return rc;
+    }
+    if (y) {
+        rc = dep_axpby(R + lo.y[L - 1], y, (long)lo.BT * D * H, 1.f, 0.f, s);
+        if (rc) return rc;
+    }
+    return DEP_OK;
+}
+
+extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const float* const* weights, const float* dy,
+                                const float* dpooled, const float* dh_n, float* const* dweights, float* dx,
+                                void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    Layout lo;
+    DEP_CHECK_ARG(make_layout(d, lo));
+    DEP_CHECK_ARG(d->training);
+    DEP_CHECK_ARG(x && weights && dweights && reserve && workspace);
+    DEP_CHECK_ARG(dy || dpooled || dh_n);
+    DEP_CHECK_ARG(!(dpooled && (d->cell != DEP_CELL_GRU || d->pool == DEP_POOL_NONE)));
+    if (reserve_bytes < lo.reserve_floats * sizeof(float) || workspace_bytes < lo.ws_floats * sizeof(float)) {
+        dep_set_error("dep_rnn_backward: reserve/workspace too small");
+        return DEP_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* R = (float*)reserve; float* W = (float*)workspace;
+    const int B = d->B, T = d->T, H = d->H, D = d->dirs, G = lo.G, L = d->L;
+    const int BTr = (int)lo.BT;
+    void* gws = W + lo.gemm; const size_t gwsb = lo.gemm_bytes;
+    int rc;
+    for (int l = L - 1; l >= 0; --l) {
+        const bool top = l == L - 1;
+        const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
+        const int Kl = l == 0 ? d->F : D * H;
+        float* dgi = W + lo.gi;
+        dep_sweep_bwd_args a{};
+        a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.impl = d->impl;
+        for (int dd = 0; dd < D; ++dd) {
+            const float* const* wl = weights + (size_t)(l * D + dd) * 4;
+            a.w_hh[dd] = wl[1]; a.wpT[dd] = R + lo.wpT[l][dd];
+        }
+        a.y = R + lo.y[l]; a.ldy = D * H;
+        if (top) { a.dy = dy; a.drop_p = 0.f; }
+        else { a.dy = W + lo.dx[(l + 1) & 1]; a.drop_p = lo.drop ? d->dropout_p : 0.f; }
+        a.lddy = D * H; a.seed = d->seed; a.site = DEP_SITE_RNN0 + l;
+        a.dpooled = top ? dpooled : nullptr;
+        a.pool_scale = d->pool == DEP_POOL_MEAN ? 1.0f / (float)T : 1.0f;
+        a.dh_n = dh_n ? dh_n + (size_t)l * D * B * H : nullptr;
+        a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3];
+        a.dgi = dgi; a.dghn = W + lo.dghn; a.dbpart = W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
+        rc = dep_launch_sweep_bwd(a);
+        if (rc) return rc;
+        float* dbi[2]; float* dbh[2];
+        for (int dd = 0; dd < D; ++dd) {
+            float* const* gl = dweights + (size_t)(l * D + dd) * 4;
+            DEP_CHECK_ARG(gl[0] && gl[1] && gl[2] && gl[3]);
+            dbi[dd] = gl[2]; dbh[dd] = gl[3];
+        }
+        rc = dep_finish_db(a, dbi, dbh);
+        if (rc) return rc;
+        float* dxl = l == 0 ? dx : W + lo.dx[l & 1];
+        for (int dd = 0; dd < D; ++dd) {
+            const float* const* wl = weights + (size_t)(l * D + dd) * 4;
+            float* const* gl = dweights + (size_t)(l * D + dd) * 4;
+            const float* dg = dgi + (size_t)dd * G * H;
+            const int ldg = D * G * H;
+            // dW_ih (G*H, Kl) = dG^T * in
+            rc = dep_gemm_internal(1, 0, G * H, Kl, BTr, dg, ldg, in, Kl, gl[0], Kl, nullptr, 0.f, 0, 0, gws, gwsb, s);
+            if (rc) return rc;
+            // dW_hh (G*H, H) = dGH^T * h_prev   (h_prev = layer output shifted by one step along the sweep)
+            const float* yl = R + lo.y[l] + (size_t)dd * H;
+            const int shift = dd == 0 ? -1 : 1;
+            if (d->cell == DEP_CELL_GRU) {
+                rc = dep_gemm_internal(1, 0, 2 * H, H, BTr, dg, ldg, yl, D * H, gl[1], H, nullptr, 0.f, T, shift, gws, gwsb, s);
+                if (rc) return rc;
+                rc = dep_gemm_internal(1, 0, H, H, BTr, W + lo.dghn, H, yl, D * H, gl[1] + (size_t)2 * H * H, H, nullptr,
+                                       0.f, T, shift, gws, gwsb, s);
+                if (rc) return rc;
+            } else {
+                rc = dep_gemm_internal(1, 0, 4 * H, H, BTr, dg, ldg, yl, D * H, gl[1], H, nullptr, 0.f, T, shift, gws, gwsb, s);
+                if (rc) return rc;
+            }
+            // dX (B*T, Kl) (+)= dG * W_ih
+            if (dxl) {
+                rc = dep_gemm_internal(0, 0, BTr, Kl, G * H, dg, ldg, wl[0], Kl, dxl, Kl, nullptr, dd == 0 ? 0.f : 1.f, 0, 0,
+                                       nullptr, 0, s);
+                if (rc) return rc;
+            }
+        }
+    }
+    return DEP_OK;
+}

@@ -1,0 +1,125 @@
+// Internal helpers shared by the gfx950 kernels of libdep_rnn.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dep_rnn.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void dep_set_error(const char* fmt, ...);
+
+#define DEP_CHECK_ARG(cond)                                                          \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            dep_set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond);     \
+            return DEP_ERR_ARG;                                                      \
+        }                                                                            \
+    } while (0)
+
+#define DEP_CHECK_LAUNCH()                                                           \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            dep_set_error("%s:%d: HIP: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return DEP_ERR_HIP;                                                      \
+        }                                                                            \
+    } while (0)
+
+static inline size_t dep_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int dep_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device math ------------------------------------------------------------------
+__device__ __forceinline__ float dep_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- Philox4x32-10 counter-based RNG (dropout masks) --------------------------------
+// key = seed ; counter = (group index lo, hi, site, 0).  One call yields the 4 uniforms of the
+// 4-element group `g4` (element indices 4*g4 .. 4*g4+3) of dropout site `site`.
+__device__ __forceinline__ void dep_philox4(uint64_t seed, uint32_t site, uint64_t g4, uint32_t (&r)[4]) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)g4, c1 = (uint32_t)(g4 >> 32), c2 = site, c3 = 0x2545F491u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+// pre-scaled keep mask (0 or 1/(1-p)) for the 4 elements of group g4
+__device__ __forceinline__ f32x4 dep_dropmask4(uint64_t seed, uint32_t site, uint64_t g4, float p, float scale) {
+    uint32_t r[4];
+    dep_philox4(seed, site, g4, r);
+    f32x4 m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float u = (float)(r[i] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+        m[i] = (u >= p) ? scale : 0.0f;
+    }
+    return m;
+}
+__device__ __forceinline__ float dep_dropmask1(uint64_t seed, uint32_t site, uint64_t idx, float p, float scale) {
+    const f32x4 m = dep_dropmask4(seed, site, idx >> 2, p, scale);
+    return m[idx & 3];
+}
+
+// dropout sites (Philox counter word 2): distinct per place a mask is drawn in one step
+enum { DEP_SITE_RNN0 = 16 /* + layer */, DEP_SITE_USER = 0 };
+
+// ---- internal launchers shared across translation units ---------------------------
+struct dep_sweep_args {
+    int B, T, H;
+    int cell, dirs;          // GRU: dirs = 1
+    int training;
+    int impl;
+    // per direction d (LSTM) / single (GRU)
+    const float* w_hh[2];    // (G*H, H) row-major
+    const float* b_hh[2];    // (G*H)  GRU only (LSTM biases are folded into GI by the GEMM)
+    const float* wp[2];      // packed fragment-order copies (MFMA path), see pack kernels
+    // activations
+    const float* gi;         // (B,T,dirs*G*H): input projection incl. bias_ih (LSTM: + bias_hh)
+    float* y;  int ldy;      // (B,T,ldy) hidden sequence; direction d writes columns [d*H,(d+1)*H)
+    float* ydrop;            // same layout: dropout(y) for the next layer, or NULL
+    float drop_p; uint64_t seed; uint32_t site;
+    float* pooled; float pool_scale;    // GRU top layer: (B,H) sum_t h_t * scale, or NULL
+    float* h_n;              // (dirs,B,H) final states or NULL
+    // reserve (training): GRU r,z,n,hn each (B,T,H) ; LSTM gates (B,T,dirs*4H) + c (B,T,dirs*H)
+    float* sv0; float* sv1; float* sv2; float* sv3;
+    hipStream_t stream;
+};
+int dep_launch_sweep_fwd(const dep_sweep_args& a);
+
+struct dep_sweep_bwd_args {
+    int B, T, H;
+    int cell, dirs;
+    int impl;
+    const float* w_hh[2];
+    const float* wpT[2];     // packed transposed copies (MFMA path)
+    const float* y; int ldy; // forward hidden sequence of this layer (h_{t-1} operand)
+    const float* dy; int lddy;           // (B,T,lddy) grad of y (columns [d*H,(d+1)*H) per direction) or NULL
+    float drop_p; uint64_t seed; uint32_t site;   // dropout applied to dy on load (p == 0: none)
+    const float* dpooled; float pool_scale;       // GRU top layer or NULL
+    const float* dh_n;       // (dirs,B,H) or NULL
+    const float* sv0; const float* sv1; const float* sv2; const float* sv3;
+    float* dgi;              // (B,T,dirs*G*H) written: grad of the input projection
+    float* dghn;             // GRU: (B,T,H) grad of the n-gate recurrent pre-activation (dn*r)
+    float* dbpart;           // partial bias sums, see dep_sweep_dbpart_floats
+    int dbpart_rows;         // number of partial rows provided
+    hipStream_t stream;
+};
+int dep_launch_sweep_bwd(const dep_sweep_bwd_args& a);
+int dep_sweep_num_wg(int B, int H, int impl);       // batch tiles (rows of dbpart) per direction
+bool dep_sweep_use_mfma(int H, int impl);
+
+// packed weight sizes / kernels (MFMA path)
+size_t dep_pack_floats(int G, int H);               // floats of one packed (G*H x H) matrix
+int dep_pack_whh(const float* w_hh, float* wp, float* wpT, int G, int H, hipStream_t s);
+// bias-gradient finish: sums partial rows
+int dep_finish_db(const dep_sweep_bwd_args& a, float* const* db_ih, float* const* db_hh);
+
+int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                      const float* B, int ldb, float* C, int ldc, const float* bias, float beta,
+                      int seq_T, int shiftB, void* ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,276 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32
+// accumulate == an fmaf chain), LDS-tiled 128x128x32, 4 waves of 64x64, register-staged prefetch.
+//
+//   C[M,N] = opA(A)[M,K] * opB(B)[K,N] + bias[N] + beta*C
+//
+// Used for every time-parallel contraction of the hot path: the input projections x_t W_ih^T of
+// nn.GRU / nn.LSTM (Classification/audio_gru_whole.py:105, text_bilstm_whole.py:105), the
+// nn.Linear layers of the heads (audio_gru_whole.py:67,70) and, in backward, dX = dG W and the
+// weight gradients dW = dG^T X (split-K over the B*T rows, deterministic two-pass reduction).
+#include "dep_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int LD_K = 129;   // LDS leading dim for operands loaded K-contiguous (scalar transposing stores)
+constexpr int LD_M = 132;   // LDS leading dim for operands loaded MN-contiguous (16-B vector stores)
+
+struct GemmP {
+    int M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const float* bias; float beta;
+    int seqT, shiftB;
+    int kchunk, splits;
+    float* part;            // split-K partials [splits][M][N] or nullptr
+};
+
+// Load one (128 x 32) operand tile into registers.  TR = operand stored MN-contiguous.
+template <bool TR, bool VEC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int mn0, int MN, int k0,
+                                          int Kend, int tid, float (&r)[4][4], int seqT, int shift) {
+    if (!TR) {   // element (mn,k) at P[mn*ld + k]
+        const int kq = tid & 7, rr = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mn = mn0 + rr + 32 * i, k = k0 + kq * 4;
+            const float* src = P + (size_t)mn * ld + k;
+            if (VEC) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (mn < MN && k < Kend) v = *reinterpret_cast<const f32x4*>(src);
+                r[i][0] = v[0]; r[i][1] = v[1]; r[i][2] = v[2]; r[i][3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i][e] = (mn < MN && k + e < Kend) ? src[e] : 0.f;
+            }
+        }
+    } else {     // element (mn,k) at P[(k+shift)*ld + mn]
+        const int mq = tid & 31, kr = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + kr + 8 * i, mn = mn0 + mq * 4;
+            bool ok = k < Kend;
+            if (seqT > 0) { const int tt = k % seqT + shift; ok = ok && tt >= 0 && tt < seqT; }
+            const float* src = P + ((long)k + shift) * ld + mn;
+            if (VEC) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok && mn < MN) v = *reinterpret_cast<const f32x4*>(src);
+                r[i][0] = v[0]; r[i][1] = v[1]; r[i][2] = v[2]; r[i][3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i][e] = (ok && mn + e < MN) ? src[e] : 0.f;
+            }
+        }
+    }
+}
+
+template <bool TR>
+__device__ __forceinline__ void store_tile(float* S, int tid, const float (&r)[4][4]) {
+    if (!TR) {
+        const int kq = tid & 7, rr = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * LD_K + rr + 32 * i] = r[i][e];
+    } else {
+        const int mq = tid & 31, kr = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = {r[i][0], r[i][1], r[i][2], r[i][3]};
+            *reinterpret_cast<f32x4*>(&S[(kr + 8 * i) * LD_M + mq * 4]) = v;
+        }
+    }
+}
+
+// TA: A stored (K,M) ; TB: B stored (N,K)  [note the asymmetry, matches the public API]
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(NT) void gemm_mfma(GemmP p) {
+    constexpr bool A_TR = TA;        // A MN-contiguous when stored (K,M)
+    constexpr bool B_TR = !TB;       // B MN-contiguous when stored (K,N)
+    constexpr int LDA_S = A_TR ? LD_M : LD_K;
+    constexpr int LDB_S = B_TR ? LD_M : LD_K;
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA_S + BK * LDB_S];
+    float* As = smem;
+    float* Bs = smem + BK * LDA_S;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float ra[4][4], rb[4][4];
+    load_tile<A_TR, VEC>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra, 0, 0);
+    load_tile<B_TR, VEC>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb, p.seqT, p.shiftB);
+
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        store_tile<A_TR>(As, tid, ra);
+        store_tile<B_TR>(Bs, tid, rb);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            load_tile<A_TR, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0);
+            load_tile<B_TR, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb, p.seqT, p.shiftB);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int kr = kk * 2 + half;
+            const float a0 = As[kr * LDA_S + wm * 64 + l31];
+            const float a1 = As[kr * LDA_S + wm * 64 + 32 + l31];
+            const float b0 = Bs[kr * LDB_S + wn * 64 + l31];
+            const float b1 = Bs[kr * LDB_S + wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: D[i][j]: j = lane&31 (n), i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (m)
+    const bool split = p.part != nullptr;
+    float* outp = split ? p.part + (size_t)blockIdx.z * p.M * p.N : p.C;
+    const int ldo = split ? p.N : p.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= p.N) continue;
+            const float bv = (!split && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < p.M) {
+                    float v = acc[i][j][e] + bv;
+                    float* dst = outp + (size_t)m * ldo + n;
+                    if (!split && p.beta != 0.f) v += p.beta * *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+__global__ void splitk_reduce(const float* __restrict__ part, int splits, int M, int N, float* C, int ldc,
+                              const float* bias, float beta) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += part[(size_t)z * M * N + idx];
+    if (bias) s += bias[n];
+    float* dst = C + (size_t)m * ldc + n;
+    if (beta != 0.f) s += beta * *dst;
+    *dst = s;
+}
+
+// Reference-quality fallback (any shape/alignment); selected with DEP_GEMM_NAIVE=1 for A/B checks.
+__global__ void gemm_naive(GemmP p, int TA, int TB) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (n >= p.N || m >= p.M) return;
+    float s = 0.f;
+    for (int k = 0; k < p.K; ++k) {
+        const float a = TA ? p.A[(size_t)k * p.lda + m] : p.A[(size_t)m * p.lda + k];
+        float b;
+        if (TB) {
+            b = p.B[(size_t)n * p.ldb + k];
+        } else {
+            bool ok = true;
+            if (p.seqT > 0) { const int tt = k % p.seqT + p.shiftB; ok = tt >= 0 && tt < p.seqT; }
+            b = ok ? p.B[((long)k + p.shiftB) * p.ldb + n] : 0.f;
+        }
+        s = fmaf(a, b, s);
+    }
+    if (p.bias) s += p.bias[n];
+    float* dst = p.C + (size_t)m * p.ldc + n;
+    if (p.beta != 0.f) s += p.beta * *dst;
+    *dst = s;
+}
+
+int choose_splits(int M, int N, int K) {
+    const long tiles = (long)dep_cdiv(M, BM) * dep_cdiv(N, BN);
+    if (tiles >= 256 || K < 1024) return 1;
+    long s = (768 + tiles - 1) / tiles;
+    const long maxs = K / 256;
+    if (s > maxs) s = maxs;
+    if (s > 128) s = 128;
+    return s < 1 ? 1 : (int)s;
+}
+
+bool naive_forced() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DEP_GEMM_NAIVE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+}  // namespace
+
+extern "C" size_t dep_gemm_workspace_bytes(int transA, int transB, int M, int N, int K) {
+    (void)transA; (void)transB;
+    const int s = choose_splits(M, N, K);
+    return s > 1 ? dep_align((size_t)s * M * N * sizeof(float)) : 0;
+}
+
+int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                      const float* B, int ldb, float* C, int ldc, const float* bias, float beta,
+                      int seq_T, int shiftB, void* ws, size_t ws_bytes, hipStream_t s) {
+    DEP_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C);
+    DEP_CHECK_ARG(!(transA && transB));
+    DEP_CHECK_ARG(!(seq_T > 0 && transB));
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, K, 1, nullptr};
+    if (naive_forced()) {
+        dim3 g(dep_cdiv(N, 128), M);
+        hipLaunchKernelGGL(gemm_naive, g, dim3(128), 0, s, p, transA, transB);
+        DEP_CHECK_LAUNCH();
+        return DEP_OK;
+    }
+    int splits = choose_splits(M, N, K);
+    if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float))) splits = 1;
+    int kchunk = K;
+    if (splits > 1) {
+        kchunk = dep_cdiv(dep_cdiv(K, splits), BK) * BK;
+        splits = dep_cdiv(K, kchunk);
+    }
+    p.kchunk = kchunk; p.splits = splits; p.part = splits > 1 ? (float*)ws : nullptr;
+    const bool a16 = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
+    const bool b16 = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+    // contiguous-dimension divisibility: K for K-contiguous operands, M/N for MN-contiguous ones
+    const bool adim = transA ? (M % 4 == 0) : (K % 4 == 0);
+    const bool bdim = transB ? (K % 4 == 0) : (N % 4 == 0);
+    const bool vec = a16 && b16 && adim && bdim;
+    dim3 g(dep_cdiv(N, BN), dep_cdiv(M, BM), splits);
+#define LAUNCH(TA, TB)                                                                     \
+    do {                                                                                   \
+        if (vec) hipLaunchKernelGGL((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \
+        else     hipLaunchKernelGGL((gemm_mfma<TA, TB, false>), g, dim3(NT), 0, s, p);     \
+    } while (0)
+    if (!transA && transB) LAUNCH(false, true);
+    else if (!transA && !transB) LAUNCH(false, false);
+    else LAUNCH(true, false);
+#undef LAUNCH
+    DEP_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long n = (long)M * N;
+        hipLaunchKernelGGL(splitk_reduce, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, p.part, splits, M, N, C, ldc,
+                           bias, beta);
+        DEP_CHECK_LAUNCH();
+    }
+    return DEP_OK;
+}
+
+extern "C" int dep_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                            const float* B, int ldb, float* C, int ldc, const float* bias, float beta,
+                            int seq_T, int shiftB, void* workspace, size_t workspace_bytes, void* stream) {
+    return dep_gemm_internal(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
+                             workspace, workspace_bytes, (hipStream_t)stream);
+}

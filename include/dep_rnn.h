@@ -1,0 +1,189 @@
+/*
+ * dep_rnn.h -- C-ABI of libdep_rnn.so: the MI355X (gfx950) operator library that replaces the
+ * PyTorch operator layer (torch.nn.GRU / LSTM / LayerNorm / Linear / Softmax / losses / Adam[W] +
+ * autograd) under the reference's five training scripts.
+ *
+ * The reference (speechandlanguageprocessing/ICASSP2022-Depression) has no FFI layer of its own:
+ * its boundary is the torch.nn operator contract used at the call sites cited on every entry
+ * point below (paths relative to DepressionCollected/).  A maintainer binds these entry points
+ * with ctypes; nothing torch-specific crosses the boundary.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (or int32 where stated), row-major, caller-owned;
+ *   - sequences are batch-first: row (b,t) of a (B,T,X) tensor sits at ((b*T + t) * ld);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - return 0 on success, negative dep_status on error; dep_last_error() returns a message;
+ *   - no allocation happens inside the library: workspace / reserve sizes come from the *_bytes
+ *     queries and the caller provides the buffers (16-byte aligned);
+ *   - gate order is PyTorch's: GRU r,z,n ; LSTM i,f,g,o ; h0 = c0 = 0 always.
+ */
+#ifndef DEP_RNN_H
+#define DEP_RNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    DEP_OK = 0,
+    DEP_ERR_ARG = -1,      /* bad argument (null pointer, size <= 0, unsupported combination) */
+    DEP_ERR_WORKSPACE = -2, /* workspace / reserve too small */
+    DEP_ERR_HIP = -3       /* a HIP call failed; see dep_last_error() */
+} dep_status;
+
+const char* dep_last_error(void);
+/* library/ABI version and compiled arch string ("gfx950") */
+int dep_version(void);
+const char* dep_arch(void);
+
+/* ------------------------------------------------------------------ descriptors ---- */
+enum { DEP_POOL_NONE = 0, DEP_POOL_MEAN = 1, DEP_POOL_SUM = 2 };
+enum { DEP_CELL_GRU = 0, DEP_CELL_LSTM = 1 };
+
+/* One stacked recurrent network: torch.nn.GRU(F,H,num_layers=L,dropout=p,batch_first=True)
+ * (Classification/audio_gru_whole.py:59-60) or torch.nn.LSTM(F,H,num_layers=L,dropout=p,
+ * bidirectional=True) (Classification/text_bilstm_whole.py:54-56). */
+typedef struct {
+    int32_t cell;        /* DEP_CELL_GRU | DEP_CELL_LSTM */
+    int32_t B, T, F, H;  /* batch, steps, input features, hidden units */
+    int32_t L;           /* stacked layers (>=1) */
+    int32_t dirs;        /* 1 (GRU, unidirectional) or 2 (bidirectional LSTM) */
+    int32_t training;    /* 1: keep the reserve for backward and apply inter-layer dropout */
+    float   dropout_p;   /* inter-layer dropout probability (applied to layers 0..L-2 outputs) */
+    uint64_t seed;       /* Philox key for this call's dropout masks */
+    int32_t pool;        /* GRU only: DEP_POOL_* over T of the top layer (fused in the sweep) */
+    int32_t impl;        /* 0 auto, 1 force generic (non-MFMA) kernels, 2 force MFMA kernels */
+} dep_rnn_desc;
+
+size_t dep_rnn_reserve_bytes(const dep_rnn_desc* d);     /* activations kept fwd -> bwd */
+size_t dep_rnn_workspace_bytes(const dep_rnn_desc* d);   /* scratch, either direction */
+/* Byte offset, inside the reserve, of layer `layer`'s output sequence (B,T,H*dirs) -- zero-copy
+ * access to `output` for the caller (attention reads it in place); (size_t)-1 on bad arguments. */
+size_t dep_rnn_reserve_y_offset(const dep_rnn_desc* d, int layer);
+/* Same for the dropped-out copy that feeds layer+1 (training && dropout_p > 0 only). */
+size_t dep_rnn_reserve_ydrop_offset(const dep_rnn_desc* d, int layer);
+
+/* ------------------------------------------------------------------ RNN stacks ----- */
+/* weights: array of 4*L*dirs device pointers ordered, for layer l and direction d (index
+ * (l*dirs+d)*4 + {0,1,2,3}): weight_ih (G*H, in), weight_hh (G*H, H), bias_ih (G*H), bias_hh (G*H),
+ * in = F for l = 0 else H*dirs; G = 3 (GRU) or 4 (LSTM)  -- the tensors of
+ * state_dict()['lstm_net_audio.weight_ih_l0'] ... / ['lstm_net.weight_ih_l0_reverse'] ...
+ *
+ * dep_rnn_forward replaces `x, _ = self.lstm_net_audio(x)` (audio_gru_whole.py:105) and
+ * `output, (h_n, _) = self.lstm_net(x)` (text_bilstm_whole.py:105).
+ *   x      (B,T,F)
+ *   y      (B,T,H*dirs) top-layer output, may be NULL when only `pooled` is wanted
+ *   pooled (B,H) mean/sum over T of the top layer (GRU, desc.pool != NONE), else NULL
+ *   h_n    (L*dirs, B, H) final hidden states ordered [l0_fwd, l0_bwd, l1_fwd, ...], may be NULL
+ */
+int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const float* const* weights,
+                    float* y, float* pooled, float* h_n,
+                    void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* Backward of dep_rnn_forward (what loss.backward() does through nn.GRU/nn.LSTM,
+ * audio_gru_whole.py:190).  Gradients are WRITTEN (not accumulated) to dweights (same order and
+ * shapes as weights).
+ *   dy      (B,T,H*dirs) grad of y, or NULL
+ *   dpooled (B,H) grad of pooled, or NULL  (the 1/T of a mean pool is applied inside)
+ *   dh_n    (L*dirs,B,H) grad of h_n, or NULL
+ *   dx      (B,T,F) grad of x, or NULL to skip it (the reference computes it but never uses it)
+ */
+int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const float* const* weights,
+                     const float* dy, const float* dpooled, const float* dh_n,
+                     float* const* dweights, float* dx,
+                     void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ------------------------------------------------------------------ dense --------- */
+/* C[M,N] = opA(A)[M,K] * opB(B)[K,N] + bias[N] + beta*C      (fp32 MFMA, exact f32 products)
+ *   transA = 0: A is (M,K) row-major ; 1: A is stored (K,M)
+ *   transB = 0: B is stored (K,N)    ; 1: B is stored (N,K)   [nn.Linear weight layout]
+ * Replaces nn.Linear forward/backward (audio_gru_whole.py:67,70) and the time-parallel
+ * input-projection / weight-gradient contractions inside nn.GRU / nn.LSTM.
+ * seq_T/shiftB: when seq_T > 0 and transB == 0, row r of B is read from row r+shiftB and is taken
+ * as zero when (r % seq_T)+shiftB falls outside [0,seq_T)  (h_{t-1} operand of dW_hh).
+ * workspace is needed for split-K (dep_gemm_workspace_bytes), may be NULL otherwise. */
+size_t dep_gemm_workspace_bytes(int transA, int transB, int M, int N, int K);
+int dep_gemm_f32(int transA, int transB, int M, int N, int K,
+                 const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                 const float* bias, float beta, int seq_T, int shiftB,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* nn.LayerNorm(F) over the last axis (audio_gru_whole.py:62,104). rows = B*T.
+ * mean_rstd: (rows,2) saved statistics (may be NULL in inference). */
+int dep_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                      float* mean_rstd, int rows, int F, float eps, void* stream);
+/* dgamma/dbeta are written; dx may be NULL (the reference never consumes it).
+ * workspace: dep_layernorm_bwd_workspace_bytes. */
+size_t dep_layernorm_bwd_workspace_bytes(int rows, int F);
+int dep_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean_rstd,
+                      float* dx, float* dgamma, float* dbeta, int rows, int F,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ attention ------ */
+/* attention_net_with_w (text_bilstm_whole.py:74-99).
+ *   out (B,T,2H), h_n (K,B,H), Wa (H,H), ba (H)  ->  ctx (B,H)
+ *   saved: alpha (B,T), pre (B,H) = Wa*sum_k(h_n)+ba, hsum (B,H)     [needed by the backward] */
+int dep_attn_fwd(const float* out, const float* h_n, int K, const float* Wa, const float* ba,
+                 float* ctx, float* alpha, float* pre, float* hsum, int B, int T, int H,
+                 void* stream);
+/*   dctx (B,H) -> dout (B,T,2H) written, dh_n (K,B,H) written, dWa (H,H), dba (H) written.
+ *   workspace: dep_attn_bwd_workspace_bytes. */
+size_t dep_attn_bwd_workspace_bytes(int B, int T, int H);
+int dep_attn_bwd(const float* dctx, const float* out, const float* Wa, const float* alpha,
+                 const float* pre, const float* hsum, int K,
+                 float* dout, float* dh_n, float* dWa, float* dba, int B, int T, int H,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ heads / losses - */
+/* Dropout as nn.Dropout(p) in training mode: y = x * m / (1-p), m ~ Bernoulli(1-p) from
+ * Philox4x32-10(seed, site, element index).  The same call on a gradient applies the same mask.
+ * p == 0 copies.  x may alias y.  */
+int dep_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint32_t site, void* stream);
+/* The pre-scaled mask itself (0 or 1/(1-p)), for tests that feed the oracle the same masks. */
+int dep_dropout_mask(float* mask, long n, float p, uint64_t seed, uint32_t site, void* stream);
+/* a = relu(z) then dropout (nn.ReLU + nn.Dropout, audio_gru_whole.py:68-69); z and a may alias. */
+int dep_relu_dropout_fwd(const float* z, float* a, long n, float p, uint64_t seed, uint32_t site, void* stream);
+/* dz = da * mask * (z > 0) */
+int dep_relu_dropout_bwd(const float* da, const float* z, float* dz, long n, float p, uint64_t seed,
+                         uint32_t site, void* stream);
+/* column sums of a (M,N) matrix (bias gradients): out[n] = sum_m x[m*ld+n] */
+int dep_colsum(const float* x, int M, int N, int ld, float* out, void* stream);
+
+enum { DEP_LOSS_CE_ON_SOFTMAX = 0, DEP_LOSS_L1_RELU = 1, DEP_LOSS_SMOOTHL1_RELU = 2, DEP_LOSS_CE_LOGITS = 3,
+       DEP_LOSS_SMOOTHL1 = 4 };
+/* Output nonlinearity + loss + its gradient w.r.t. the pre-activation z (B,C), one kernel:
+ *   CE_ON_SOFTMAX : out = softmax(z) ; loss = CrossEntropyLoss(out, y)  (double softmax,
+ *                   audio_gru_whole.py:72,188,308)              target = int32 labels
+ *   L1_RELU       : out = relu(z) ; L1Loss(out, y)   (audio_bilstm_perm.py:91,251)  target = float
+ *   SMOOTHL1_RELU : out = relu(z) ; SmoothL1Loss(out, y) (text_bilstm_perm.py:247)   target = float
+ *   CE_LOGITS / SMOOTHL1 : plain losses on z (MyLoss halves, fuse_net_whole.py:384-395)
+ * out (B,C) written; loss_rows (B) per-row loss; dz (B,C) = dLoss/dz with Loss = sum_rows / norm
+ * (norm = global batch size so that data-parallel shards sum to the reference's batch mean);
+ * dz may be NULL (evaluate); target may be NULL when dz and loss_rows are NULL (pure forward). */
+int dep_head_loss(int kind, const float* z, const void* target, float* out, float* loss_rows,
+                  float* dz, int B, int C, float norm, void* stream);
+/* loss = sum(loss_rows[0..B)) / norm, deterministic single-block tree; result on device. */
+int dep_reduce_loss(const float* loss_rows, int B, float norm, float* loss_out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ optimizer ------ */
+/* torch.optim.Adam / AdamW update on a contiguous parameter range (audio_gru_whole.py:307 AdamW
+ * with two weight-decay groups; audio_bilstm_perm.py:250 Adam).  step is the 1-based count. */
+int dep_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int decoupled, int step, void* stream);
+
+/* ------------------------------------------------------------------ misc ----------- */
+int dep_fill(float* p, long n, float value, void* stream);
+/* y = a*x + b*y */
+int dep_axpby(const float* x, float* y, long n, float a, float b, void* stream);
+/* sigmoid gating of the regression fusion head: y = sigmoid(g) * x (Regression/fuse_net.py:345-351) */
+int dep_sigmoid_gate(const float* g, const float* x, float* y, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEP_RNN_H */

@@ -1,0 +1,324 @@
+"""GPU parity tests of the C-ABI operators (through ctypes) against the numpy oracle.
+Run on the MI355X box:  python -m pytest tests -m gpu -q"""
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as R
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from icassp2022_depression_amd import _lib as L
+    DEV = torch.device('cuda:0')
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('tA,tB', [(0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize('M,N,K', [(300, 200, 64), (77, 45, 39), (128, 128, 32), (1, 5, 7), (513, 260, 100)])
+def test_gemm_shapes(tA, tB, M, N, K):
+    rng = np.random.default_rng(M * 7 + N * 3 + K + tA * 2 + tB)
+    A = rng.standard_normal((K, M) if tA else (M, K))
+    B = rng.standard_normal((N, K) if tB else (K, N))
+    bias = rng.standard_normal(N)
+    C0 = rng.standard_normal((M, N))
+    ref = (A.T if tA else A) @ (B.T if tB else B) + bias + 0.5 * C0
+    a, b, c, bi = dev(A), dev(B), dev(C0), dev(bias)
+    L.gemm(tA, tB, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias=bi, beta=0.5)
+    # compare against the fp32-rounded inputs
+    A32, B32, b32, C32 = (x.astype(np.float32).astype(np.float64) for x in (A, B, bias, C0))
+    ref = (A32.T if tA else A32) @ (B32.T if tB else B32) + b32 + 0.5 * C32
+    assert relerr(host(c), ref) < 2e-6
+
+
+def test_gemm_splitk_and_shift():
+    """dW_hh-style contraction: C (M,N) = A^T (M,K) * shift(B) (K,N) with K = B*T rows, zero rows at
+    sequence starts, split-K with the deterministic two-pass reduction."""
+    rng = np.random.default_rng(5)
+    Bsz, T, M, N = 9, 300, 96, 64
+    K = Bsz * T
+    A = rng.standard_normal((K, M)); Bm = rng.standard_normal((K, N))
+    a, b = dev(A), dev(Bm)
+    for shift in (-1, 1):
+        Bs = np.zeros_like(Bm)
+        B3 = Bm.reshape(Bsz, T, N).astype(np.float32).astype(np.float64)
+        if shift == -1:
+            Bs.reshape(Bsz, T, N)[:, 1:] = B3[:, :-1]
+        else:
+            Bs.reshape(Bsz, T, N)[:, :-1] = B3[:, 1:]
+        ref = A.astype(np.float32).astype(np.float64).T @ Bs
+        c = torch.full((M, N), 7.0, device=DEV)
+        ws = L.gemm_ws(1, 0, M, N, K, DEV)
+        assert ws.numel() > 64          # split-K really engaged
+        L.gemm(1, 0, M, N, K, a, M, b, N, c, N, seq_T=T, shiftB=shift, ws=ws)
+        assert relerr(host(c), ref) < 5e-6
+        c2 = torch.empty_like(c)
+        L.gemm(1, 0, M, N, K, a, M, b, N, c2, N, seq_T=T, shiftB=shift, ws=ws)
+        assert torch.equal(c, c2)       # deterministic
+
+
+def test_gemm_strided_views():
+    """sub-blocks with ld > width (the way dep_rnn_backward slices dGI / writes dW blocks)."""
+    rng = np.random.default_rng(6)
+    M, N, K, ld = 64, 48, 200, 160
+    big = rng.standard_normal((K, ld)); Bm = rng.standard_normal((K, N))
+    a, b = dev(big), dev(Bm)
+    c = torch.zeros(M, N, device=DEV)
+    A_view = a[:, 32:32 + M]
+    L.gemm(1, 0, M, N, K, A_view, ld, b, N, c, N)
+    ref = big[:, 32:32 + M].astype(np.float32).astype(np.float64).T @ Bm.astype(np.float32).astype(np.float64)
+    assert relerr(host(c), ref) < 2e-6
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize('rows,F', [(37, 39), (600, 256), (9, 5)])
+def test_layernorm(rows, F):
+    rng = np.random.default_rng(rows + F)
+    x = rng.standard_normal((rows, F)) * 2 + 0.3
+    g = rng.standard_normal(F); b = rng.standard_normal(F)
+    dy = rng.standard_normal((rows, F))
+    y, mr = L.layernorm_fwd(dev(x), dev(g), dev(b))
+    x32 = x.astype(np.float32).astype(np.float64)
+    yr, cache = R.layernorm_fwd(x32, g.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64))
+    assert np.abs(host(y) - yr).max() < 2e-5
+    dg = torch.empty(F, device=DEV); db = torch.empty(F, device=DEV)
+    dx = L.layernorm_bwd(dev(dy), dev(x), dev(g), mr, dg, db, want_dx=True)
+    dxr, dgr, dbr = R.layernorm_bwd(dy.astype(np.float32).astype(np.float64), g.astype(np.float32).astype(np.float64), cache)
+    assert relerr(host(dx), dxr) < 2e-5
+    assert relerr(host(dg), dgr) < 2e-5
+    assert relerr(host(db), dbr) < 2e-5
+
+
+# ----------------------------------------------------------------------------- RNN stacks
+def make_rnn_params(rng, cell, F, H, L, dirs):
+    G = 3 if cell == 'gru' else 4
+    P = {}; names = []
+    prefix = 'lstm_net_audio' if cell == 'gru' else 'lstm_net'
+    k = 1.0 / np.sqrt(H)
+    for l in range(L):
+        for d in range(dirs):
+            sfx = f'l{l}' + ('_reverse' if d else '')
+            inp = F if l == 0 else H * dirs
+            for nm, shp in (('weight_ih', (G * H, inp)), ('weight_hh', (G * H, H)), ('bias_ih', (G * H,)), ('bias_hh', (G * H,))):
+                key = f'{prefix}.{nm}_{sfx}'
+                P[key] = rng.uniform(-k, k, shp).astype(np.float32).astype(np.float64)
+                names.append(key)
+    return P, names, prefix
+
+
+RNN_CASES = [
+    # cell, B, T, F, H, impl     (impl 1 = generic kernels, 2 = MFMA kernels)
+    ('gru', 4, 6, 5, 8, 1),
+    ('gru', 6, 20, 24, 16, 1),
+    ('gru', 6, 20, 24, 16, 2),
+    ('gru', 8, 50, 39, 128, 2),         # BASELINE configs[0] shape
+    ('gru', 37, 9, 64, 256, 2),         # ragged batch tile, 2 hidden tiles per wave (cfg2 H)
+    ('gru', 5, 7, 12, 48, 2),           # 3 tiles on one wave
+    ('lstm', 4, 6, 5, 8, 1),
+    ('lstm', 6, 20, 24, 16, 1),
+    ('lstm', 6, 20, 24, 16, 2),
+    ('lstm', 19, 11, 40, 128, 2),       # cfg3 H
+    ('lstm', 3, 5, 16, 32, 2),
+]
+
+
+@pytest.mark.parametrize('cell,B,T,F,H,impl', RNN_CASES)
+def test_rnn_stack_fwd_bwd(cell, B, T, F, H, impl):
+    rng = np.random.default_rng(B * 1000 + T * 100 + F + H + impl)
+    Lyr = 2
+    dirs = 1 if cell == 'gru' else 2
+    P, names, prefix = make_rnn_params(rng, cell, F, H, Lyr, dirs)
+    x = rng.standard_normal((B, T, F)).astype(np.float32).astype(np.float64)
+    Wd = [dev(P[n]) for n in names]
+    Gd = [torch.full_like(w, float('nan')) for w in Wd]
+    xd = dev(x)
+    pool = L.POOL_MEAN if cell == 'gru' else L.POOL_NONE
+    rnn = L.Rnn(L.CELL_GRU if cell == 'gru' else L.CELL_LSTM, B, T, F, H, Lyr, dirs, True, 0.0, pool, DEV, impl=impl)
+    pooled = torch.full((B, H), float('nan'), device=DEV) if cell == 'gru' else None
+    h_n = torch.full((Lyr * dirs, B, H), float('nan'), device=DEV)
+    rnn.forward(xd, Wd, pooled=pooled, h_n=h_n)
+    y = host(rnn.layer_output())
+    if cell == 'gru':
+        yr, caches = R.gru_stack_fwd(x, P, prefix, Lyr)
+        assert np.abs(y - yr).max() < 1e-4
+        assert np.abs(host(pooled) - yr.mean(1)).max() < 1e-4
+        assert np.abs(host(h_n)[-1] - yr[:, -1]).max() < 1e-4
+        dpool = rng.standard_normal((B, H))
+        dyv = rng.standard_normal((B, T, H)) * 0.3
+        dxd = torch.full((B, T, F), float('nan'), device=DEV)
+        rnn.backward(xd, Wd, Gd, dy=dev(dyv), dpooled=dev(dpool), dx=dxd)
+        dy_full = dyv.astype(np.float32).astype(np.float64) + dpool.astype(np.float32).astype(np.float64)[:, None, :] / T
+        dxr, Gr = R.gru_stack_bwd(dy_full, P, prefix, Lyr, caches)
+    else:
+        yr, hnr, caches = R.bilstm_stack_fwd(x, P, prefix, Lyr)
+        assert np.abs(y - yr).max() < 1e-4
+        assert np.abs(host(h_n) - hnr).max() < 1e-4
+        dyv = rng.standard_normal((B, T, 2 * H)) * 0.3
+        dhn = rng.standard_normal((Lyr * 2, B, H)) * 0.3
+        dxd = torch.full((B, T, F), float('nan'), device=DEV)
+        rnn.backward(xd, Wd, Gd, dy=dev(dyv), dh_n=dev(dhn), dx=dxd)
+        dxr, Gr = R.bilstm_stack_bwd(dyv.astype(np.float32).astype(np.float64), dhn.astype(np.float32).astype(np.float64),
+                                     P, prefix, Lyr, caches)
+    assert relerr(host(dxd), dxr) < 1e-4, 'dx'
+    for n, g in zip(names, Gd):
+        assert relerr(host(g), Gr[n]) < 1e-4, n
+
+
+@pytest.mark.parametrize('cell,impl,H', [('gru', 2, 16), ('gru', 1, 16), ('lstm', 2, 16), ('lstm', 1, 8)])
+def test_rnn_interlayer_dropout_matches_oracle_with_same_masks(cell, impl, H):
+    """nn.GRU/LSTM(dropout=p) training mode: the oracle is fed the masks the HIP path drew."""
+    rng = np.random.default_rng(77 + impl + H)
+    B, T, F, Lyr, p, seed = 5, 9, 10, 2, 0.5, 1234
+    dirs = 1 if cell == 'gru' else 2
+    P, names, prefix = make_rnn_params(rng, cell, F, H, Lyr, dirs)
+    x = rng.standard_normal((B, T, F)).astype(np.float32).astype(np.float64)
+    Wd = [dev(P[n]) for n in names]; Gd = [torch.zeros_like(w) for w in Wd]
+    rnn = L.Rnn(L.CELL_GRU if cell == 'gru' else L.CELL_LSTM, B, T, F, H, Lyr, dirs, True, p, L.POOL_NONE, DEV, impl=impl)
+    xd = dev(x)
+    rnn.forward(xd, Wd, seed=seed)
+    y0 = host(rnn.layer_output(0)); y0d = host(rnn.layer_output_dropped(0))
+    mask = host(L.dropout_mask(B * T * H * dirs, p, seed, 16, DEV)).reshape(B, T, H * dirs)   # site = DEP_SITE_RNN0 + 0
+    assert set(np.unique(mask)).issubset({0.0, 2.0})
+    assert 0.35 < (mask == 0).mean() < 0.65
+    assert np.abs(y0d - y0 * mask).max() < 1e-6
+    dyv = rng.standard_normal((B, T, H * dirs)).astype(np.float32).astype(np.float64)
+    if cell == 'gru':
+        yr, caches = R.gru_stack_fwd(x, P, prefix, Lyr, masks=[mask])
+        rnn.backward(xd, Wd, Gd, dy=dev(dyv))
+        _, Gr = R.gru_stack_bwd(dyv, P, prefix, Lyr, caches, masks=[mask])
+    else:
+        yr, hnr, caches = R.bilstm_stack_fwd(x, P, prefix, Lyr, masks=[mask])
+        rnn.backward(xd, Wd, Gd, dy=dev(dyv))
+        _, Gr = R.bilstm_stack_bwd(dyv, np.zeros((Lyr * 2, B, H)), P, prefix, Lyr, caches, masks=[mask])
+    assert np.abs(host(rnn.layer_output()) - yr).max() < 1e-4
+    for n, g in zip(names, Gd):
+        assert relerr(host(g), Gr[n]) < 1e-4, n
+    # a different seed draws a different mask; the same seed reproduces it bit for bit
+    y_a = rnn.layer_output().clone()
+    rnn.forward(xd, Wd, seed=seed)
+    assert torch.equal(y_a, rnn.layer_output())
+    rnn.forward(xd, Wd, seed=seed + 1)
+    assert not torch.equal(y_a, rnn.layer_output())
+
+
+def test_rnn_generic_and_mfma_agree_on_cfg1_shape():
+    rng = np.random.default_rng(3)
+    B, T, F, H = 8, 50, 39, 128
+    P, names, prefix = make_rnn_params(rng, 'gru', F, H, 2, 1)
+    x = dev(rng.standard_normal((B, T, F)))
+    Wd = [dev(P[n]) for n in names]
+    outs = []
+    for impl in (1, 2):
+        rnn = L.Rnn(L.CELL_GRU, B, T, F, H, 2, 1, False, 0.0, L.POOL_SUM, DEV, impl=impl)
+        pooled = torch.empty(B, H, device=DEV)
+        rnn.forward(x, Wd, pooled=pooled)
+        outs.append((host(rnn.layer_output()), host(pooled)))
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 2e-5
+    assert np.abs(outs[0][1] - outs[1][1]).max() < 2e-4
+
+
+# ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize('B,T,H', [(3, 6, 8), (7, 50, 128), (2, 300, 16)])
+def test_attention(B, T, H):
+    rng = np.random.default_rng(B + T + H)
+    out = rng.standard_normal((B, T, 2 * H)).astype(np.float32).astype(np.float64)
+    hn = rng.standard_normal((4, B, H)).astype(np.float32).astype(np.float64)
+    Wa = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float32).astype(np.float64)
+    ba = rng.standard_normal(H).astype(np.float32).astype(np.float64)
+    dctx = rng.standard_normal((B, H)).astype(np.float32).astype(np.float64)
+    ctx, saved = L.attn_fwd(dev(out), dev(hn), dev(Wa), dev(ba))
+    ctxr, cache = R.attention_fwd(out, hn, Wa, ba)
+    assert np.abs(host(ctx) - ctxr).max() < 1e-4
+    assert np.abs(host(saved[0]) - cache[5]).max() < 1e-5
+    dWa = torch.empty(H, H, device=DEV); dba = torch.empty(H, device=DEV)
+    dout, dhn = L.attn_bwd(dev(dctx), dev(out), dev(Wa), saved, 4, dWa, dba)
+    doutr, dhnr, dWar, dbar = R.attention_bwd(dctx, Wa, cache)
+    assert relerr(host(dout), doutr) < 1e-4
+    assert relerr(host(dhn), dhnr) < 1e-4
+    assert relerr(host(dWa), dWar) < 1e-4
+    assert relerr(host(dba), dbar) < 1e-4
+
+
+# ----------------------------------------------------------------------------- heads / losses
+def test_head_loss_kinds():
+    rng = np.random.default_rng(9)
+    B = 37
+    z = rng.standard_normal((B, 2)).astype(np.float32).astype(np.float64) * 2
+    y = rng.integers(0, 2, B)
+    zd = dev(z); yd = torch.from_numpy(y.astype(np.int32)).to(DEV)
+    out = torch.empty(B, 2, device=DEV); rows = torch.empty(B, device=DEV); dz = torch.empty(B, 2, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    # CE on softmax output (double softmax)
+    L.head_loss(L.LOSS_CE_ON_SOFTMAX, zd, yd, out, rows, dz, B)
+    L.reduce_loss(rows, B, loss)
+    p = R.softmax(z); lr_, dp = R.ce_on_probs(p, y)
+    assert np.abs(host(out) - p).max() < 1e-6
+    assert abs(host(loss)[0] - lr_) < 1e-6
+    assert relerr(host(dz), R.softmax_bwd(p, dp)) < 1e-5
+    # CE on logits
+    L.head_loss(L.LOSS_CE_LOGITS, zd, yd, out, rows, dz, B)
+    L.reduce_loss(rows, B, loss)
+    lr_, dzr = R.ce_logits(z, y)
+    assert abs(host(loss)[0] - lr_) < 1e-6 and relerr(host(dz), dzr) < 1e-5
+    # regression heads
+    z1 = (rng.standard_normal((B, 1)) * 3 + 1).astype(np.float32).astype(np.float64)
+    yt = rng.uniform(-1, 3, (B, 1)).astype(np.float32).astype(np.float64)
+    z1d, ytd = dev(z1), dev(yt)
+    out1 = torch.empty(B, 1, device=DEV); dz1 = torch.empty(B, 1, device=DEV)
+    for kind, fn, relu in ((L.LOSS_L1_RELU, R.l1_loss, True), (L.LOSS_SMOOTHL1_RELU, R.smooth_l1_loss, True),
+                           (L.LOSS_SMOOTHL1, R.smooth_l1_loss, False)):
+        L.head_loss(kind, z1d, ytd, out1, rows, dz1, B)
+        L.reduce_loss(rows, B, loss)
+        o = np.maximum(z1, 0) if relu else z1
+        lr_, g = fn(o, yt)
+        if relu:
+            g = g * (z1 > 0)
+        assert np.abs(host(out1) - o).max() < 1e-6
+        assert abs(host(loss)[0] - lr_) < 1e-5
+        assert np.abs(host(dz1) - g).max() < 1e-6
+
+
+def test_relu_dropout_colsum_adam():
+    rng = np.random.default_rng(10)
+    M, N = 50, 70
+    z = rng.standard_normal((M, N)).astype(np.float32)
+    zd = dev(z); a = torch.empty_like(zd)
+    L.relu_dropout_fwd(zd, a, 0.3, 99, L.SITE_FC1)
+    mask = host(L.dropout_mask(M * N, 0.3, 99, L.SITE_FC1, DEV)).reshape(M, N)
+    assert np.abs(host(a) - np.maximum(z, 0) * mask).max() < 1e-6
+    da = rng.standard_normal((M, N)).astype(np.float32); dz = torch.empty_like(zd)
+    L.relu_dropout_bwd(dev(da), zd, dz, 0.3, 99, L.SITE_FC1)
+    assert np.abs(host(dz) - da * mask * (z > 0)).max() < 1e-6
+    cs = torch.empty(N, device=DEV)
+    L.colsum(zd, cs)
+    assert np.abs(host(cs) - z.astype(np.float64).sum(0)).max() < 1e-4
+    # Adam / AdamW, 3 steps
+    n = 1000
+    for decoupled, wd in ((True, 1e-2), (False, 0.0), (False, 1e-3)):
+        p = rng.standard_normal(n).astype(np.float32).astype(np.float64); m = np.zeros(n); v = np.zeros(n)
+        pd = dev(p); md = torch.zeros(n, device=DEV); vd = torch.zeros(n, device=DEV)
+        for step in range(1, 4):
+            g = rng.standard_normal(n).astype(np.float32).astype(np.float64)
+            L.adam_step(pd, dev(g), md, vd, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, step)
+            p, m, v = R.adam_step(p, g, m, v, step, 1e-3, wd=wd, decoupled=decoupled)
+        assert np.abs(host(pd) - p).max() < 1e-6
+
+
+def test_bad_arguments_fail_loudly():
+    with pytest.raises(L.DepError):
+        L.gemm(1, 1, 4, 4, 4, torch.zeros(16, device=DEV), 4, torch.zeros(16, device=DEV), 4, torch.zeros(16, device=DEV), 4)
+    with pytest.raises(L.DepError):
+        L.Rnn(L.CELL_GRU, 4, 4, 4, 4, 2, 2, False, 0.0, L.POOL_NONE, DEV)     # bidirectional GRU is not in the path
