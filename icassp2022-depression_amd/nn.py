@@ -1,0 +1,354 @@
+"""Host-side module / loss / optimizer layer over libdep_rnn.so.
+
+This is the part of torch.nn / torch.optim / autograd the reference scripts lean on, restated so
+that their `model(x)`, `criterion(output, y)`, `loss.backward()`, `optimizer.step()`,
+`state_dict()` / `load_state_dict(strict=False)` / `named_parameters()` call surface keeps working
+while every FLOP runs in the HIP library.  No torch.nn layer, no autograd: each Module owns
+
+  * one flat fp32 parameter buffer and one flat gradient buffer on the GPU (Parameters are views),
+    laid out [live + weight-decay | live + no-decay ('ln') | dead] so that Adam/AdamW is at most
+    two kernel launches and the data-parallel gradient all-reduce is ONE contiguous bucket;
+  * an explicit backward() that the Loss object returned by a criterion triggers.
+
+"Dead" parameters are the ones the reference defines but never uses in forward() (SURVEY 2.1
+quirk 1): they exist in state_dict(), never receive a gradient (`.grad is None`) and are skipped
+by the optimizers exactly like torch skips parameters whose grad is None.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import parallel
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise L.DepError('no MI355X visible (torch.cuda.is_available() is False): the HIP path has no CPU fallback')
+    L.load()
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class Parameter:
+    """A named view into the owning module's flat buffers."""
+
+    def __init__(self, name, shape, owner):
+        self.name = name
+        self.shape = tuple(shape)
+        self.numel = int(np.prod(shape))
+        self.owner = owner
+        self.offset = -1
+        self.live = True             # receives a gradient in backward()
+        self.requires_grad = True
+        self.data = None             # torch view, set by Module._finalize
+        self._grad = None
+
+    @property
+    def grad(self):
+        if not self.live or not self.requires_grad or not self.owner._grad_ready:
+            return None
+        return self._grad
+
+    def __repr__(self):
+        return f'Parameter({self.name}, shape={self.shape}, live={self.live})'
+
+
+class Module:
+    def __init__(self):
+        self._params = OrderedDict()
+        self.training = True
+        self._grad_ready = False
+        self._flat = None
+        self._flat_grad = None
+
+    # -- construction ------------------------------------------------------------------
+    def _add(self, name, shape, live=True):
+        p = Parameter(name, shape, self)
+        p.live = live
+        self._params[name] = p
+        return p
+
+    def _finalize(self, init_values):
+        """Lay the parameters out in the flat buffers and upload `init_values` (name -> ndarray)."""
+        dev = _device()
+        order = ([p for p in self._params.values() if p.live and 'ln' not in p.name] +
+                 [p for p in self._params.values() if p.live and 'ln' in p.name] +
+                 [p for p in self._params.values() if not p.live])
+        off = 0
+        for p in order:
+            p.offset = off
+            off += (p.numel + 3) // 4 * 4            # keep every tensor 16-byte aligned
+        self._n_live = sum((p.numel + 3) // 4 * 4 for p in order if p.live)
+        host = np.zeros(off, np.float32)
+        for p in order:
+            host[p.offset:p.offset + p.numel] = np.asarray(init_values[p.name], np.float32).reshape(-1)
+        self._flat = torch.from_numpy(host).to(dev)
+        self._flat_grad = torch.zeros(max(self._n_live, 4), dtype=torch.float32, device=dev)
+        for p in order:
+            p.data = self._flat[p.offset:p.offset + p.numel].view(p.shape)
+            p._grad = self._flat_grad[p.offset:p.offset + p.numel].view(p.shape) if p.live else None
+        self.device = dev
+
+    # -- torch.nn.Module surface ----------------------------------------------------------
+    def named_parameters(self):
+        return iter(self._params.items())
+
+    def parameters(self):
+        return iter(self._params.values())
+
+    def state_dict(self):
+        return OrderedDict((k, p.data) for k, p in self._params.items())
+
+    def load_state_dict(self, sd, strict=True):
+        """Name-based load.  strict=False ignores missing/unexpected keys like torch does
+        (Classification/fuse_net_whole.py:586-588 relies on this)."""
+        missing = [k for k in self._params if k not in sd]
+        unexpected = [k for k in sd if k not in self._params]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'load_state_dict: missing {missing}, unexpected {unexpected}')
+        for k, v in sd.items():
+            if k in self._params:
+                p = self._params[k]
+                t = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))
+                if tuple(t.shape) != p.shape:
+                    raise RuntimeError(f'size mismatch for {k}: {tuple(t.shape)} vs {p.shape}')
+                p.data.copy_(t.to(dtype=torch.float32))
+        return missing, unexpected
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def zero_grad(self):
+        self._grad_ready = False
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def cuda(self):
+        return self
+
+    # -- helpers -------------------------------------------------------------------------
+    def live_grad_bucket(self):
+        """The single contiguous gradient bucket the data-parallel all-reduce operates on."""
+        return self._flat_grad[:self._n_live]
+
+    def _to_dev(self, x):
+        if torch.is_tensor(x):
+            t = x
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(x))
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+
+class Output:
+    """What `model(x)` returns: the result tensor plus the owner that can run backward for it.
+    `.data` is the plain device tensor (the reference reads `output.data.max(1, keepdim=True)[1]`)."""
+
+    def __init__(self, data, owner=None, z=None):
+        self.data = data
+        self._owner = owner
+        self._z = z              # pre-activation the fused loss kernel starts from
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def cpu(self):
+        return self.data.cpu()
+
+    def detach(self):
+        return self.data
+
+    def flatten(self):
+        return self.data.flatten()
+
+    def numpy(self):
+        return self.data.cpu().numpy()
+
+    def max(self, *a, **k):
+        return self.data.max(*a, **k)
+
+
+class Loss:
+    def __init__(self, value_dev, backward_fn):
+        self._v = value_dev
+        self._bw = backward_fn
+
+    def item(self):
+        return float(self._v.item())        # host sync point, as in the reference (loss.item())
+
+    def backward(self):
+        if self._bw is None:
+            raise RuntimeError('loss computed under evaluate(): nothing to backpropagate')
+        self._bw()
+
+    def __float__(self):
+        return self.item()
+
+
+class _HeadLoss:
+    """Loss on a model output; the output nonlinearity, the loss and dLoss/dz are one HIP kernel."""
+    kind = None
+    target_dtype = None
+
+    def __call__(self, output, target):
+        owner = output._owner
+        z = output._z
+        B, Cc = z.shape
+        dev = z.device
+        if self.target_dtype == 'int':
+            t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target)
+            t = t.to(device=dev, dtype=torch.int32).contiguous().view(-1)
+        else:
+            t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target)
+            t = t.to(device=dev, dtype=torch.float32).contiguous().view(B, Cc)
+        norm_local = B * (1 if self.target_dtype == 'int' else Cc)
+        train = owner is not None and owner.training
+        # data parallel: every rank normalises by the GLOBAL batch so that summed gradients equal
+        # the reference's batch-mean gradient (ragged shards included)
+        norm = parallel.global_count(norm_local) if train else norm_local
+        rows = torch.empty(B, dtype=torch.float32, device=dev)
+        dz = torch.empty_like(z) if train else None
+        L.head_loss(self.kind, z, t, None, rows, dz, norm)
+        val = torch.zeros(1, dtype=torch.float32, device=dev)
+        L.reduce_loss(rows, norm, val)
+        if train and parallel.world_size() > 1:
+            parallel.all_reduce_sum(val)
+        return Loss(val, (lambda: owner.backward(dz)) if train else None)
+
+
+class CrossEntropyLoss(_HeadLoss):
+    """nn.CrossEntropyLoss on the model's Softmax output (audio_gru_whole.py:308)."""
+    kind = L.LOSS_CE_ON_SOFTMAX
+    target_dtype = 'int'
+
+
+class L1Loss(_HeadLoss):
+    """nn.L1Loss on the ReLU output (Regression/audio_bilstm_perm.py:251)."""
+    kind = L.LOSS_L1_RELU
+    target_dtype = 'float'
+
+
+class SmoothL1Loss(_HeadLoss):
+    """nn.SmoothL1Loss on the ReLU output (Regression/text_bilstm_perm.py:247)."""
+    kind = L.LOSS_SMOOTHL1_RELU
+    target_dtype = 'float'
+
+
+# ----------------------------------------------------------------------------- optimizers
+class _AdamBase:
+    decoupled = False
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=None):
+        params = list(params)
+        default_wd = (1e-2 if self.decoupled else 0.0) if weight_decay is None else weight_decay
+        if params and isinstance(params[0], dict):
+            groups = [dict(g) for g in params]
+        else:
+            groups = [{'params': params}]
+        self.param_groups = []
+        for g in groups:
+            g = dict(g)
+            g['params'] = list(g['params'])
+            g.setdefault('lr', lr); g.setdefault('betas', betas); g.setdefault('eps', eps)
+            g.setdefault('weight_decay', default_wd)
+            self.param_groups.append(g)
+        self._step = 0
+        self._state = {}          # id(module) -> (m, v)
+
+    def zero_grad(self):
+        for g in self.param_groups:
+            for p in g['params']:
+                p.owner._grad_ready = False
+
+    def _ranges(self, g):
+        """Contiguous [start, end) ranges (in the owner's flat buffer) of the parameters of group g that
+        currently hold a gradient -- parameters whose grad is None are skipped like torch does."""
+        per_owner = {}
+        for p in g['params']:
+            if p.grad is None:
+                continue
+            per_owner.setdefault(id(p.owner), (p.owner, []))[1].append((p.offset, p.offset + (p.numel + 3) // 4 * 4))
+        out = []
+        for owner, rs in per_owner.values():
+            rs.sort()
+            cur_s, cur_e = rs[0]
+            for s, e in rs[1:]:
+                if s == cur_e:
+                    cur_e = e
+                else:
+                    out.append((owner, cur_s, cur_e)); cur_s, cur_e = s, e
+            out.append((owner, cur_s, cur_e))
+        return out
+
+    def step(self):
+        self._step += 1
+        for g in self.param_groups:
+            b1, b2 = g['betas']
+            for owner, s, e in self._ranges(g):
+                st = self._state.get(id(owner))
+                if st is None:
+                    st = (torch.zeros_like(owner._flat_grad), torch.zeros_like(owner._flat_grad))
+                    self._state[id(owner)] = st
+                m, v = st
+                L.adam_step(owner._flat[s:e], owner._flat_grad[s:e], m[s:e], v[s:e], g['lr'], b1, b2, g['eps'],
+                            g['weight_decay'], self.decoupled, self._step)
+
+
+class Adam(_AdamBase):
+    """torch.optim.Adam (Regression/audio_bilstm_perm.py:250, Classification/fuse_net_whole.py:416)."""
+    decoupled = False
+
+
+class AdamW(_AdamBase):
+    """torch.optim.AdamW with per-group decoupled weight decay (audio_gru_whole.py:247-255,307)."""
+    decoupled = True
+
+
+# ----------------------------------------------------------------------------- initialisers
+def _uniform(shape, bound, gen):
+    return ((torch.rand(*shape, generator=gen) * 2 - 1) * bound).numpy()
+
+
+def default_rnn_init(names_shapes, H, gen):
+    """nn.GRU / nn.LSTM reset_parameters: U(-1/sqrt(H), 1/sqrt(H)) for every tensor."""
+    k = 1.0 / math.sqrt(H)
+    return {n: _uniform(s, k, gen) for n, s in names_shapes}
+
+
+def default_linear_init(name_w, name_b, out_f, in_f, gen, bias=True):
+    """nn.Linear reset_parameters: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))."""
+    k = 1.0 / math.sqrt(in_f)
+    d = {name_w: _uniform((out_f, in_f), k, gen)}
+    if bias:
+        d[name_b] = _uniform((out_f,), k, gen)
+    return d
+
+
+def xavier_uniform(shape, gen):
+    fan_out, fan_in = shape[0], shape[1]
+    return _uniform(shape, math.sqrt(6.0 / (fan_in + fan_out)), gen)
+
+
+def make_generator(seed=None):
+    g = torch.Generator()
+    g.manual_seed(int(torch.initial_seed() if seed is None else seed) & 0x7fffffffffffffff)
+    return g
+
+
+_seed_counter = [0]
+
+
+def next_dropout_seed():
+    """A fresh Philox key per training forward; distinct per data-parallel rank."""
+    _seed_counter[0] += 1
+    return (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + _seed_counter[0] * 1000003 + parallel.rank() * 7919) \
+        & 0xFFFFFFFFFFFFFFFF

@@ -1,0 +1,230 @@
+"""GPU parity of the script-shaped modules (forward, loss, gradients, optimizer steps, train()/evaluate())
+against the golden fixtures captured from the reference's own classes.  Tolerance: 1e-4 fp32 (north_star)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from icassp2022_depression_amd import (audio_bilstm_perm, audio_gru_whole, fuse_net_whole, nn,
+                                           text_bilstm_perm, text_bilstm_whole)
+    from icassp2022_depression_amd import fuse_net as fuse_net_reg
+
+ATOL = 1e-4
+
+
+def relerr(a, b):
+    return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-12)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def make(mod, cls, g, dropout=0.0, **over):
+    B, T, F, H = [int(v) for v in g['shape']]
+    cfg = dict(mod.config); cfg.update(embedding_size=F, hidden_dims=H, dropout=dropout); cfg.update(over)
+    m = getattr(mod, cls)(cfg, seed=0)
+    assert list(m.state_dict().keys())[:len(g['sd'])] == list(g['sd'].keys()) or \
+        [k for k in m.state_dict().keys() if k in g['sd']] == list(g['sd'].keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()}, strict=True)
+    return m, cfg
+
+
+CASES = [
+    ('audio_clf_tiny', 'audio_gru_whole', 'AudioBiLSTM', 'adamw', 'ce'),
+    ('audio_clf_mid', 'audio_gru_whole', 'AudioBiLSTM', 'adamw', 'ce'),
+    ('audio_clf_cfg1', 'audio_gru_whole', 'AudioBiLSTM', 'adamw', 'ce'),
+    ('audio_reg_tiny', 'audio_bilstm_perm', 'AudioBiLSTM', 'adam', 'l1'),
+    ('audio_reg_mid', 'audio_bilstm_perm', 'AudioBiLSTM', 'adam', 'l1'),
+    ('text_clf_tiny', 'text_bilstm_whole', 'TextBiLSTM', 'adamw', 'ce'),
+    ('text_clf_mid', 'text_bilstm_whole', 'TextBiLSTM', 'adamw', 'ce'),
+    ('text_reg_tiny', 'text_bilstm_perm', 'TextBiLSTM', 'adam', 'sl1'),
+    ('text_reg_mid', 'text_bilstm_perm', 'TextBiLSTM', 'adam', 'sl1'),
+]
+
+
+@pytest.mark.parametrize('name,modname,cls,opt,loss', CASES)
+def test_model_forward_loss_grads_steps(name, modname, cls, opt, loss):
+    mod = {'audio_gru_whole': audio_gru_whole, 'audio_bilstm_perm': audio_bilstm_perm,
+           'text_bilstm_whole': text_bilstm_whole, 'text_bilstm_perm': text_bilstm_perm}[modname]
+    g = load_golden(name)
+    model, cfg = make(mod, cls, g)
+    x = g['x']; y = g['y']
+    model.eval()
+    out = model(x)
+    assert np.abs(out.numpy() - g['out_eval']).max() < ATOL
+    model.train()
+    lr = float(g['lr'])
+    if opt == 'adamw':
+        groups = mod.get_param_group(model)
+        got_nd = sorted(p.name for p in groups[1]['params'])
+        assert got_nd == sorted(g['nodecay_names'].tolist())
+        optimizer = nn.AdamW(groups, lr=lr)
+    else:
+        optimizer = nn.Adam(model.parameters(), lr=lr)
+    crit = {'ce': nn.CrossEntropyLoss, 'l1': nn.L1Loss, 'sl1': nn.SmoothL1Loss}[loss]()
+    nsteps = 3
+    for s in range(1, nsteps + 1):
+        optimizer.zero_grad()
+        out = model(x)
+        l = crit(out, y if loss == 'ce' else y.reshape(-1, 1))
+        l.backward()
+        assert abs(l.item() - g['losses'][s - 1]) < ATOL * max(1.0, abs(g['losses'][s - 1])), (s, l.item())
+        if s == 1:
+            assert np.abs(out.numpy() - g['out_train']).max() < ATOL
+            live = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+            assert set(live) == set(g['grads']), sorted(set(live) ^ set(g['grads']))   # dead params get no grad
+            for k, gr in g['grads'].items():
+                assert relerr(live[k].cpu().numpy(), gr) < 1e-3, (k, relerr(live[k].cpu().numpy(), gr))
+        optimizer.step()
+        if s == 1 and 'after1' in g:
+            sd = model.state_dict()
+            for k, v in g['after1'].items():
+                assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5 + 1e-4 * np.abs(v).max(), k
+    sd = model.state_dict()
+    for k, v in g[f'after{nsteps}'].items():
+        if k in sd and sd[k].dtype.is_floating_point:
+            assert np.abs(sd[k].cpu().numpy() - v).max() < 5e-5 + 2e-4 * np.abs(v).max(), k
+
+
+def test_audio_clf_train_evaluate_functions():
+    """Module-level train()/evaluate() with the reference's global protocol (audio_gru_whole.py:161-245)."""
+    g = load_golden('audio_clf_train_eval')
+    N, T, F, H = [int(v) for v in g['shape']]
+    m = audio_gru_whole
+    saved_cfg = dict(m.config)
+    try:
+        m.config.update(embedding_size=F, hidden_dims=H, dropout=0.0, batch_size=int(g['batch_size']), learning_rate=float(g['lr']))
+        m.audio_features = g['feats']; m.audio_targets = g['targs']
+        m.model = m.AudioBiLSTM(m.config, seed=0)
+        m.model.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()})
+        m.optimizer = nn.AdamW(m.get_param_group(m.model), lr=m.config['learning_rate'])
+        m.criterion = nn.CrossEntropyLoss()
+        m.max_f1 = m.max_acc = m.max_rec = m.max_prec = 2.0
+        tr = g['train_idxs'].tolist(); te = g['test_idxs'].tolist()
+        quiet(m.train, 1, tr); acc1 = m.train_acc
+        quiet(m.train, 2, tr); acc2 = m.train_acc
+        tl = quiet(m.evaluate, m.model, te, 1, tr, tr)
+        assert [acc1, acc2] == g['train_acc'].tolist()
+        assert abs(tl - float(g['eval_loss'])) < ATOL
+        sd = m.model.state_dict()
+        for k, v in g['after'].items():
+            assert np.abs(sd[k].cpu().numpy() - v).max() < 5e-5 + 2e-4 * np.abs(v).max(), k
+        m.model.eval()
+        probs = m.model(g['feats'][te].astype(np.float32)).numpy()
+        assert np.abs(probs - g['probs']).max() < ATOL
+        cm = m.standard_confusion_matrix(torch.from_numpy(g['targs'][te]), probs.argmax(1))
+        assert (cm == g['conf']).all()
+    finally:
+        m.config.clear(); m.config.update(saved_cfg)
+
+
+def test_audio_reg_train_evaluate_functions():
+    g = load_golden('audio_reg_train_eval')
+    N, T, F, H = [int(v) for v in g['shape']]
+    m = audio_bilstm_perm
+    saved_cfg = dict(m.config)
+    try:
+        m.config.update(embedding_size=F, hidden_dims=H, dropout=0.0, batch_size=int(g['batch_size']), learning_rate=float(g['lr']))
+        m.audio_features = g['feats']; m.audio_targets = g['targs']
+        m.model = m.AudioBiLSTM(m.config, seed=0)
+        m.model.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()})
+        m.optimizer = nn.Adam(m.model.parameters(), lr=m.config['learning_rate'])
+        m.criterion = nn.L1Loss()
+        m.train_dep_idxs = [0, 1, 2, 3, 4]; m.train_non_idxs = [5, 6, 7, 8, 9, 10]
+        m.test_dep_idxs = [11, 12]; m.test_non_idxs = [13, 14, 15, 16]
+        m.min_mae = -1.0; m.min_rmse = -1.0
+        mae1 = quiet(m.train, 1); mae2 = quiet(m.train, 2)
+        tl = quiet(m.evaluate, 0, m.model, mae2)
+        assert np.abs(np.array([mae1, mae2]) - g['train_mae']).max() < 1e-3
+        assert abs(tl - float(g['eval_loss'])) < 1e-3 * max(1.0, abs(float(g['eval_loss'])))
+        sd = m.model.state_dict()
+        for k, v in g['after'].items():
+            if sd[k].dtype.is_floating_point:
+                assert np.abs(sd[k].cpu().numpy() - v).max() < 5e-5 + 2e-4 * np.abs(v).max(), k
+    finally:
+        m.config.clear(); m.config.update(saved_cfg)
+
+
+@pytest.mark.parametrize('name', ['fuse_clf', 'fuse_reg'])
+def test_fusion(name):
+    g = load_golden(name)
+    N, T, Fa, Ft, Ha, Ht = [int(v) for v in g['dims']]
+    m = fuse_net_whole if name == 'fuse_clf' else fuse_net_reg
+    saved_cfg = dict(m.config)
+    try:
+        m.config.update(audio_embed_size=Fa, text_embed_size=Ft, audio_hidden_dims=Ha, text_hidden_dims=Ht, dropout=0.0,
+                        batch_size=4, learning_rate=float(g['lr']))
+        model = m.build(seed=0)
+        assert list(model.state_dict().keys()) == list(g['sd'].keys())
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()})
+        feats = [[g['xa'][i], g['xt'][i]] for i in range(N)]
+        model.eval()
+        tf, af = model.pretrained_feature(feats)
+        assert np.abs(tf.cpu().numpy() - g['text_feature']).max() < ATOL
+        assert relerr(af.cpu().numpy(), g['audio_feature']) < ATOL
+        out = model(torch.cat((tf, af), dim=1))
+        assert relerr(out.numpy(), g['out']) < ATOL
+        model.train()         # dropout is 0 here, so train-mode features equal eval-mode ones
+        y = g['y']
+        for s in range(1, 4):
+            m.optimizer.zero_grad()
+            l = m.criterion(tf, af, y, model)
+            l.backward()
+            assert abs(l.item() - g['losses'][s - 1]) < ATOL * max(1.0, abs(g['losses'][s - 1]))
+            if s == 1:
+                grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+                assert list(grads) == ['fc_final.0.weight']          # the only tensor that trains
+                assert relerr(grads['fc_final.0.weight'].cpu().numpy(), g['gW']) < 1e-3
+            m.optimizer.step()
+        assert np.abs(model.state_dict()['fc_final.0.weight'].cpu().numpy() - g['W3']).max() < 5e-5
+        if name == 'fuse_clf':
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()})
+            m.optimizer = nn.Adam(model.parameters(), lr=m.config['learning_rate'])
+            m.fuse_features = feats; m.fuse_targets = y
+            m.max_f1 = 2.0; m.max_acc = 2.0
+            quiet(m.train, 1, g['train_idxs'].tolist())
+            assert m.train_acc == int(g['train_acc'])
+            tl = quiet(m.evaluate, model, g['test_idxs'].tolist(), 1, g['train_idxs'].tolist())
+            assert abs(tl - float(g['eval_loss'])) < ATOL * 10
+            assert np.abs(model.state_dict()['fc_final.0.weight'].cpu().numpy() - g['W_after_train']).max() < 5e-5
+    finally:
+        m.config.clear(); m.config.update(saved_cfg)
+
+
+def test_dropout_training_mode_is_stochastic_and_eval_is_not():
+    g = load_golden('audio_clf_mid')
+    model, _ = make(audio_gru_whole, 'AudioBiLSTM', g, dropout=0.5)
+    x = g['x']
+    model.train()
+    a = model(x).numpy(); b = model(x).numpy()
+    assert np.abs(a - b).max() > 1e-6
+    model.eval()
+    c = model(x).numpy(); d = model(x).numpy()
+    assert np.array_equal(c, d)
+    assert np.abs(c - g['out_eval']).max() < ATOL
+
+
+def test_transplant_name_mismatch_behaviour():
+    """fuse_net_whole.py:566-588: a text_bilstm_whole checkpoint carries fc_out.0/3 which fusion_net lacks
+    (its Linear sits at fc_out.1), so the text head stays at its random init; fc_audio.4 is dropped."""
+    gt = load_golden('text_clf_mid'); ga = load_golden('audio_clf_mid')
+    B, T, Ft, Ht = [int(v) for v in gt['shape']]; _, _, Fa, Ha = [int(v) for v in ga['shape']]
+    model = fuse_net_whole.fusion_net(Ft, Ht, 2, 0.0, 2, Ha, Fa, seed=3)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    fuse_net_whole.transplant(model, {k: torch.from_numpy(v) for k, v in gt['sd'].items()},
+                              {k: torch.from_numpy(v) for k, v in ga['sd'].items()})
+    sd = model.state_dict()
+    assert torch.equal(sd['fc_out.1.weight'], before['fc_out.1.weight'])
+    assert np.array_equal(sd['lstm_net.weight_hh_l1_reverse'].cpu().numpy(), gt['sd']['lstm_net.weight_hh_l1_reverse'])
+    assert np.array_equal(sd['lstm_net_audio.weight_ih_l0'].cpu().numpy(), ga['sd']['lstm_net_audio.weight_ih_l0'])
+    assert np.array_equal(sd['ln.weight'].cpu().numpy(), ga['sd']['ln.weight'])
+    assert [p.name for p in model.parameters() if p.requires_grad] == ['fc_final.0.weight']
