@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/s of one full train step (forward + CE-on-softmax loss + backward +
+AdamW, dropout on) of the audio GRU-256 x2 classifier on synthetic (B,T,F) = (512,300,256) per GPU
+(BASELINE.json configs[1]), weak-scaled over N GPUs with one RCCL gradient all-reduce per step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload audio_gru|text_bilstm]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the persistent GRU sweep): algorithmic
+flops per launch / its mean launch duration measured with HIP events on the launch stream during the timed
+region, against the dense fp32-MFMA peak.  `cpu_baseline` (N=1 only) times the same train step on the host
+cores with stock torch.nn (oracle/torch_cpu_baseline.py, validated against the reference's fixtures).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak
+WORKLOADS = {
+    # name: (module, class, B per GPU, T, F, H)
+    'audio_gru': ('audio_gru_whole', 'AudioBiLSTM', 512, 300, 256, 256),
+    'text_bilstm': ('text_bilstm_whole', 'TextBiLSTM', 512, 300, 1024, 128),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='audio_gru', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from icassp2022_depression_amd import _lib as L, nn, parallel
+    import importlib
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if world_env > 1:
+        parallel.init_from_env('nccl')
+    rank, world = parallel.rank(), parallel.world_size()
+    if world != args.gpus and rank == 0:
+        print(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(dev)
+
+    modname, cls, B, T, F, H = WORKLOADS[args.workload]
+    mod = importlib.import_module('icassp2022_depression_amd.' + modname)
+    cfg = dict(mod.config); cfg.update(embedding_size=F, hidden_dims=H)
+    torch.manual_seed(0)
+    model = getattr(mod, cls)(cfg, seed=0)
+    parallel.broadcast_params(model)
+    optimizer = nn.AdamW(mod.get_param_group(model), lr=cfg['learning_rate'])
+    criterion = nn.CrossEntropyLoss()
+    g = torch.Generator(device='cpu'); g.manual_seed(1234 + rank)
+    x = torch.randn(B, T, F, generator=g).to(dev)            # synthetic features, resident in HBM
+    y = torch.randint(0, 2, (B,), generator=g).to(dev)
+    model.train()
+
+    def step():
+        parallel.set_global_count(B * world)
+        optimizer.zero_grad()
+        out = model(x)
+        loss = criterion(out, y)
+        loss.backward()                                       # includes the RCCL all-reduce of the grad bucket
+        optimizer.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    parallel.barrier(); torch.cuda.synchronize()
+    L.profile_enable(True); L.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(); parallel.barrier()
+    dt = time.perf_counter() - t0
+    prof = L.profile_read(); L.profile_enable(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    final_loss = loss.item()
+
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    # ---- roofline of the dominant kernel ------------------------------------------------
+    G = 3 if args.workload == 'audio_gru' else 4
+    dirs = 1 if args.workload == 'audio_gru' else 2
+    sweep_flops = 2.0 * B * T * (G * H) * H * dirs           # one layer sweep launch (fwd or bwd): gates x H MACs
+    cats = {k: v for k, v in prof.items() if v[1] > 0}
+    sweeps = {k: v for k, v in cats.items() if 'sweep' in k}
+    dom = max(sweeps, key=lambda k: sweeps[k][0])
+    dom_ms = sweeps[dom][0] / sweeps[dom][1]
+    achieved = sweep_flops / (dom_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                'flops_per_launch': sweep_flops, 'avg_launch_ms': round(dom_ms, 4),
+                'kernels_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in cats.items()}}
+    train_flops_per_utt = 1.4156e9 if args.workload == 'audio_gru' else 2.831e9
+    step_tflops = train_flops_per_utt * value / 1e12 / world
+    roofline['step_mfma_frac'] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)
+
+    out = {'metric': 'utterances/sec (train step) for GRU-256 on (B,T,F)=(512,300,256)' if args.workload == 'audio_gru'
+           else 'utterances/sec (train step) for BiLSTM-128x2 on (B,T,F)=(512,300,1024)',
+           'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'{modname}.{cls} train step, B={B}/GPU T={T} F={F} H={H} L=2 dropout={cfg["dropout"]} '
+                                  f'AdamW, CE-on-softmax', 'global_batch': B * world, 'parallelism': f'dp{world}'},
+           'final_loss': round(final_loss, 6), 'roofline': roofline}
+
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_cpu_baseline as tb
+        threads = os.cpu_count() or 1
+        kind = 'audio' if args.workload == 'audio_gru' else 'text'
+        ups, sec, nthr = tb.time_train_step(kind, B, T, F, H, steps=3, warmup=1, threads=threads, lr=cfg['learning_rate'])
+        out['cpu_baseline'] = {'value': round(ups, 1), 'unit': 'utterances/s', 'cores': nthr, 'kind': 'port',
+                               'sample': f'same train step (stock torch.nn CPU, fp32), B={B} T={T}, median of 3 steps after 1 warm-up, '
+                                         f'{sec:.2f} s/step'}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

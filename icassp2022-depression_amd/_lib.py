@@ -58,6 +58,8 @@ _SIGS = {
     'dep_reduce_loss': (C.c_int, [_P, C.c_int, C.c_float, _P, C.c_int, _P]),
     'dep_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int, C.c_int, _P]),
+    'dep_profile_enable': (C.c_int, [C.c_int]),
+    'dep_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     'dep_fill': (C.c_int, [_P, C.c_long, C.c_float, _P]),
     'dep_axpby': (C.c_int, [_P, _P, C.c_long, C.c_float, C.c_float, _P]),
     'dep_sigmoid_gate': (C.c_int, [_P, _P, _P, C.c_long, _P]),
@@ -280,3 +282,18 @@ class Rnn:
                                         self._garr, _ptr(dx), _ptr(self.reserve), self.reserve.numel() * 4,
                                         _ptr(self.workspace), self.workspace.numel() * 4, stream()),
               'dep_rnn_backward')
+
+
+PROF_CATS = ('gru_fwd_sweep', 'gru_bwd_sweep', 'lstm_fwd_sweep', 'lstm_bwd_sweep', 'gemm_nt', 'gemm_nn', 'gemm_tn')
+
+
+def profile_enable(on=True):
+    load().dep_profile_enable(int(on))
+
+
+def profile_read():
+    """{category: (total_ms, launches)} since the last read (HIP events on the launch stream)."""
+    n = len(PROF_CATS)
+    ms = (C.c_double * n)(); cnt = (C.c_int * n)()
+    load().dep_profile_read(ms, cnt, n)
+    return {PROF_CATS[i]: (ms[i], cnt[i]) for i in range(n)}

@@ -3,6 +3,8 @@
 // See include/dep_rnn.h for the contract and the reference call sites each entry replaces.
 #include <stdarg.h>
 #include <string.h>
+#include <utility>
+#include <vector>
 #include "dep_common.h"
 
 static thread_local char g_err[512] = "";
@@ -17,6 +19,44 @@ void dep_set_error(const char* fmt, ...) {
 extern "C" const char* dep_last_error(void) { return g_err; }
 extern "C" int dep_version(void) { return 100; }
 extern "C" const char* dep_arch(void) { return "gfx950"; }
+
+// ---- event-based kernel timing -------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int cat; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+ProfRec g_cur;
+}  // namespace
+bool dep_prof_on() { return g_prof_on; }
+void dep_prof_begin(int cat, hipStream_t s) {
+    if (g_pool.empty()) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        g_pool.push_back({a, b});
+    }
+    g_cur.a = g_pool.back().first; g_cur.b = g_pool.back().second; g_cur.cat = cat;
+    g_pool.pop_back();
+    (void)hipEventRecord(g_cur.a, s);
+}
+void dep_prof_end(hipStream_t s) {
+    (void)hipEventRecord(g_cur.b, s);
+    g_recs.push_back(g_cur);
+}
+extern "C" int dep_profile_enable(int on) { g_prof_on = on != 0; return DEP_OK; }
+// Sums the recorded launch durations per category (ms) and resets; blocks until the events completed.
+extern "C" int dep_profile_read(double* total_ms, int* counts, int ncat) {
+    for (int i = 0; i < ncat; ++i) { total_ms[i] = 0.0; counts[i] = 0; }
+    for (auto& r : g_recs) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        if (r.cat < ncat) { total_ms[r.cat] += ms; counts[r.cat] += 1; }
+        g_pool.push_back({r.a, r.b});
+    }
+    g_recs.clear();
+    return DEP_OK;
+}
 
 namespace {
 

@@ -69,6 +69,18 @@ __device__ __forceinline__ float dep_dropmask1(uint64_t seed, uint32_t site, uin
 // dropout sites (Philox counter word 2): distinct per place a mask is drawn in one step
 enum { DEP_SITE_RNN0 = 16 /* + layer */, DEP_SITE_USER = 0 };
 
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
+enum { DEP_PROF_GRU_FWD = 0, DEP_PROF_GRU_BWD = 1, DEP_PROF_LSTM_FWD = 2, DEP_PROF_LSTM_BWD = 3,
+       DEP_PROF_GEMM_NT = 4, DEP_PROF_GEMM_NN = 5, DEP_PROF_GEMM_TN = 6, DEP_PROF_NCAT = 7 };
+bool dep_prof_on();
+void dep_prof_begin(int cat, hipStream_t s);
+void dep_prof_end(hipStream_t s);
+struct DepProfScope {
+    hipStream_t s; bool on;
+    DepProfScope(int cat, hipStream_t st) : s(st), on(dep_prof_on()) { if (on) dep_prof_begin(cat, s); }
+    ~DepProfScope() { if (on) dep_prof_end(s); }
+};
+
 // ---- internal launchers shared across translation units ---------------------------
 struct dep_sweep_args {
     int B, T, H;

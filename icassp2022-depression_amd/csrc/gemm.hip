@@ -249,6 +249,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     const bool bdim = transB ? (K % 4 == 0) : (N % 4 == 0);
     const bool vec = a16 && b16 && adim && bdim;
     dim3 g(dep_cdiv(N, BN), dep_cdiv(M, BM), splits);
+    DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s);
 #define LAUNCH(TA, TB)                                                                     \
     do {                                                                                   \
         if (vec) hipLaunchKernelGGL((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \

@@ -671,6 +671,7 @@ int dep_launch_sweep_fwd(const dep_sweep_args& a) {
     p.pooled = a.pooled; p.pool_scale = a.pool_scale; p.h_n = a.h_n;
     p.sv0 = a.training ? a.sv0 : nullptr; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
     DEP_CHECK_ARG(a.y && a.gi);
+    DepProfScope prof(a.cell == DEP_CELL_GRU ? DEP_PROF_GRU_FWD : DEP_PROF_LSTM_FWD, a.stream);
     if (dep_sweep_use_mfma(a.H, a.impl)) {
         int nw = 0; const int jpw = pick_jpw(a.H, &nw);
         const size_t lds = (size_t)2 * BT * (a.H + LPAD) * sizeof(float);
@@ -701,6 +702,7 @@ int dep_launch_sweep_bwd(const dep_sweep_bwd_args& a) {
     p.nwg = dep_sweep_num_wg(a.B, a.H, a.impl);
     DEP_CHECK_ARG(a.dbpart_rows >= p.nwg * a.dirs);
     DEP_CHECK_ARG(a.sv0 && a.dgi && a.dbpart);
+    DepProfScope prof(a.cell == DEP_CELL_GRU ? DEP_PROF_GRU_BWD : DEP_PROF_LSTM_BWD, a.stream);
     if (dep_sweep_use_mfma(a.H, a.impl)) {
         int nw = 0; const int jpw = pick_jpw(a.H, &nw);
         const size_t lds = (size_t)2 * BT * (G * a.H + LPAD) * sizeof(float);

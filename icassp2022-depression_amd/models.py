@@ -394,8 +394,6 @@ class MyLoss:
         dza = torch.empty_like(za) if train else None
         L.head_loss(kind, zt, t, None, rows, dzt, norm); L.reduce_loss(rows, norm, val)
         L.head_loss(kind, za, t, None, rows, dza, norm); L.reduce_loss(rows, norm, val, accumulate=True)
-        if train and parallel.world_size() > 1:
-            parallel.all_reduce_sum(val)
 
         def bw():
             g = Wp._grad
@@ -403,4 +401,4 @@ class MyLoss:
             L.gemm(1, 0, Cc, Ha, B, dza, Cc, audio_feature, Ha, g[:, Ht:], D)      # dW[:, Ht:] = dza^T audio
             model._grad_ready = True
             parallel.all_reduce_grads(model)
-        return nn.Loss(val, bw if train else None)
+        return nn.Loss(val, bw if train else None, reduce=train and parallel.world_size() > 1)

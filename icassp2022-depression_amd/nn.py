@@ -178,12 +178,18 @@ class Output:
 
 
 class Loss:
-    def __init__(self, value_dev, backward_fn):
+    def __init__(self, value_dev, backward_fn, reduce=False):
         self._v = value_dev
         self._bw = backward_fn
+        self._reduce = reduce               # data parallel: the local part of a global batch mean
 
     def item(self):
-        return float(self._v.item())        # host sync point, as in the reference (loss.item())
+        """Host sync point, as in the reference (loss.item()).  Under data parallelism every rank calls it
+        (train() does) and the per-rank parts are summed here, lazily, off the critical path."""
+        if self._reduce:
+            parallel.all_reduce_sum(self._v)
+            self._reduce = False
+        return float(self._v.item())
 
     def backward(self):
         if self._bw is None:
@@ -220,9 +226,7 @@ class _HeadLoss:
         L.head_loss(self.kind, z, t, None, rows, dz, norm)
         val = torch.zeros(1, dtype=torch.float32, device=dev)
         L.reduce_loss(rows, norm, val)
-        if train and parallel.world_size() > 1:
-            parallel.all_reduce_sum(val)
-        return Loss(val, (lambda: owner.backward(dz)) if train else None)
+        return Loss(val, (lambda: owner.backward(dz)) if train else None, reduce=train and parallel.world_size() > 1)
 
 
 class CrossEntropyLoss(_HeadLoss):

@@ -176,6 +176,15 @@ int dep_reduce_loss(const float* loss_rows, int B, float norm, float* loss_out, 
 int dep_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int decoupled, int step, void* stream);
 
+/* ------------------------------------------------------------------ profiling ------ */
+/* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
+ * roofline figure).  Categories: 0 GRU fwd sweep, 1 GRU bwd sweep, 2 LSTM fwd sweep, 3 LSTM bwd sweep,
+ * 4 GEMM NT (input projection / Linear), 5 GEMM NN (dX), 6 GEMM TN (weight gradients; the split-K
+ * reduce pass is not included).  dep_profile_read sums launch durations (ms) and counts per
+ * category, then resets. */
+int dep_profile_enable(int on);
+int dep_profile_read(double* total_ms, int* counts, int ncat);
+
 /* ------------------------------------------------------------------ misc ----------- */
 int dep_fill(float* p, long n, float value, void* stream);
 /* y = a*x + b*y */

@@ -1,0 +1,120 @@
+"""Host logic on CPU: loaders' helpers, metrics, augmentation, data-parallel sharding (gloo, world_size 2),
+and the stock-torch CPU baseline against the reference fixtures."""
+import itertools
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from icassp2022_depression_amd import _common, parallel
+from oracle import ref_numpy as R
+from oracle import torch_cpu_baseline as TB
+
+
+def test_confusion_matrix_and_prf():
+    y = np.array([1, 1, 0, 0, 1, 0]); p = np.array([1, 0, 0, 1, 1, 0])
+    cm = _common.standard_confusion_matrix(torch.from_numpy(y), p)
+    assert cm.tolist() == [[2, 1], [1, 2]]                   # [[TP, FP], [FN, TN]]
+    acc, prec, rec, f1 = _common.prf(cm)
+    assert (acc, prec, rec) == (4 / 6, 2 / 3, 2 / 3) and abs(f1 - 2 / 3) < 1e-12
+    with pytest.raises(ValueError):                          # one class only: the reference's 2x2 unpack fails
+        _common.standard_confusion_matrix(np.array([1, 1]), np.array([1, 1]))
+    acc, prec, rec, f1 = _common.prf(np.array([[0, 0], [3, 3]]))   # 0/0 precision -> nan, not an exception
+    assert np.isnan(prec) and rec == 0.0 and np.isnan(f1)
+
+
+def test_minibatches_ragged_tail():
+    assert list(_common.minibatches(10, 4)) == [(0, 4), (4, 8), (8, 10)]
+    assert list(_common.minibatches(8, 8)) == [(0, 8)]
+
+
+def test_permutation_augment_matches_itertools_order():
+    rng = np.random.default_rng(0)
+    feats = rng.standard_normal((5, 3, 4)); targs = np.array([0, 1, 0, 1, 0])
+    f2, t2, idxs = _common.permutation_augment(feats, targs, [0, 1, 3, 4], lambda i: targs[i] == 1, (0, 1, 4, 5), label=1)
+    assert idxs == [0, 5, 6, 7, 8, 9, 10, 11, 12, 4] and f2.shape == (13, 3, 4) and t2[5:].tolist() == [1] * 8
+    perms = list(itertools.permutations(feats[1], 3))
+    for k, c in enumerate((0, 1, 4, 5)):
+        assert np.array_equal(f2[5 + k], np.stack(perms[c]))
+    f3, t3, idxs3 = _common.permutation_augment(feats, targs.astype(float), [1], lambda i: True, range(6))
+    assert len(idxs3) == 6 and np.array_equal(f3[5], feats[1]) and t3[5:].tolist() == [1.0] * 6
+
+
+def test_shard_slice_partitions_every_batch():
+    for n in (1, 2, 5, 8, 511, 512):
+        for w in (1, 2, 4, 8):
+            parts = [parallel.shard_slice(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_torch_baseline_matches_reference_fixture():
+    """oracle/torch_cpu_baseline.py is the CPU yardstick of bench.py: same state_dict -> same outputs as the
+    reference's own classes (fixtures), so timing it times the reference's arithmetic."""
+    for name, cls in (('audio_clf_mid', TB.AudioClf), ('text_clf_mid', TB.TextClf)):
+        g = load_golden(name)
+        B, T, F, H = [int(v) for v in g['shape']]
+        m = cls(F, H, p=0.0)
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()}, strict=True)
+        m.eval()
+        with torch.no_grad():
+            out = m(torch.from_numpy(g['x'])).numpy()
+        assert np.abs(out - g['out_eval']).max() < 1e-6
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from icassp2022_depression_amd import parallel as par
+    par.init_from_env('gloo')
+    g = load_golden('audio_clf_tiny')
+    P = R.to_f64(g['sd']); x = g['x'].astype(np.float64); y = g['y']
+    B = x.shape[0] + 1                                         # 5 rows -> ragged shards 3 + 2
+    x = np.concatenate([x, x[:1] * 0.5]); y = np.concatenate([y, y[:1]])
+    lo, hi = par.shard_slice(B)
+    par.set_global_count(B)
+    out, cache = R.audio_forward(P, x[lo:hi], {'rnn_layers': 2}, 'clf')
+    # every rank normalises by the GLOBAL batch: local mean-loss gradient * (n_local / n_global)
+    n_loc = hi - lo
+    _, dout = R.ce_on_probs(out, y[lo:hi])
+    dout = dout * n_loc / par.global_count(n_loc)
+    _, G = R.audio_backward(P, dout, cache)
+    names = sorted(G)
+
+    class FakeModel:
+        _grad_ready = True
+        bucket = torch.from_numpy(np.concatenate([G[k].reshape(-1) for k in names]))
+
+        def live_grad_bucket(self):
+            return self.bucket
+    fm = FakeModel()
+    par.all_reduce_grads(fm)                                   # ONE collective on ONE contiguous bucket
+    if rank == 0:
+        of, cf = R.audio_forward(P, x, {'rnn_layers': 2}, 'clf')
+        _, df = R.ce_on_probs(of, y)
+        _, Gf = R.audio_backward(P, df, cf)
+        ref = np.concatenate([Gf[k].reshape(-1) for k in names])
+        q.put(float(np.abs(fm.bucket.numpy() - ref).max() / np.abs(ref).max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_sum_of_shards_equals_full_batch_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err < 1e-12
