@@ -30,6 +30,19 @@ WORKLOADS = {
 }
 
 
+def usable_cores():
+    """Host cores this process may really use: min(affinity mask, cgroup CPU quota).  os.cpu_count() alone
+    over-subscribes a quota-limited container (256 logical CPUs visible, 16 granted on the GPU box)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -129,7 +142,7 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import torch_cpu_baseline as tb
-        threads = os.cpu_count() or 1
+        threads = usable_cores()
         kind = 'audio' if args.workload == 'audio_gru' else 'text'
         ups, sec, nthr = tb.time_train_step(kind, B, T, F, H, steps=3, warmup=1, threads=threads, lr=cfg['learning_rate'])
         out['cpu_baseline'] = {'value': round(ups, 1), 'unit': 'utterances/s', 'cores': nthr, 'kind': 'port',
