@@ -36,6 +36,7 @@ _SIGS = {
     'dep_rnn_workspace_bytes': (C.c_size_t, [C.POINTER(RnnDesc)]),
     'dep_rnn_reserve_y_offset': (C.c_size_t, [C.POINTER(RnnDesc), C.c_int]),
     'dep_rnn_reserve_ydrop_offset': (C.c_size_t, [C.POINTER(RnnDesc), C.c_int]),
+    'dep_rnn_status': (C.c_int, [C.POINTER(RnnDesc), _P, _P]),
     'dep_rnn_forward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     'dep_rnn_backward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, C.POINTER(_P), _P, _P,
                                    C.c_size_t, _P, C.c_size_t, _P]),
@@ -248,6 +249,10 @@ class Rnn:
         self.n_w = 4 * L * dirs
         self._warr = (_P * self.n_w)()
         self._garr = (_P * self.n_w)()
+
+    def check(self):
+        """Synchronise and raise if a cluster sweep gave up on a bounded spin (never silently wrong)."""
+        check(self.lib.dep_rnn_status(C.byref(self.desc), _ptr(self.workspace), stream()), 'dep_rnn_status')
 
     def layer_output(self, layer=None):
         """Zero-copy view of a layer's output sequence (B,T,H*dirs) inside the reserve."""

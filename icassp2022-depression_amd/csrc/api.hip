@@ -69,10 +69,11 @@ struct Layout {
     size_t y[MAXL], ydrop[MAXL], sv[MAXL][4], wp[MAXL][2], wpT[MAXL][2];
     size_t reserve_floats;
     // workspace (float offsets)
-    size_t gi, dghn, dx[2], dbpart, biastmp, gemm;
-    size_t gemm_bytes, ws_floats;
+    size_t gi, dghn, dx[2], dbpart, biastmp, gemm, xbuf;
+    size_t gemm_bytes, xbuf_bytes, ws_floats;
     int nwg;
     bool drop;
+    bool cluster;                    // cluster-parallel sweeps (rnn_cluster.hip)
 };
 
 bool make_layout(const dep_rnn_desc* d, Layout& lo) {
@@ -123,6 +124,12 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
         if (b2 > gb) gb = b2;
     }
     lo.gemm = w; lo.gemm_bytes = gb; w += al(gb / sizeof(float) + 64);
+    // impl: 0 auto (cluster > tile-MFMA > generic), 1 generic, 2 tile-MFMA, 3 cluster (must be supported)
+    const bool cok = dep_cluster_ok(d->cell, d->H, d->B, d->dirs);
+    if (d->impl == 3 && !cok) return false;
+    lo.cluster = cok && (d->impl == 0 || d->impl == 3);
+    lo.xbuf = w; lo.xbuf_bytes = lo.cluster ? dep_cluster_xbuf_bytes(d->cell, d->H, d->B, d->dirs) : 0;
+    w += al(lo.xbuf_bytes / sizeof(float) + 64);
     lo.ws_floats = w;
     return true;
 }
@@ -151,6 +158,21 @@ extern "C" size_t dep_rnn_reserve_ydrop_offset(const dep_rnn_desc* d, int layer)
     return lo.ydrop[layer] * sizeof(float);
 }
 
+// Status of the cluster sweeps that ran on (workspace): 0 ok, 2 = a bounded spin gave up (a cluster member was
+// not resident or died).  Synchronises the stream.
+extern "C" int dep_rnn_status(const dep_rnn_desc* d, void* workspace, void* stream) {
+    Layout lo;
+    DEP_CHECK_ARG(make_layout(d, lo) && workspace);
+    if (!lo.cluster) return DEP_OK;
+    unsigned st = 0;
+    if (hipMemcpyAsync(&st, (float*)workspace + lo.xbuf, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        dep_set_error("dep_rnn_status: HIP copy failed"); return DEP_ERR_HIP;
+    }
+    if (st != 0) { dep_set_error("cluster sweep gave up waiting for a member (status %u)", st); return DEP_ERR_HIP; }
+    return DEP_OK;
+}
+
 extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const float* const* weights, float* y,
                                float* pooled, float* h_n, void* reserve, size_t reserve_bytes, void* workspace,
                                size_t workspace_bytes, void* stream) {
@@ -167,7 +189,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     float* R = (float*)reserve; float* W = (float*)workspace;
     const int B = d->B, T = d->T, H = d->H, D = d->dirs, G = lo.G, L = d->L;
     const int BTr = (int)lo.BT;
-    const bool mfma = dep_sweep_use_mfma(H, d->impl);
+    const bool mfma = lo.cluster || dep_sweep_use_mfma(H, d->impl);
     int rc;
     for (int l = 0; l < L; ++l) {
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
@@ -177,6 +199,9 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             DEP_CHECK_ARG(wl[0] && wl[1] && wl[2] && wl[3]);
             if (mfma) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
+            if (lo.cluster && d->training) {     // the cluster backward wants its own member-sliced image
+                rc = dep_pack_cluster_bwd(wl[1], R + lo.wpT[l][dd], G, H, s); if (rc) return rc;
+            }
             const float* bias = wl[2];
             if (d->cell == DEP_CELL_LSTM) {          // both biases fold into the projection
                 float* tb = W + lo.biastmp;
@@ -205,7 +230,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         a.h_n = h_n ? h_n + (size_t)l * D * B * H : nullptr;
         if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
         a.stream = s;
-        rc = dep_launch_sweep_fwd(a);
+        rc = lo.cluster ? dep_launch_cluster_fwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_fwd(a);
         if (rc) return rc;
     }
     if (y) {
@@ -255,7 +280,7 @@ extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const flo
         a.dh_n = dh_n ? dh_n + (size_t)l * D * B * H : nullptr;
         a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3];
         a.dgi = dgi; a.dghn = W + lo.dghn; a.dbpart = W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
-        rc = dep_launch_sweep_bwd(a);
+        rc = lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
         if (rc) return rc;
         float* dbi[2]; float* dbh[2];
         for (int dd = 0; dd < D; ++dd) {

@@ -132,6 +132,13 @@ int dep_pack_whh(const float* w_hh, float* wp, float* wpT, int G, int H, hipStre
 // bias-gradient finish: sums partial rows
 int dep_finish_db(const dep_sweep_bwd_args& a, float* const* db_ih, float* const* db_hh);
 
+// cluster-parallel sweeps (rnn_cluster.hip)
+bool dep_cluster_ok(int cell, int H, int B, int dirs);
+size_t dep_cluster_xbuf_bytes(int cell, int H, int B, int dirs);
+int dep_pack_cluster_bwd(const float* w_hh, float* out, int G, int H, hipStream_t s);
+int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
+int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
+
 int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* A, int lda,
                       const float* B, int ldb, float* C, int ldc, const float* bias, float beta,
                       int seq_T, int shiftB, void* ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,404 @@
+// Cluster-parallel GRU BPTT sweep, flag-published exchange (cdna_hip_programming.md G16 recipe R1).
+//
+// Same decomposition as rnn_cluster.hip (member c of a 16-utterance tile's cluster keeps the W_hh rows of
+// hidden units [32c, 32c+32) in VGPRs and turns ITS 16x96 slice of dgh_t into a partial dh_{t-1} for all H
+// columns), but the reduce-scatter of the partials moves 4096 values per member per step, too many for
+// 8-byte tagged granules (each narrow write-through store is its own fabric write).  Here the partials are
+// plain fp32 written in MFMA-fragment order with wave-contiguous 16-byte sc1 (write-through) stores, every
+// wave drains (s_waitcnt vmcnt(0)), the workgroup barriers, and one lane publishes the step's epoch in the
+// member's flag word; consumers poll the NC flags with relaxed agent-scope loads (>= epoch: flags only grow)
+// and then read their two columns of every member's partial with sc1 loads, summing in member order
+// (deterministic).  Payload buffers alternate by step parity; only the status/flag words are zeroed per launch.
+#include "dep_common.h"
+
+namespace {
+
+constexpr int BT = 16;
+constexpr int LPAD = 4;
+constexpr int CT = 256;
+constexpr unsigned SPIN_LIMIT = 1u << 20;
+constexpr size_t FLAG_OFF = 256, PAYLOAD_OFF = 8192;
+
+typedef unsigned long long u64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+struct P2 {
+    int B, T, H, nbtp;
+    const f32x4* wp;
+    const float* y; int ldy;
+    const float* dy; int lddy;
+    float drop_p, drop_scale; uint64_t seed; uint32_t site;
+    const float* dpooled; float pool_scale;
+    const float* dh_n;
+    const float* sv0; const float* sv1; const float* sv2; const float* sv3;
+    float* dgi; int lddg;
+    float* dghn;
+    float* dbpart;
+    unsigned* status; unsigned* flags; float* payload; unsigned payload_bytes;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ float2 f2(float a, float b) { return make_float2(a, b); }
+
+__device__ __forceinline__ unsigned ld_agent(unsigned* p) {
+    return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) {
+    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld2_agent(const float* p) {      // 8-byte sc1 load (bypasses the stale-prone L1)
+    const u64 x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)x), __uint_as_float((unsigned)(x >> 32)));
+}
+
+struct StepIn { float2 r, z, n, hn, hp, dy; };
+
+// Thread -> element map (matches the fragment order of the published partials, so the gather is coalesced):
+//   jl = tid>>7 (which of the member's two 16-column tiles), lp = (tid>>1)&63 (MFMA lane id: row lp&15, quad lp>>4),
+//   half = tid&1 -> columns (2c+jl)*16 + (lp>>4)*4 + 2*half + {0,1} of utterance row lp&15.
+template <int NTW>      // output tiles per wave = H/64
+__global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 96, KCB = KS / 16, LDG = KS + LPAD;
+    const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
+    const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
+    if (bt * BT >= p.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int jl = tid >> 7, lp = (tid >> 1) & 63, half = tid & 1;
+    const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;      // unit inside the member's 32
+    const int col = 32 * c + ul;
+    const int b = bt * BT + j;
+    const bool valid = b < p.B;
+    float* dgs = smem;                                                     // [16][LDG]
+
+    f32x4 wr[NTW][KCB];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int k = 0; k < KCB; ++k)
+            wr[i][k] = p.wp[(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
+    float2 dhrec = (p.dh_n && valid) ? ld2(p.dh_n + (size_t)b * H + col) : f2(0.f, 0.f);
+    float2 dpl = f2(0.f, 0.f);
+    if (p.dpooled && valid) { dpl = ld2(p.dpooled + (size_t)b * H + col); dpl.x *= p.pool_scale; dpl.y *= p.pool_scale; }
+    float2 dbr = f2(0.f, 0.f), dbz = dbr, dbn = dbr, dbh = dbr;
+    const size_t pstride = (size_t)p.nbtp * NC * BT * H;                   // floats per parity buffer
+    const size_t tile_base = (size_t)bt * NC * BT * H;                     // this tile's [NC][NTT][64][4] block
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
+    unsigned* myflag = p.flags + bt * NC + c;
+    unsigned* tflags = p.flags + bt * NC;
+    const int ml = lane & 15, mq = lane >> 4;
+    bool dead = false;
+
+    auto load_step = [&](int t, StepIn& s) {
+        s.r = s.z = s.n = s.hn = s.hp = s.dy = f2(0.f, 0.f);
+        if (valid && t >= 0) {
+            const size_t row = (size_t)b * T + t;
+            const size_t so = row * H + col;
+            s.r = ld2(p.sv0 + so); s.z = ld2(p.sv1 + so); s.n = ld2(p.sv2 + so); s.hn = ld2(p.sv3 + so);
+            if (t > 0) s.hp = ld2(p.y + (row - 1) * p.ldy + col);
+            if (p.dy) s.dy = ld2(p.dy + row * p.lddy + col);
+        }
+    };
+    StepIn cur, nxt;
+    load_step(T - 1, cur);
+
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t row = (size_t)b * T + t;
+        float2 dyv = cur.dy;
+        if (p.dy && p.drop_p > 0.f && valid) {
+            const size_t o = row * p.lddy + col;
+            const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+            dyv.x *= (half ? m[2] : m[0]); dyv.y *= (half ? m[3] : m[1]);
+        }
+        const float2 r = cur.r, z = cur.z, n = cur.n, hn = cur.hn, hp = cur.hp;
+        const float2 d = f2(dhrec.x + dpl.x + dyv.x, dhrec.y + dpl.y + dyv.y);
+        float2 dn, dz, dr, dnr, dzt;
+        dn.x = d.x * (1.0f - z.x) * (1.0f - n.x * n.x); dn.y = d.y * (1.0f - z.y) * (1.0f - n.y * n.y);
+        dz.x = d.x * (hp.x - n.x) * z.x * (1.0f - z.x); dz.y = d.y * (hp.y - n.y) * z.y * (1.0f - z.y);
+        dr.x = dn.x * hn.x * r.x * (1.0f - r.x); dr.y = dn.y * hn.y * r.y * (1.0f - r.y);
+        dnr.x = dn.x * r.x; dnr.y = dn.y * r.y;
+        dzt.x = d.x * z.x; dzt.y = d.y * z.y;
+        st2(dgs + j * LDG + ul, dr); st2(dgs + j * LDG + 32 + ul, dz); st2(dgs + j * LDG + 64 + ul, dnr);
+        if (valid) {
+            float* g = p.dgi + row * p.lddg;
+            st2(g + col, dr); st2(g + H + col, dz); st2(g + 2 * H + col, dn);
+            st2(p.dghn + row * H + col, dnr);
+        }
+        dbr.x += dr.x; dbr.y += dr.y; dbz.x += dz.x; dbz.y += dz.y; dbn.x += dn.x; dbn.y += dn.y; dbh.x += dnr.x; dbh.y += dnr.y;
+        __syncthreads();
+        if (t == 0) break;
+        load_step(t - 1, nxt);                       // independent of the recurrence: in flight under the MFMAs
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] = zero4();
+        const float* drow = dgs + ml * LDG + mq * 4;
+#pragma unroll
+        for (int k = 0; k < KCB; ++k) {
+            const f32x4 hv = ld4(drow + k * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[e], acc[i], 0, 0, 0);
+        }
+        // publish: payload[parity][tile][src c][out tile][lane][4]
+        const unsigned epoch = (unsigned)(T - t);
+        const size_t pbase = (size_t)(t & 1) * pstride + tile_base;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const size_t fo = pbase + ((size_t)(c * NTT + w * NTW + i) * 64 + lane) * 4;
+            u32x4 v;
+            v.x = __float_as_uint(acc[i][0]); v.y = __float_as_uint(acc[i][1]);
+            v.z = __float_as_uint(acc[i][2]); v.w = __float_as_uint(acc[i][3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 16 /* sc1: write-through */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) st_agent(myflag, epoch);
+        // wait for every member's flag (one wave polls, relaxed; flags are monotonic)
+        if (w == 0) {
+            for (unsigned spins = 0;; ++spins) {
+                const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
+                if (__all(ok)) break;
+                if (spins > SPIN_LIMIT) { st_agent(p.status, 3); dead = true; break; }
+                if ((spins & 63) == 63 && ld_agent(p.status) != 0) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (__syncthreads_or(dead)) return;
+        // gather this thread's two columns from the NC partials, sum in member order
+        float2 s = f2(0.f, 0.f);
+        const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
+        float2 part[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            part[m] = (m < NC) ? ld2_agent(src + (size_t)m * NTT * 256) : f2(0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { s.x += part[m].x; s.y += part[m].y; }
+        dhrec = f2(dzt.x + s.x, dzt.y + s.y);
+        cur = nxt;
+    }
+    // bias-gradient partials dbpart[bt][4][H]: sum over the 16 utterance rows = lanes that differ in bits 1..4
+    float2 a[4] = {dbr, dbz, dbn, dbh};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int m = 2; m <= 16; m <<= 1) { a[k].x += __shfl_xor(a[k].x, m, 64); a[k].y += __shfl_xor(a[k].y, m, 64); }
+    if (j == 0) {
+        float* o = p.dbpart + (size_t)bt * 4 * H;
+        st2(o + col, a[0]); st2(o + H + col, a[1]); st2(o + 2 * H + col, a[2]); st2(o + 3 * H + col, a[3]);
+    }
+}
+
+// =============================================================================== GRU forward, flag-published
+// Same member/wave roles as gru_fwd_cluster (rnn_cluster.hip): wave w = (hidden tile jl = w>>1, K half kh = w&1).
+// h_t travels as plain fp32 rows payload[parity][tile][16][H]: each lane stores its two values with one 8-byte
+// sc1 store, the workgroup drains + barriers, one lane raises the member's flag; after the NC flags are seen the
+// whole 16xH block is read once with 16-byte sc1 loads into LDS (no per-value polling traffic).
+struct F2 {
+    int B, T, H, nbtp;
+    const f32x4* wp; const float* b_hh;
+    const float* gi; int ldgi;
+    float* y; int ldy;
+    float* ydrop; float drop_p, drop_scale; uint64_t seed; uint32_t site;
+    float* pooled; float pool_scale;
+    float* h_n;
+    float* sv0; float* sv1; float* sv2; float* sv3;
+    unsigned* status; unsigned* flags; float* payload; unsigned payload_bytes;
+};
+
+template <int KCH>
+__global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
+    const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
+    if (bt * BT >= p.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4, jl = w >> 1, kh = w & 1;
+    const int jt = c * 2 + jl;
+    const int b = bt * BT + j;
+    const bool valid = b < p.B;
+    float* hs = smem;                                 // [16][LDH]
+    float* red = smem + BT * LDH;                     // [4][3][64][4]
+    for (int i = tid; i < BT * LDH; i += CT) hs[i] = 0.f;
+
+    f32x4 wr[3][KCH];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+            wr[g][k] = p.wp[(size_t)((jt * 3 + g) * KC + kh * KCH + k) * 64 + lane];
+    const int col = jt * 16 + q * 4 + 2 * kh;
+    float2 bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = ld2(p.b_hh + g * H + col);
+    float2 hprev = f2(0.f, 0.f), pool = f2(0.f, 0.f);
+    const size_t pstride = (size_t)p.nbtp * BT * H;
+    const size_t tile_base = (size_t)bt * BT * H;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
+    unsigned* myflag = p.flags + bt * NC + c;
+    unsigned* tflags = p.flags + bt * NC;
+    const int hshift = __ffs(H) - 1;
+    bool dead = false;
+    float2 gin[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+        gin[g] = valid ? ld2(p.gi + (size_t)b * T * p.ldgi + g * H + col) : f2(0.f, 0.f);
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const size_t row = (size_t)b * T + t;
+        float2 gi[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gi[g] = gin[g];
+        if (valid && t + 1 < T) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gin[g] = ld2(p.gi + (row + 1) * p.ldgi + g * H + col);
+        }
+        f32x4 acc[3] = {zero4(), zero4(), zero4()};
+        const float* hrow = hs + j * LDH + kh * KCH * 16 + q * 4;
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) {
+            const f32x4 hv = ld4(hrow + k * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[e], acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + ((w * 3 + g) * 64 + lane) * 4) = acc[g];
+        __syncthreads();
+        float2 tot[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float2 pv = ld2(red + (((w ^ 1) * 3 + g) * 64 + lane) * 4 + 2 * kh);
+            tot[g].x = (kh ? acc[g][2] : acc[g][0]) + pv.x;
+            tot[g].y = (kh ? acc[g][3] : acc[g][1]) + pv.y;
+        }
+        float2 r, z, hn, n, h;
+        r.x = dep_sigmoid(gi[0].x + tot[0].x + bh[0].x); r.y = dep_sigmoid(gi[0].y + tot[0].y + bh[0].y);
+        z.x = dep_sigmoid(gi[1].x + tot[1].x + bh[1].x); z.y = dep_sigmoid(gi[1].y + tot[1].y + bh[1].y);
+        hn.x = tot[2].x + bh[2].x; hn.y = tot[2].y + bh[2].y;
+        n.x = tanhf(gi[2].x + r.x * hn.x); n.y = tanhf(gi[2].y + r.y * hn.y);
+        h.x = (1.0f - z.x) * n.x + z.x * hprev.x; h.y = (1.0f - z.y) * n.y + z.y * hprev.y;
+        hprev = h; pool.x += h.x; pool.y += h.y;
+        const unsigned epoch = (unsigned)t + 1u;
+        const size_t pbase = (size_t)(t & 1) * pstride + tile_base;
+        const bool more = t + 1 < T;
+        if (more) {       // publish first: it is on the critical path of the other members
+            const u64 bits = (u64)__float_as_uint(h.x) | ((u64)__float_as_uint(h.y) << 32);
+            __hip_atomic_store((gu64*)(p.payload + pbase + (size_t)j * H + col), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) st_agent(myflag, epoch);
+        }
+        if (valid) {
+            const size_t o = row * p.ldy + col;
+            st2(p.y + o, h);
+            if (p.ydrop) {
+                const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+                st2(p.ydrop + o, f2(h.x * (kh ? m[2] : m[0]), h.y * (kh ? m[3] : m[1])));
+            }
+            if (p.sv0) {
+                const size_t so = row * H + col;
+                st2(p.sv0 + so, r); st2(p.sv1 + so, z); st2(p.sv2 + so, n); st2(p.sv3 + so, hn);
+            }
+        }
+        if (more) {
+            if (w == 0) {
+                for (unsigned spins = 0;; ++spins) {
+                    const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
+                    if (__all(ok)) break;
+                    if (spins > SPIN_LIMIT) { st_agent(p.status, 4); dead = true; break; }
+                    if ((spins & 63) == 63 && ld_agent(p.status) != 0) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (__syncthreads_or(dead)) return;
+            constexpr int PER = KCH / 2;              // 16-byte pieces per thread = 16*H/4/256
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i4 = (tid + CT * k) * 4;    // float index inside the 16xH block
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((pbase + i4) * 4), 0, 16 /* sc1 */);
+                f32x4 f;
+                f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+                *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
+            }
+            __syncthreads();
+        }
+    }
+    if (valid) {
+        if (p.pooled) st2(p.pooled + (size_t)b * H + col, f2(pool.x * p.pool_scale, pool.y * p.pool_scale));
+        if (p.h_n) st2(p.h_n + (size_t)b * H + col, hprev);
+    }
+}
+
+}  // namespace
+
+int dep_launch_cluster_fwd_granule(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
+
+int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
+    static int use_granule = -1;
+    if (use_granule < 0) { const char* e = getenv("DEP_CLUSTER_FWD"); use_granule = (e && e[0] == 'g') ? 1 : 0; }
+    if (use_granule) return dep_launch_cluster_fwd_granule(a, xbuf, xbuf_bytes);
+    DEP_CHECK_ARG(dep_cluster_ok(a.cell, a.H, a.B, a.dirs) && xbuf && xbuf_bytes >= dep_cluster_xbuf_bytes(a.cell, a.H, a.B, a.dirs));
+    const int NC = a.H / 32, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    F2 p{};
+    p.B = a.B; p.T = a.T; p.H = a.H; p.nbtp = nbtp;
+    p.wp = (const f32x4*)a.wp[0]; p.b_hh = a.b_hh[0];
+    p.gi = a.gi; p.ldgi = 3 * a.H; p.y = a.y; p.ldy = a.ldy;
+    p.ydrop = (a.drop_p > 0.f) ? a.ydrop : nullptr;
+    p.drop_p = a.drop_p; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f; p.seed = a.seed; p.site = a.site;
+    p.pooled = a.pooled; p.pool_scale = a.pool_scale; p.h_n = a.h_n;
+    p.sv0 = a.training ? a.sv0 : nullptr; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
+    const size_t pay = (size_t)2 * nbtp * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC * 4 <= PAYLOAD_OFF - FLAG_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF);
+    p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
+    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+    DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
+    const size_t lds = (size_t)(BT * (a.H + LPAD) + 4 * 3 * 64 * 4) * sizeof(float);
+    dim3 grid(NC * nbtp);
+    if (a.H == 128) hipLaunchKernelGGL(gru_fwd_cluster_r1<4>, grid, dim3(CT), lds, a.stream, p);
+    else hipLaunchKernelGGL(gru_fwd_cluster_r1<8>, grid, dim3(CT), lds, a.stream, p);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
+
+int dep_launch_cluster_bwd_granule(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
+
+int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
+    static int use_granule = -1;
+    if (use_granule < 0) { const char* e = getenv("DEP_CLUSTER_BWD"); use_granule = (e && e[0] == 'g') ? 1 : 0; }
+    if (use_granule) return dep_launch_cluster_bwd_granule(a, xbuf, xbuf_bytes);
+    DEP_CHECK_ARG(dep_cluster_ok(a.cell, a.H, a.B, a.dirs) && xbuf && xbuf_bytes >= dep_cluster_xbuf_bytes(a.cell, a.H, a.B, a.dirs));
+    const int NC = a.H / 32, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    P2 p{};
+    p.B = a.B; p.T = a.T; p.H = a.H; p.nbtp = nbtp;
+    p.wp = (const f32x4*)a.wpT[0];
+    p.y = a.y; p.ldy = a.ldy; p.dy = a.dy; p.lddy = a.lddy;
+    p.drop_p = a.dy ? a.drop_p : 0.f; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    p.seed = a.seed; p.site = a.site;
+    p.dpooled = a.dpooled; p.pool_scale = a.pool_scale; p.dh_n = a.dh_n;
+    p.sv0 = a.sv0; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
+    p.dgi = a.dgi; p.lddg = 3 * a.H; p.dghn = a.dghn; p.dbpart = a.dbpart;
+    DEP_CHECK_ARG(a.dbpart_rows >= nbt);
+    const size_t pay = (size_t)2 * nbtp * NC * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC * 4 <= PAYLOAD_OFF - FLAG_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF);
+    p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
+    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+    DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
+    const size_t lds = (size_t)(BT * (96 + LPAD)) * sizeof(float);
+    dim3 grid(NC * nbtp);
+    if (a.H == 128) hipLaunchKernelGGL(gru_bwd_cluster_r1<2>, grid, dim3(CT), lds, a.stream, p);
+    else hipLaunchKernelGGL(gru_bwd_cluster_r1<4>, grid, dim3(CT), lds, a.stream, p);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}

@@ -55,7 +55,8 @@ typedef struct {
     float   dropout_p;   /* inter-layer dropout probability (applied to layers 0..L-2 outputs) */
     uint64_t seed;       /* Philox key for this call's dropout masks */
     int32_t pool;        /* GRU only: DEP_POOL_* over T of the top layer (fused in the sweep) */
-    int32_t impl;        /* 0 auto, 1 force generic (non-MFMA) kernels, 2 force MFMA kernels */
+    int32_t impl;        /* 0 auto (cluster > tile-MFMA > generic), 1 generic kernels, 2 one-workgroup-per-tile
+                            MFMA kernels, 3 cluster-parallel MFMA kernels (GRU, H in {128,256}) */
 } dep_rnn_desc;
 
 size_t dep_rnn_reserve_bytes(const dep_rnn_desc* d);     /* activations kept fwd -> bwd */
@@ -65,6 +66,12 @@ size_t dep_rnn_workspace_bytes(const dep_rnn_desc* d);   /* scratch, either dire
 size_t dep_rnn_reserve_y_offset(const dep_rnn_desc* d, int layer);
 /* Same for the dropped-out copy that feeds layer+1 (training && dropout_p > 0 only). */
 size_t dep_rnn_reserve_ydrop_offset(const dep_rnn_desc* d, int layer);
+
+/* Health of the cluster-parallel sweeps that last ran on `workspace` (desc.impl 0/3 with H in {128,256}):
+ * they exchange data between workgroups inside one launch with bounded spins; if a spin ever gives up
+ * the kernels exit early and this returns DEP_ERR_HIP.  Synchronises `stream`.  Always DEP_OK for the
+ * single-workgroup kernels. */
+int dep_rnn_status(const dep_rnn_desc* d, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------ RNN stacks ----- */
 /* weights: array of 4*L*dirs device pointers ordered, for layer l and direction d (index

@@ -127,6 +127,10 @@ RNN_CASES = [
     ('gru', 8, 50, 39, 128, 2),         # BASELINE configs[0] shape
     ('gru', 37, 9, 64, 256, 2),         # ragged batch tile, 2 hidden tiles per wave (cfg2 H)
     ('gru', 5, 7, 12, 48, 2),           # 3 tiles on one wave
+    ('gru', 8, 50, 39, 128, 3),         # cluster-parallel sweeps: 4 members per tile
+    ('gru', 37, 9, 64, 256, 3),         # 8 members, ragged tile, padded tile count
+    ('gru', 130, 12, 32, 256, 3),       # 9 tiles -> 16 padded -> 128 workgroups
+    ('gru', 16, 300, 256, 256, 3),      # full T of the benchmark
     ('lstm', 4, 6, 5, 8, 1),
     ('lstm', 6, 20, 24, 16, 1),
     ('lstm', 6, 20, 24, 16, 2),
@@ -172,12 +176,13 @@ def test_rnn_stack_fwd_bwd(cell, B, T, F, H, impl):
         rnn.backward(xd, Wd, Gd, dy=dev(dyv), dh_n=dev(dhn), dx=dxd)
         dxr, Gr = R.bilstm_stack_bwd(dyv.astype(np.float32).astype(np.float64), dhn.astype(np.float32).astype(np.float64),
                                      P, prefix, Lyr, caches)
+    rnn.check()
     assert relerr(host(dxd), dxr) < 1e-4, 'dx'
     for n, g in zip(names, Gd):
         assert relerr(host(g), Gr[n]) < 1e-4, n
 
 
-@pytest.mark.parametrize('cell,impl,H', [('gru', 2, 16), ('gru', 1, 16), ('lstm', 2, 16), ('lstm', 1, 8)])
+@pytest.mark.parametrize('cell,impl,H', [('gru', 2, 16), ('gru', 1, 16), ('lstm', 2, 16), ('lstm', 1, 8), ('gru', 3, 128)])
 def test_rnn_interlayer_dropout_matches_oracle_with_same_masks(cell, impl, H):
     """nn.GRU/LSTM(dropout=p) training mode: the oracle is fed the masks the HIP path drew."""
     rng = np.random.default_rng(77 + impl + H)
