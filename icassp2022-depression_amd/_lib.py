@@ -43,6 +43,10 @@ _SIGS = {
     'dep_gemm_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
     'dep_gemm_f32': (C.c_int, [C.c_int] * 5 + [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_float, C.c_int, C.c_int,
                                _P, C.c_size_t, _P]),
+    'dep_gemm_bf16x3': (C.c_int, [C.c_int] * 5 + [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_float, C.c_int, C.c_int,
+                                  _P, C.c_size_t, _P]),
+    'dep_set_gemm_mode': (C.c_int, [C.c_int, C.c_long]),
+    'dep_get_gemm_mode': (C.c_int, []),
     'dep_layernorm_fwd': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     'dep_layernorm_bwd_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'dep_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
@@ -116,6 +120,18 @@ def gemm(transA, transB, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, beta=0.0, 
     wsb = ws.numel() * ws.element_size() if ws is not None else 0
     check(lib.dep_gemm_f32(transA, transB, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(Cm), ldc, _ptr(bias), beta,
                            seq_T, shiftB, _ptr(ws), wsb, stream()), 'dep_gemm_f32')
+
+
+def gemm_split(transA, transB, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, beta=0.0, seq_T=0, shiftB=0, ws=None):
+    """dep_gemm_bf16x3: the 3-term bf16 split-precision kernel (fp32 in / fp32 accumulate)."""
+    lib = load()
+    wsb = ws.numel() * ws.element_size() if ws is not None else 0
+    check(lib.dep_gemm_bf16x3(transA, transB, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(Cm), ldc, _ptr(bias), beta,
+                              seq_T, shiftB, _ptr(ws), wsb, stream()), 'dep_gemm_bf16x3')
+
+
+def set_gemm_mode(mode, min_macs=-1):
+    check(load().dep_set_gemm_mode(int(mode), int(min_macs)), 'dep_set_gemm_mode')
 
 
 def gemm_ws(transA, transB, M, N, K, device):

@@ -340,7 +340,7 @@ extern "C" int dep_layernorm_fwd(const float* x, const float* gamma, const float
     return DEP_OK;
 }
 
-static int ln_bwd_blocks(int rows) { int b = dep_cdiv(rows, 64); return b > 1024 ? 1024 : b; }
+static int ln_bwd_blocks(int rows) { int b = dep_cdiv(rows, 64); return b > 512 ? 512 : b; }
 
 extern "C" size_t dep_layernorm_bwd_workspace_bytes(int rows, int F) {
     return dep_align((size_t)ln_bwd_blocks(rows) * 2 * F * sizeof(float));
@@ -357,7 +357,9 @@ extern "C" int dep_layernorm_bwd(const float* dy, const float* x, const float* g
     const int rpb = dep_cdiv(rows, nb);
     hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(nb), dim3(256), 0, S_, dy, x, mean_rstd, (float*)workspace, rows, F, rpb);
     DEP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3(nblk(2 * F, 128)), dim3(128), 0, S_, (const float*)workspace, nb, F, dgamma, dbeta);
+    // partial is [nb][2F]: column sums of its two halves (parallel over row groups, unlike the old serial finish)
+    hipLaunchKernelGGL(colsum_kernel, dim3(dep_cdiv(F, 64)), dim3(256), 0, S_, (const float*)workspace, nb, F, 2 * F, dgamma);
+    hipLaunchKernelGGL(colsum_kernel, dim3(dep_cdiv(F, 64)), dim3(256), 0, S_, (const float*)workspace + F, nb, F, 2 * F, dbeta);
     DEP_CHECK_LAUNCH();
     if (dx) {
         hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(dep_cdiv(rows, 4)), dim3(256), 0, S_, dy, x, gamma, mean_rstd, dx, rows, F);

@@ -215,6 +215,27 @@ bool naive_forced() {
 
 }  // namespace
 
+// ---- precision mode of the large contractions ----------------------------------------------------------
+// 0 = exact fp32 MFMA everywhere ; 1 = 3-term bf16 split (gemm_bf16x3.hip) for contractions of at least
+// g_split_min_macs multiply-adds (the time-parallel projections / dX / dW of the RNN stacks).  dep_gemm_f32 is
+// always exact.  Default: DEP_GEMM_MODE env ("f32" -> 0), else 1.
+int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
+                           int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
+                           int splits, int kchunk, float* part, bool vec, hipStream_t s);
+static int g_split_mode = -1;
+static long g_split_min_macs = 1L << 28;
+static thread_local int g_force_exact = 0;
+static void init_split_mode() {
+    if (g_split_mode < 0) { const char* e = getenv("DEP_GEMM_MODE"); g_split_mode = (e && e[0] == 'f') ? 0 : 1; }
+}
+extern "C" int dep_set_gemm_mode(int mode, long min_macs) {
+    if (mode != 0 && mode != 1) { dep_set_error("dep_set_gemm_mode: mode must be 0 (f32) or 1 (bf16x3 split)"); return DEP_ERR_ARG; }
+    g_split_mode = mode;
+    if (min_macs >= 0) g_split_min_macs = min_macs;
+    return DEP_OK;
+}
+extern "C" int dep_get_gemm_mode(void) { init_split_mode(); return g_split_mode; }
+
 extern "C" size_t dep_gemm_workspace_bytes(int transA, int transB, int M, int N, int K) {
     (void)transA; (void)transB;
     const int s = choose_splits(M, N, K);
@@ -250,7 +271,11 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     const bool vec = a16 && b16 && adim && bdim;
     dim3 g(dep_cdiv(N, BN), dep_cdiv(M, BM), splits);
     DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s);
-#define LAUNCH(TA, TB)                                                                     \
+    init_split_mode();
+    if (g_force_exact == 0 && g_split_mode == 1 && (long)M * N * K >= g_split_min_macs)
+        return dep_gemm_bf16x3_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
+                                      splits, kchunk, p.part, vec, s);
+#define LAUNCH(TA, TB)                                                                    \
     do {                                                                                   \
         if (vec) hipLaunchKernelGGL((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \
         else     hipLaunchKernelGGL((gemm_mfma<TA, TB, false>), g, dim3(NT), 0, s, p);     \
@@ -272,6 +297,22 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
 extern "C" int dep_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda,
                             const float* B, int ldb, float* C, int ldc, const float* bias, float beta,
                             int seq_T, int shiftB, void* workspace, size_t workspace_bytes, void* stream) {
-    return dep_gemm_internal(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
-                             workspace, workspace_bytes, (hipStream_t)stream);
+    g_force_exact = 1;                  // the public fp32 entry is always exact
+    const int rc = dep_gemm_internal(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
+                                     workspace, workspace_bytes, (hipStream_t)stream);
+    g_force_exact = 0;
+    return rc;
+}
+
+// Same contract, 3-term bf16 split products (fp32 operands and accumulation): see gemm_bf16x3.hip.
+extern "C" int dep_gemm_bf16x3(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                               const float* B, int ldb, float* C, int ldc, const float* bias, float beta,
+                               int seq_T, int shiftB, void* workspace, size_t workspace_bytes, void* stream) {
+    init_split_mode();
+    const int mode = g_split_mode; const long mm = g_split_min_macs;
+    g_split_mode = 1; g_split_min_macs = 0;
+    const int rc = dep_gemm_internal(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
+                                     workspace, workspace_bytes, (hipStream_t)stream);
+    g_split_mode = mode; g_split_min_macs = mm;
+    return rc;
 }

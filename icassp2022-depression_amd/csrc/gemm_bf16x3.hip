@@ -1,0 +1,219 @@
+// Split-precision GEMM for the large time-parallel contractions: fp32 operands in HBM, fp32 accumulate,
+// products formed on the bf16 matrix cores with the 3-term split
+//       a*b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi ,   x_hi = bf16(x), x_lo = bf16(x - x_hi)
+// (|x - x_hi - x_lo| <= 2^-18 |x|, dropped a_lo*b_lo <= 2^-18 |ab|: relative error per product ~1e-5 worst case,
+// ~4e-6 typical -- inside the path's 1e-4 parity budget, checked by the same tests as the exact-f32 kernel).
+// v_mfma_f32_32x32x16_bf16 does 16 k per 32 cycles vs 2 k per 64 cycles for v_mfma_f32_32x32x2_f32, so three of them
+// cost 6 cycles/k against 32: the contraction stops being MFMA-bound and runs at the rate fp32 operands can be fed.
+// The split happens once per element while staging global -> LDS (v_cvt_pk_bf16_f32), never in HBM.
+//
+//   C[M,N] = opA(A)[M,K] * opB(B)[K,N] + bias[N] + beta*C        same operand forms / split-K / row shift as gemm.hip
+#include "dep_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int LDK = 40;      // bf16 per LDS row: 80-byte rows -> conflict-free ds_read_b128 fragments and ds_write_b64 staging
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct GemmP {
+    int M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const float* bias; float beta;
+    int seqT, shiftB;
+    int kchunk, splits;
+    float* part;
+};
+
+// r[i][e]: !TR -> row (mn0 + rr + 32 i), k = k0 + kq*4 + e      (kq = tid&7, rr = tid>>3)
+//           TR -> k row (k0 + kg*4 + i), mn = mn0 + mq*4 + e     (kg = tid&7, mq = tid>>3)
+template <bool TR, bool VEC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int Kend,
+                                          int tid, float (&r)[4][4], int seqT, int shift) {
+    const int a = tid & 7, bq = tid >> 3;
+    if (!TR) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mn = mn0 + bq + 32 * i, k = k0 + a * 4;
+            const float* src = P + (size_t)mn * ld + k;
+            if (VEC) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (mn < MN && k < Kend) v = *reinterpret_cast<const f32x4*>(src);
+                r[i][0] = v[0]; r[i][1] = v[1]; r[i][2] = v[2]; r[i][3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i][e] = (mn < MN && k + e < Kend) ? src[e] : 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + a * 4 + i, mn = mn0 + bq * 4;
+            bool ok = k < Kend;
+            if (seqT > 0) { const int tt = k % seqT + shift; ok = ok && tt >= 0 && tt < seqT; }
+            const float* src = P + ((long)k + shift) * ld + mn;
+            if (VEC) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok && mn < MN) v = *reinterpret_cast<const f32x4*>(src);
+                r[i][0] = v[0]; r[i][1] = v[1]; r[i][2] = v[2]; r[i][3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i][e] = (ok && mn + e < MN) ? src[e] : 0.f;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
+    hi = __builtin_convertvector(x, bf16x4);
+    const f32x4 back = __builtin_convertvector(hi, f32x4);
+    lo = __builtin_convertvector(x - back, bf16x4);
+}
+
+// LDS images Sh/Sl: [128 rows (m or n)][LDK] bf16, k contiguous
+template <bool TR>
+__device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, const float (&r)[4][4]) {
+    const int a = tid & 7, bq = tid >> 3;
+    if (!TR) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 x = {r[i][0], r[i][1], r[i][2], r[i][3]};
+            bf16x4 hi, lo; split4(x, hi, lo);
+            const int o = (bq + 32 * i) * LDK + a * 4;
+            *reinterpret_cast<bf16x4*>(Sh + o) = hi; *reinterpret_cast<bf16x4*>(Sl + o) = lo;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4 x = {r[0][e], r[1][e], r[2][e], r[3][e]};       // 4 consecutive k of row (bq*4 + e)
+            bf16x4 hi, lo; split4(x, hi, lo);
+            const int o = (bq * 4 + e) * LDK + a * 4;
+            *reinterpret_cast<bf16x4*>(Sh + o) = hi; *reinterpret_cast<bf16x4*>(Sl + o) = lo;
+        }
+    }
+}
+
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(NT) void gemm_bf16x3(GemmP p) {
+    constexpr bool A_TR = TA, B_TR = !TB;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[4 * BM * LDK];
+    __bf16* Ah = smem; __bf16* Al = smem + BM * LDK; __bf16* Bh = smem + 2 * BM * LDK; __bf16* Bl = smem + 3 * BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float ra[4][4], rb[4][4];
+    load_tile<A_TR, VEC>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra, 0, 0);
+    load_tile<B_TR, VEC>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb, p.seqT, p.shiftB);
+
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        store_tile<A_TR>(Ah, Al, tid, ra);
+        store_tile<B_TR>(Bh, Bl, tid, rb);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            load_tile<A_TR, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0);
+            load_tile<B_TR, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb, p.seqT, p.shiftB);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int ko = s * 16 + half * 8;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ro = (wm * 64 + i * 32 + l31) * LDK + ko;
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro); al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ro = (wn * 64 + j * 32 + l31) * LDK + ko;
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro); bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    const bool split = p.part != nullptr;
+    float* outp = split ? p.part + (size_t)blockIdx.z * p.M * p.N : p.C;
+    const int ldo = split ? p.N : p.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= p.N) continue;
+            const float bv = (!split && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < p.M) {
+                    float v = acc[i][j][e] + bv;
+                    float* dst = outp + (size_t)m * ldo + n;
+                    if (!split && p.beta != 0.f) v += p.beta * *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+__global__ void splitk_reduce2(const float* __restrict__ part, int splits, int M, int N, float* C, int ldc,
+                               const float* bias, float beta) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += part[(size_t)z * M * N + idx];
+    if (bias) s += bias[n];
+    float* dst = C + (size_t)m * ldc + n;
+    if (beta != 0.f) s += beta * *dst;
+    *dst = s;
+}
+
+}  // namespace
+
+// Same contract as dep_gemm_internal (gemm.hip); `splits` is decided by the caller's shared heuristic.
+int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
+                           int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
+                           int splits, int kchunk, float* part, bool vec, hipStream_t s) {
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part};
+    dim3 g(dep_cdiv(N, BN), dep_cdiv(M, BM), splits);
+#define LAUNCH(TA, TB)                                                                     \
+    do {                                                                                   \
+        if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true>), g, dim3(NT), 0, s, p);    \
+        else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false>), g, dim3(NT), 0, s, p);   \
+    } while (0)
+    if (!transA && transB) LAUNCH(false, true);
+    else if (!transA && !transB) LAUNCH(false, false);
+    else LAUNCH(true, false);
+#undef LAUNCH
+    DEP_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long n = (long)M * N;
+        hipLaunchKernelGGL(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, part, splits, M, N, C, ldc, bias, beta);
+        DEP_CHECK_LAUNCH();
+    }
+    return DEP_OK;
+}

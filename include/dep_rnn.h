@@ -120,6 +120,19 @@ int dep_gemm_f32(int transA, int transB, int M, int N, int K,
                  const float* bias, float beta, int seq_T, int shiftB,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same contract with split-precision products: every fp32 operand element is split on the fly into
+ * bf16 hi + bf16 lo and a*b is formed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores with
+ * fp32 accumulation (relative error per product ~1e-5, inside the path's 1e-4 parity budget; 5x the MFMA
+ * rate of the exact kernel).  dep_rnn_forward/backward use it for their time-parallel contractions of at
+ * least `min_macs` multiply-adds when the mode is 1 (default; DEP_GEMM_MODE=f32 or dep_set_gemm_mode(0,-1)
+ * selects the exact fp32 kernel everywhere).  dep_gemm_f32 itself is always exact. */
+int dep_gemm_bf16x3(int transA, int transB, int M, int N, int K,
+                    const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    const float* bias, float beta, int seq_T, int shiftB,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int dep_set_gemm_mode(int mode, long min_macs);   /* mode 0 exact f32 | 1 bf16x3 split ; min_macs < 0 keeps it */
+int dep_get_gemm_mode(void);
+
 /* nn.LayerNorm(F) over the last axis (audio_gru_whole.py:62,104). rows = B*T.
  * mean_rstd: (rows,2) saved statistics (may be NULL in inference). */
 int dep_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,

@@ -44,6 +44,39 @@ def test_gemm_shapes(tA, tB, M, N, K):
     assert relerr(host(c), ref) < 2e-6
 
 
+@pytest.mark.parametrize('tA,tB', [(0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize('M,N,K', [(300, 200, 64), (77, 45, 39), (513, 260, 100), (256, 384, 2048)])
+def test_gemm_bf16x3_split_accuracy(tA, tB, M, N, K):
+    """3-term bf16 split: error relative to sum_k |a||b| must stay ~1e-5 (exact-f32 kernel: ~1e-7)."""
+    rng = np.random.default_rng(M + N * 3 + K * 5 + tA * 2 + tB)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32).astype(np.float64)
+    B = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32).astype(np.float64)
+    bias = rng.standard_normal(N).astype(np.float32).astype(np.float64)
+    opA = A.T if tA else A; opB = B.T if tB else B
+    ref = opA @ opB + bias
+    scale = np.abs(opA) @ np.abs(opB)
+    a, b, bi = dev(A), dev(B), dev(bias)
+    c = torch.empty(M, N, device=DEV)
+    ws = L.gemm_ws(tA, tB, M, N, K, DEV)
+    L.gemm_split(tA, tB, M, N, K, a, a.stride(0), b, b.stride(0), c, N, bias=bi, ws=ws)
+    err = np.abs(host(c) - ref) / scale
+    assert err.max() < 1.5e-5, err.max()
+    assert err.mean() < 2e-6
+
+
+def test_gemm_bf16x3_shift_and_splitk_match_exact_kernel():
+    rng = np.random.default_rng(15)
+    Bsz, T, M, N = 9, 300, 96, 64
+    K = Bsz * T
+    a, b = dev(rng.standard_normal((K, M))), dev(rng.standard_normal((K, N)))
+    ws = L.gemm_ws(1, 0, M, N, K, DEV)
+    for shift in (-1, 1):
+        c0 = torch.empty(M, N, device=DEV); c1 = torch.empty(M, N, device=DEV)
+        L.gemm(1, 0, M, N, K, a, M, b, N, c0, N, seq_T=T, shiftB=shift, ws=ws)
+        L.gemm_split(1, 0, M, N, K, a, M, b, N, c1, N, seq_T=T, shiftB=shift, ws=ws)
+        assert relerr(host(c1), host(c0)) < 2e-5
+
+
 def test_gemm_splitk_and_shift():
     """dW_hh-style contraction: C (M,N) = A^T (M,K) * shift(B) (K,N) with K = B*T rows, zero rows at
     sequence starts, split-K with the deterministic two-pass reduction."""
@@ -139,8 +172,16 @@ RNN_CASES = [
 ]
 
 
+@pytest.fixture(params=['f32', 'bf16x3'])
+def gemm_mode(request):
+    """Run a test under both precision modes of the time-parallel contractions (forced on every size)."""
+    L.set_gemm_mode(0 if request.param == 'f32' else 1, 0)
+    yield request.param
+    L.set_gemm_mode(1, 1 << 28)
+
+
 @pytest.mark.parametrize('cell,B,T,F,H,impl', RNN_CASES)
-def test_rnn_stack_fwd_bwd(cell, B, T, F, H, impl):
+def test_rnn_stack_fwd_bwd(cell, B, T, F, H, impl, gemm_mode):
     rng = np.random.default_rng(B * 1000 + T * 100 + F + H + impl)
     Lyr = 2
     dirs = 1 if cell == 'gru' else 2
