@@ -69,6 +69,18 @@ __device__ __forceinline__ float dep_dropmask1(uint64_t seed, uint32_t site, uin
 // dropout sites (Philox counter word 2): distinct per place a mask is drawn in one step
 enum { DEP_SITE_RNN0 = 16 /* + layer */, DEP_SITE_USER = 0 };
 
+// ---- XCD-aware tile order -----------------------------------------------------------------------
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, speed only).  Remap the
+// linear block id so that every XCD walks a contiguous run of the (x fastest, y, z) tile order: neighbouring
+// tiles share an operand panel and now hit the same 4 MB L2 instead of refetching it on 6-8 different XCDs.
+// Bijective for any block count (cdna_hip_programming.md T1).
+__device__ __forceinline__ void dep_xcd_tile(int gx, int gy, int gz, int& bx, int& by, int& bz) {
+    const int n = gx * gy * gz, orig = blockIdx.x;
+    const int q = n / 8, r = n % 8, xcd = orig % 8;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    bx = id % gx; by = (id / gx) % gy; bz = id / (gx * gy);
+}
+
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
 enum { DEP_PROF_GRU_FWD = 0, DEP_PROF_GRU_BWD = 1, DEP_PROF_LSTM_FWD = 2, DEP_PROF_LSTM_BWD = 3,
        DEP_PROF_GEMM_NT = 4, DEP_PROF_GEMM_NN = 5, DEP_PROF_GEMM_TN = 6, DEP_PROF_NCAT = 7 };

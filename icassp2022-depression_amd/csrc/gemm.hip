@@ -23,7 +23,8 @@ struct GemmP {
     const float* bias; float beta;
     int seqT, shiftB;
     int kchunk, splits;
-    float* part;            // split-K partials [splits][M][N] or nullptr
+    float* part;
+    int gx, gy;             // tile grid (x: N tiles, y: M tiles); the launch is 1-D, see dep_xcd_tile            // split-K partials [splits][M][N] or nullptr
 };
 
 // Load one (128 x 32) operand tile into registers.  TR = operand stored MN-contiguous.
@@ -96,8 +97,10 @@ __global__ __launch_bounds__(NT) void gemm_mfma(GemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.kchunk;
+    int bx, by, bz;
+    dep_xcd_tile(p.gx, p.gy, p.splits, bx, by, bz);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
     f32x16 acc[2][2];
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(NT) void gemm_mfma(GemmP p) {
 
     // epilogue: D[i][j]: j = lane&31 (n), i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (m)
     const bool split = p.part != nullptr;
-    float* outp = split ? p.part + (size_t)blockIdx.z * p.M * p.N : p.C;
+    float* outp = split ? p.part + (size_t)bz * p.M * p.N : p.C;
     const int ldo = split ? p.N : p.ldc;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -248,7 +251,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     DEP_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C);
     DEP_CHECK_ARG(!(transA && transB));
     DEP_CHECK_ARG(!(seq_T > 0 && transB));
-    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, K, 1, nullptr};
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, K, 1, nullptr, 1, 1};
     if (naive_forced()) {
         dim3 g(dep_cdiv(N, 128), M);
         hipLaunchKernelGGL(gemm_naive, g, dim3(128), 0, s, p, transA, transB);
@@ -269,7 +272,8 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     const bool adim = transA ? (M % 4 == 0) : (K % 4 == 0);
     const bool bdim = transB ? (K % 4 == 0) : (N % 4 == 0);
     const bool vec = a16 && b16 && adim && bdim;
-    dim3 g(dep_cdiv(N, BN), dep_cdiv(M, BM), splits);
+    p.gx = dep_cdiv(N, BN); p.gy = dep_cdiv(M, BM);
+    dim3 g(p.gx * p.gy * splits);
     DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s);
     init_split_mode();
     if (g_force_exact == 0 && g_split_mode == 1 && (long)M * N * K >= g_split_min_macs)

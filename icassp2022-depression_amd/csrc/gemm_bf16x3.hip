@@ -27,6 +27,7 @@ struct GemmP {
     int seqT, shiftB;
     int kchunk, splits;
     float* part;
+    int gx, gy;             // tile grid (x: N tiles, y: M tiles); the launch is 1-D, see dep_xcd_tile
 };
 
 // r[i][e]: !TR -> row (mn0 + rr + 32 i), k = k0 + kq*4 + e      (kq = tid&7, rr = tid>>3)
@@ -105,8 +106,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16x3(GemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.kchunk;
+    int bx, by, bz;
+    dep_xcd_tile(p.gx, p.gy, p.splits, bx, by, bz);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
     f32x16 acc[2][2];
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16x3(GemmP p) {
     }
 
     const bool split = p.part != nullptr;
-    float* outp = split ? p.part + (size_t)blockIdx.z * p.M * p.N : p.C;
+    float* outp = split ? p.part + (size_t)bz * p.M * p.N : p.C;
     const int ldo = split ? p.N : p.ldc;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -198,8 +201,8 @@ __global__ void splitk_reduce2(const float* __restrict__ part, int splits, int M
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
                            int splits, int kchunk, float* part, bool vec, hipStream_t s) {
-    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part};
-    dim3 g(dep_cdiv(N, BN), dep_cdiv(M, BM), splits);
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BM)};
+    dim3 g(p.gx * p.gy * splits);
 #define LAUNCH(TA, TB)                                                                     \
     do {                                                                                   \
         if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true>), g, dim3(NT), 0, s, p);    \
