@@ -37,6 +37,7 @@ _SIGS = {
     'dep_rnn_reserve_y_offset': (C.c_size_t, [C.POINTER(RnnDesc), C.c_int]),
     'dep_rnn_reserve_ydrop_offset': (C.c_size_t, [C.POINTER(RnnDesc), C.c_int]),
     'dep_rnn_status': (C.c_int, [C.POINTER(RnnDesc), _P, _P]),
+    'dep_rnn_workspace_xbuf_offset': (C.c_size_t, [C.POINTER(RnnDesc)]),
     'dep_rnn_forward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     'dep_rnn_backward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, C.POINTER(_P), _P, _P,
                                    C.c_size_t, _P, C.c_size_t, _P]),

@@ -2,6 +2,7 @@
 // per layer  [pack W_hh] -> input-projection GEMM -> persistent sweep ; backward mirrors it.
 // See include/dep_rnn.h for the contract and the reference call sites each entry replaces.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <utility>
 #include <vector>
@@ -73,7 +74,9 @@ struct Layout {
     size_t gemm_bytes, xbuf_bytes, ws_floats;
     int nwg;
     bool drop;
-    bool cluster;                    // cluster-parallel sweeps (rnn_cluster.hip)
+    bool cluster;                    // cluster-parallel sweeps (rnn_cluster*.hip)
+    bool cluster16;                  // forward with 16-unit members, two workgroups per CU (rnn_cluster16.hip)
+    bool cluster16_bwd;              // same for the backward (slower than 32-unit members: A/B only, DEP_CLUSTER16_BWD=1)
 };
 
 bool make_layout(const dep_rnn_desc* d, Layout& lo) {
@@ -128,6 +131,8 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     const bool cok = dep_cluster_ok(d->cell, d->H, d->B, d->dirs);
     if (d->impl == 3 && !cok) return false;
     lo.cluster = cok && (d->impl == 0 || d->impl == 3);
+    lo.cluster16 = lo.cluster && dep_cluster16_ok(d->cell, d->H, d->B);
+    { const char* e = getenv("DEP_CLUSTER16_BWD"); lo.cluster16_bwd = lo.cluster16 && e && e[0] == '1'; }
     lo.xbuf = w; lo.xbuf_bytes = lo.cluster ? dep_cluster_xbuf_bytes(d->cell, d->H, d->B, d->dirs) : 0;
     w += al(lo.xbuf_bytes / sizeof(float) + 64);
     lo.ws_floats = w;
@@ -156,6 +161,13 @@ extern "C" size_t dep_rnn_reserve_ydrop_offset(const dep_rnn_desc* d, int layer)
     Layout lo;
     if (!make_layout(d, lo) || layer < 0 || layer >= d->L - 1 || !lo.drop) return (size_t)-1;
     return lo.ydrop[layer] * sizeof(float);
+}
+
+// Byte offset of the cluster exchange buffer inside the workspace (debug tooling: DEP_TRACE stamps live at +4096).
+extern "C" size_t dep_rnn_workspace_xbuf_offset(const dep_rnn_desc* d) {
+    Layout lo;
+    if (!make_layout(d, lo) || !lo.cluster) return (size_t)-1;
+    return lo.xbuf * sizeof(float);
 }
 
 // Status of the cluster sweeps that ran on (workspace): 0 ok, 2 = a bounded spin gave up (a cluster member was
@@ -200,7 +212,9 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             DEP_CHECK_ARG(wl[0] && wl[1] && wl[2] && wl[3]);
             if (mfma) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
             if (lo.cluster && d->training) {     // the cluster backward wants its own member-sliced image
-                rc = dep_pack_cluster_bwd(wl[1], R + lo.wpT[l][dd], G, H, s); if (rc) return rc;
+                rc = lo.cluster16_bwd ? dep_pack_cluster16_bwd(wl[1], R + lo.wpT[l][dd], H, s)
+                                  : dep_pack_cluster_bwd(wl[1], R + lo.wpT[l][dd], G, H, s);
+                if (rc) return rc;
             }
             const float* bias = wl[2];
             if (d->cell == DEP_CELL_LSTM) {          // both biases fold into the projection
@@ -230,7 +244,8 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         a.h_n = h_n ? h_n + (size_t)l * D * B * H : nullptr;
         if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
         a.stream = s;
-        rc = lo.cluster ? dep_launch_cluster_fwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_fwd(a);
+        rc = lo.cluster16 ? dep_launch_cluster16_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
+           : lo.cluster ? dep_launch_cluster_fwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_fwd(a);
         if (rc) return rc;
     }
     if (y) {
@@ -280,7 +295,8 @@ extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const flo
         a.dh_n = dh_n ? dh_n + (size_t)l * D * B * H : nullptr;
         a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3];
         a.dgi = dgi; a.dghn = W + lo.dghn; a.dbpart = W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
-        rc = lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
+        rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
+           : lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
         if (rc) return rc;
         float* dbi[2]; float* dbh[2];
         for (int dd = 0; dd < D; ++dd) {

@@ -150,6 +150,10 @@ size_t dep_cluster_xbuf_bytes(int cell, int H, int B, int dirs);
 int dep_pack_cluster_bwd(const float* w_hh, float* out, int G, int H, hipStream_t s);
 int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
 int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
+bool dep_cluster16_ok(int cell, int H, int B);
+int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s);
+int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
+int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
 
 int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* A, int lda,
                       const float* B, int ldb, float* C, int ldc, const float* bias, float beta,

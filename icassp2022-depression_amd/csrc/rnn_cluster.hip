@@ -360,7 +360,7 @@ bool dep_cluster_ok(int cell, int H, int B, int dirs) {
 size_t dep_cluster_xbuf_bytes(int cell, int H, int B, int dirs) {
     if (!dep_cluster_ok(cell, H, B, dirs)) return 0;
     const int NC = H / 32, nbtp = (dep_cdiv(B, BT) + 7) / 8 * 8;
-    return 256 + (size_t)2 * nbtp * NC * BT * H * sizeof(u64) * dirs;      // sized for the backward exchange
+    return 16384 + (size_t)2 * nbtp * NC * BT * H * sizeof(u64) * dirs;    // header + the largest (backward) exchange
 }
 
 int dep_pack_cluster_bwd(const float* w_hh, float* out, int G, int H, hipStream_t s) {

@@ -17,7 +17,10 @@ constexpr int BT = 16;
 constexpr int LPAD = 4;
 constexpr int CT = 256;
 constexpr unsigned SPIN_LIMIT = 1u << 20;
-constexpr size_t FLAG_OFF = 256, PAYLOAD_OFF = 8192;
+constexpr size_t EXCLUSIVE_LDS = 84 * 1024;
+constexpr size_t HELLO_OFF = 1280;      // after up to 256 flag words
+constexpr size_t FLAG_OFF = 256, TRACE_OFF = 4096, PAYLOAD_OFF = 8192;
+#define DEP_STAMP(slot) do { if (tr && t >= 100 && t < 104) tr[(t - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -36,7 +39,9 @@ struct P2 {
     float* dgi; int lddg;
     float* dghn;
     float* dbpart;
-    unsigned* status; unsigned* flags; float* payload; unsigned payload_bytes;
+    unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
+    int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
+    long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -54,6 +59,36 @@ __device__ __forceinline__ void st_agent(unsigned* p, unsigned v) {
 __device__ __forceinline__ float2 ld2_agent(const float* p) {      // 8-byte sc1 load (bypasses the stale-prone L1)
     const u64 x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_float2(__uint_as_float((unsigned)x), __uint_as_float((unsigned)(x >> 32)));
+}
+
+__device__ __forceinline__ void st_local(unsigned* p, unsigned v) {   // plain store: stays in this XCD's L2
+    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Same-XCD fast path.  Correctness never depends on placement: every member announces the XCD it runs on through
+// the placement-independent protocol (sc1 store / sc1 polls); only if ALL members of the cluster report the same
+// XCD do the per-step payload and flag stores drop the write-through bit -- that XCD's L2 is then the coherence
+// point for writers (plain stores are acknowledged by L2) and readers (sc1 loads bypass L1 and are served by L2),
+// and a step's hand-off costs an L2 round trip instead of a trip through the fabric.  Returns -1 on timeout.
+__device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, unsigned* status) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = 0x100u | (xcc & 0xffu);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) st_agent(hello + c, xcc);
+    int verdict = 1;
+    if (w == 0) {
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned v = lane < NC ? ld_agent(hello + lane) : xcc;
+            if (__all(v != 0)) { verdict = __all(v == xcc) ? 1 : 0; break; }
+            if (spins > SPIN_LIMIT) { st_agent(status, 5); verdict = -1; break; }
+            if ((spins & 63) == 63 && ld_agent(status) != 0) { verdict = -1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    const int dead = __syncthreads_or(verdict < 0);
+    const int same = __syncthreads_and(verdict == 1);
+    return dead ? -1 : same;
 }
 
 struct StepIn { float2 r, z, n, hn, hp, dy; };
@@ -93,6 +128,9 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     unsigned* tflags = p.flags + bt * NC;
     const int ml = lane & 15, mq = lane >> 4;
     bool dead = false;
+    const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * NC, NC, c, p.status);
+    if (sx < 0) return;
+    const bool fast = sx == 1;
 
     auto load_step = [&](int t, StepIn& s) {
         s.r = s.z = s.n = s.hn = s.hp = s.dy = f2(0.f, 0.f);
@@ -137,14 +175,17 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) acc[i] = zero4();
         const float* drow = dgs + ml * LDG + mq * 4;
+        f32x4 hv[KCB];
+#pragma unroll
+        for (int k = 0; k < KCB; ++k) hv[k] = ld4(drow + k * 16);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < KCB; ++k) {
-            const f32x4 hv = ld4(drow + k * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < NTW; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[e], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[k][e], acc[i], 0, 0, 0);
         }
         // publish: payload[parity][tile][src c][out tile][lane][4]
         const unsigned epoch = (unsigned)(T - t);
@@ -155,11 +196,12 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
             u32x4 v;
             v.x = __float_as_uint(acc[i][0]); v.y = __float_as_uint(acc[i][1]);
             v.z = __float_as_uint(acc[i][2]); v.w = __float_as_uint(acc[i][3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 16 /* sc1: write-through */);
+            if (fast) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 0 /* plain: stays in this XCD's L2 */);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 16 /* sc1: write-through */);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
         __syncthreads();
-        if (tid == 0) st_agent(myflag, epoch);
+        if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         // wait for every member's flag (one wave polls, relaxed; flags are monotonic)
         if (w == 0) {
             for (unsigned spins = 0;; ++spins) {
@@ -209,7 +251,9 @@ struct F2 {
     float* pooled; float pool_scale;
     float* h_n;
     float* sv0; float* sv1; float* sv2; float* sv3;
-    unsigned* status; unsigned* flags; float* payload; unsigned payload_bytes;
+    unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
+    int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
+    long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
 };
 
 template <int KCH>
@@ -245,14 +289,19 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
     unsigned* tflags = p.flags + bt * NC;
     const int hshift = __ffs(H) - 1;
     bool dead = false;
+    const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * NC, NC, c, p.status);
+    if (sx < 0) return;
+    const bool fast = sx == 1;
     float2 gin[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
         gin[g] = valid ? ld2(p.gi + (size_t)b * T * p.ldgi + g * H + col) : f2(0.f, 0.f);
     __syncthreads();
 
+    long long* tr = (p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)b * T + t;
+        DEP_STAMP(0);
         float2 gi[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) gi[g] = gin[g];
@@ -262,18 +311,23 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
         }
         f32x4 acc[3] = {zero4(), zero4(), zero4()};
         const float* hrow = hs + j * LDH + kh * KCH * 16 + q * 4;
+        f32x4 hv[KCH];                                 // all B fragments first: one LDS latency, not KCH of them
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) hv[k] = ld4(hrow + k * 16);
+        __builtin_amdgcn_sched_barrier(0);             // keep the loads grouped: hipcc otherwise sinks each next to its MFMAs
 #pragma unroll
         for (int k = 0; k < KCH; ++k) {
-            const f32x4 hv = ld4(hrow + k * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[e], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
         }
+        DEP_STAMP(1);
 #pragma unroll
         for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + ((w * 3 + g) * 64 + lane) * 4) = acc[g];
         __syncthreads();
+        DEP_STAMP(2);
         float2 tot[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
@@ -291,12 +345,15 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
         const unsigned epoch = (unsigned)t + 1u;
         const size_t pbase = (size_t)(t & 1) * pstride + tile_base;
         const bool more = t + 1 < T;
+        DEP_STAMP(3);
         if (more) {       // publish first: it is on the critical path of the other members
             const u64 bits = (u64)__float_as_uint(h.x) | ((u64)__float_as_uint(h.y) << 32);
-            __hip_atomic_store((gu64*)(p.payload + pbase + (size_t)j * H + col), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fast) __hip_atomic_store((gu64*)(p.payload + pbase + (size_t)j * H + col), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store((gu64*)(p.payload + pbase + (size_t)j * H + col), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DEP_STAMP(4);
             __syncthreads();
-            if (tid == 0) st_agent(myflag, epoch);
+            if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         }
         if (valid) {
             const size_t o = row * p.ldy + col;
@@ -320,7 +377,9 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+            DEP_STAMP(5);
             if (__syncthreads_or(dead)) return;
+            DEP_STAMP(6);
             constexpr int PER = KCH / 2;              // 16-byte pieces per thread = 16*H/4/256
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
@@ -331,12 +390,19 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
                 *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
             }
             __syncthreads();
+            DEP_STAMP(7);
         }
     }
     if (valid) {
         if (p.pooled) st2(p.pooled + (size_t)b * H + col, f2(pool.x * p.pool_scale, pool.y * p.pool_scale));
         if (p.h_n) st2(p.h_n + (size_t)b * H + col, hprev);
     }
+}
+
+int nofast_env() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DEP_CLUSTER_NOFAST"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
 }
 
 }  // namespace
@@ -359,11 +425,22 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
     p.sv0 = a.training ? a.sv0 : nullptr; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
     const size_t pay = (size_t)2 * nbtp * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC * 4 <= PAYLOAD_OFF - FLAG_OFF);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
-    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+    { static int tr = -1; if (tr < 0) { const char* e = getenv("DEP_TRACE"); tr = (e && e[0] == '1') ? 1 : 0; }
+      p.trace = tr ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr; }
+    if (hipMemsetAsync(xbuf, 0, p.trace ? FLAG_OFF + 2048 : PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
-    const size_t lds = (size_t)(BT * (a.H + LPAD) + 4 * 3 * 64 * 4) * sizeof(float);
+    // Ask for more than half of the CU's 160 KiB LDS: the dispatcher can then never co-locate two members on one
+    // CU (they would share the four matrix pipes and stretch every step of BOTH clusters).
+    const size_t lds = EXCLUSIVE_LDS;
+    static bool attr_f = false;
+    if (!attr_f) {
+        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_f = true;
+    }
     dim3 grid(NC * nbtp);
     if (a.H == 128) hipLaunchKernelGGL(gru_fwd_cluster_r1<4>, grid, dim3(CT), lds, a.stream, p);
     else hipLaunchKernelGGL(gru_fwd_cluster_r1<8>, grid, dim3(CT), lds, a.stream, p);
@@ -391,11 +468,18 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
     const size_t pay = (size_t)2 * nbtp * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC * 4 <= PAYLOAD_OFF - FLAG_OFF);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
     if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
-    const size_t lds = (size_t)(BT * (96 + LPAD)) * sizeof(float);
+    const size_t lds = EXCLUSIVE_LDS;
+    static bool attr_b = false;
+    if (!attr_b) {
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_b = true;
+    }
     dim3 grid(NC * nbtp);
     if (a.H == 128) hipLaunchKernelGGL(gru_bwd_cluster_r1<2>, grid, dim3(CT), lds, a.stream, p);
     else hipLaunchKernelGGL(gru_bwd_cluster_r1<4>, grid, dim3(CT), lds, a.stream, p);

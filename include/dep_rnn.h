@@ -72,6 +72,9 @@ size_t dep_rnn_reserve_ydrop_offset(const dep_rnn_desc* d, int layer);
  * the kernels exit early and this returns DEP_ERR_HIP.  Synchronises `stream`.  Always DEP_OK for the
  * single-workgroup kernels. */
 int dep_rnn_status(const dep_rnn_desc* d, void* workspace, void* stream);
+/* Debug tooling: byte offset of the cluster exchange buffer inside the workspace ((size_t)-1 if unused).
+ * With DEP_TRACE=1 workgroup 0 of the forward sweep leaves shader-clock stamps of its phases at +4096. */
+size_t dep_rnn_workspace_xbuf_offset(const dep_rnn_desc* d);
 
 /* ------------------------------------------------------------------ RNN stacks ----- */
 /* weights: array of 4*L*dirs device pointers ordered, for layer l and direction d (index
