@@ -28,6 +28,7 @@ struct GemmP {
     int kchunk, splits;
     float* part;
     int gx, gy;             // tile grid (x: N tiles, y: M tiles); the launch is 1-D, see dep_xcd_tile
+    int ablate;             // debug (DEP_GEMM_ABLATE): 1 no epilogue stores, 2 no MFMA, 4 no tile reloads, 8 no LDS staging
 };
 
 // r[i][e]: !TR -> row (mn0 + rr + 32 i), k = k0 + kq*4 + e      (kq = tid&7, rr = tid>>3)
@@ -98,88 +99,121 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
     }
 }
 
+// Persistent, cross-tile pipelined: a workgroup walks a strided list of output tiles taken from ITS XCD's contiguous
+// share of the tile order (so tiles processed together on an XCD share operand panels in that L2) and treats
+// (tile, k-tile) as one iteration space: the register prefetch issued in the last k-iteration of a tile already
+// belongs to the next tile, and a tile's epilogue stores drain while the next tile's loads are in flight.  These
+// contractions have short K per tile (256..2400), so without this every tile paid an exposed load latency up front
+// and an exposed store burst at the end (the phases of a tile were additive in an ablation, not overlapped).
 template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(NT) void gemm_bf16x3(GemmP p) {
+__global__ __launch_bounds__(NT, 3) void gemm_bf16x3(GemmP p) {
     constexpr bool A_TR = TA, B_TR = !TB;
     __shared__ __attribute__((aligned(16))) __bf16 smem[4 * BM * LDK];
     __bf16* Ah = smem; __bf16* Al = smem + BM * LDK; __bf16* Bh = smem + 2 * BM * LDK; __bf16* Bl = smem + 3 * BM * LDK;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    int bx, by, bz;
-    dep_xcd_tile(p.gx, p.gy, p.splits, bx, by, bz);
-    const int m0 = by * BM, n0 = bx * BN;
-    const int kbeg = bz * p.kchunk;
-    const int kend = min(p.K, kbeg + p.kchunk);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // this workgroup's tile list: XCD x = blockIdx % 8 owns tiles [lo, hi) of the (x fastest, y, z) order
+    const int ntiles = p.gx * p.gy * p.splits;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int q = ntiles / 8, r = ntiles % 8;
+    const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int hi = lo + (xcd < r ? q + 1 : q);
+    int tile = lo + slot;
+    if (tile >= hi) return;
+
+    auto coords = [&](int t, int& m0, int& n0, int& kb, int& ke, int& bz) {
+        const int bx = t % p.gx, by = (t / p.gx) % p.gy; bz = t / (p.gx * p.gy);
+        m0 = by * BM; n0 = bx * BN; kb = bz * p.kchunk; ke = min(p.K, kb + p.kchunk);
+    };
+    int m0, n0, kbeg, kend, bz;
+    coords(tile, m0, n0, kbeg, kend, bz);
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
     float ra[4][4], rb[4][4];
     load_tile<A_TR, VEC>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra, 0, 0);
     load_tile<B_TR, VEC>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb, p.seqT, p.shiftB);
 
-    const int half = lane >> 5, l31 = lane & 31;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        store_tile<A_TR>(Ah, Al, tid, ra);
-        store_tile<B_TR>(Bh, Bl, tid, rb);
-        __syncthreads();
-        if (k0 + BK < kend) {
-            load_tile<A_TR, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0);
-            load_tile<B_TR, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb, p.seqT, p.shiftB);
-        }
+    while (true) {
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            const int ko = s * 16 + half * 8;
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ro = (wm * 64 + i * 32 + l31) * LDK + ko;
-                ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro); al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int next = tile + slots;
+        const bool has_next = next < hi;
+        int nm0 = 0, nn0 = 0, nkb = 0, nke = 0, nbz = 0;
+        if (has_next) coords(next, nm0, nn0, nkb, nke, nbz);
+
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            if (!(p.ablate & 8) || k0 == kbeg) {
+                store_tile<A_TR>(Ah, Al, tid, ra);
+                store_tile<B_TR>(Bh, Bl, tid, rb);
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ro = (wn * 64 + j * 32 + l31) * LDK + ko;
-                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro); bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
+            __syncthreads();
+            if (!(p.ablate & 4)) {
+                if (k0 + BK < kend) {
+                    load_tile<A_TR, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0);
+                    load_tile<B_TR, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb, p.seqT, p.shiftB);
+                } else if (has_next) {       // first k-tile of the NEXT output tile
+                    load_tile<A_TR, VEC>(p.A, p.lda, nm0, p.M, nkb, nke, tid, ra, 0, 0);
+                    load_tile<B_TR, VEC>(p.B, p.ldb, nn0, p.N, nkb, nke, tid, rb, p.seqT, p.shiftB);
+                }
             }
+            if (!(p.ablate & 2))
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int s = 0; s < BK / 16; ++s) {
+                const int ko = s * 16 + half * 8;
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ro = (wm * 64 + i * 32 + l31) * LDK + ko;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro); al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    const int ro = (wn * 64 + j * 32 + l31) * LDK + ko;
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro); bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
                 }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
 
-    const bool split = p.part != nullptr;
-    float* outp = split ? p.part + (size_t)bz * p.M * p.N : p.C;
-    const int ldo = split ? p.N : p.ldc;
+        const bool split = p.part != nullptr;
+        float* outp = split ? p.part + (size_t)bz * p.M * p.N : p.C;
+        const int ldo = split ? p.N : p.ldc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + l31;
-            if (n >= p.N) continue;
-            const float bv = (!split && p.bias) ? p.bias[n] : 0.f;
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                if (n >= p.N) continue;
+                const float bv = (!split && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (m < p.M) {
-                    float v = acc[i][j][e] + bv;
-                    float* dst = outp + (size_t)m * ldo + n;
-                    if (!split && p.beta != 0.f) v += p.beta * *dst;
-                    *dst = v;
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (m < p.M) {
+                        float v = acc[i][j][e] + bv;
+                        float* dst = outp + (size_t)m * ldo + n;
+                        if (!split && p.beta != 0.f) v += p.beta * *dst;
+                        if (!(p.ablate & 1) || v == 1.2345e30f) *dst = v;
+                    }
                 }
             }
-        }
+        if (!has_next) break;
+        tile = next; m0 = nm0; n0 = nn0; kbeg = nkb; kend = nke; bz = nbz;
+    }
 }
 
 __global__ void splitk_reduce2(const float* __restrict__ part, int splits, int M, int N, float* C, int ldc,
@@ -201,8 +235,14 @@ __global__ void splitk_reduce2(const float* __restrict__ part, int splits, int M
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
                            int splits, int kchunk, float* part, bool vec, hipStream_t s) {
-    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BM)};
-    dim3 g(p.gx * p.gy * splits);
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("DEP_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BM), abl};
+    // persistent launch: at most PERSIST workgroups (a multiple of 8: one share per XCD), each walks a list of tiles
+    const int ntiles = p.gx * p.gy * splits;
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("DEP_GEMM_PERSIST"); persist = e ? atoi(e) : 768; if (persist < 8) persist = 8; persist = persist / 8 * 8; }
+    dim3 g(ntiles < persist ? (ntiles + 7) / 8 * 8 : persist);
 #define LAUNCH(TA, TB)                                                                     \
     do {                                                                                   \
         if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true>), g, dim3(NT), 0, s, p);    \
