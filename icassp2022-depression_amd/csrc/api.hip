@@ -128,12 +128,13 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     }
     lo.gemm = w; lo.gemm_bytes = gb; w += al(gb / sizeof(float) + 64);
     // impl: 0 auto (cluster > tile-MFMA > generic), 1 generic, 2 tile-MFMA, 3 cluster (must be supported)
-    const bool cok = dep_cluster_ok(d->cell, d->H, d->B, d->dirs);
+    const bool cok = d->cell == DEP_CELL_GRU ? dep_cluster_ok(d->cell, d->H, d->B, d->dirs) : dep_cluster_lstm_ok(d->H, d->B, d->dirs);
     if (d->impl == 3 && !cok) return false;
     lo.cluster = cok && (d->impl == 0 || d->impl == 3);
     lo.cluster16 = lo.cluster && dep_cluster16_ok(d->cell, d->H, d->B);
     { const char* e = getenv("DEP_CLUSTER16_BWD"); lo.cluster16_bwd = lo.cluster16 && e && e[0] == '1'; }
-    lo.xbuf = w; lo.xbuf_bytes = lo.cluster ? dep_cluster_xbuf_bytes(d->cell, d->H, d->B, d->dirs) : 0;
+    lo.xbuf = w; lo.xbuf_bytes = !lo.cluster ? 0 : (d->cell == DEP_CELL_GRU ? dep_cluster_xbuf_bytes(d->cell, d->H, d->B, d->dirs)
+                                                                : dep_cluster_lstm_xbuf_bytes(d->H, d->B, d->dirs));
     w += al(lo.xbuf_bytes / sizeof(float) + 64);
     lo.ws_floats = w;
     return true;
@@ -245,6 +246,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
         a.stream = s;
         rc = lo.cluster16 ? dep_launch_cluster16_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
+           : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : lo.cluster ? dep_launch_cluster_fwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_fwd(a);
         if (rc) return rc;
     }
@@ -296,6 +298,7 @@ extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const flo
         a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3];
         a.dgi = dgi; a.dghn = W + lo.dghn; a.dbpart = W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
         rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
+           : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
         if (rc) return rc;
         float* dbi[2]; float* dbh[2];

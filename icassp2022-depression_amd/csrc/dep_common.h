@@ -151,6 +151,10 @@ int dep_pack_cluster_bwd(const float* w_hh, float* out, int G, int H, hipStream_
 int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
 int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
 bool dep_cluster16_ok(int cell, int H, int B);
+bool dep_cluster_lstm_ok(int H, int B, int dirs);
+size_t dep_cluster_lstm_xbuf_bytes(int H, int B, int dirs);
+int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
+int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
 int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
 int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);

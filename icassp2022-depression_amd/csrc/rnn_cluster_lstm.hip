@@ -1,0 +1,425 @@
+// Cluster-parallel sweeps for the bidirectional LSTM (nn.LSTM of Classification/text_bilstm_whole.py:54-56,105;
+// gates i,f,g,o; h0 = c0 = 0).  Same scheme as the GRU kernels of rnn_cluster_bwd.hip: a (direction, 16-utterance
+// tile) pair is owned by a cluster of NC = H/32 workgroups, member c keeps the W_hh rows of hidden units
+// [32c, 32c+32) (all four gates) in VGPRs for the whole sweep, h_t (forward) / the partial dh (backward) travel
+// through flag-published fp32 payloads with the same-XCD fast path, parity double-buffering and bounded spins.
+// Both directions run in the same launch: at H = 128, B = 512 that is 2 x 32 tiles x 4 members = 256 workgroups.
+// Both biases are folded into the input projection by the caller (dep_rnn_forward), as in rnn_sweep.hip.
+#include "dep_common.h"
+
+namespace {
+
+constexpr int BT = 16;
+constexpr int LPAD = 4;
+constexpr int CT = 256;
+constexpr unsigned SPIN_LIMIT = 1u << 20;
+constexpr size_t FLAG_OFF = 256, HELLO_OFF = 3328, PAYLOAD_OFF = 8192;
+
+typedef unsigned long long u64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+struct LF {
+    int B, T, H, dirs, nbtp;
+    const f32x4* wp[2];
+    const float* gi; int ldgi;
+    float* y; int ldy;
+    float* ydrop; float drop_p, drop_scale; uint64_t seed; uint32_t site;
+    float* h_n;
+    float* svg; float* svc;                        // activated gates (B,T,dirs*4H), cell state (B,T,dirs*H); null in inference
+    unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
+    int nofast;
+};
+
+struct LB {
+    int B, T, H, dirs, nbtp;
+    const f32x4* wp[2];
+    const float* dy; int lddy;
+    float drop_p, drop_scale; uint64_t seed; uint32_t site;
+    const float* dh_n;
+    const float* svg; const float* svc;
+    float* dgi; int lddg;
+    float* dbpart; int nwg;
+    unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
+    int nofast;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ float2 f2(float a, float b) { return make_float2(a, b); }
+__device__ __forceinline__ unsigned ld_agent(unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_local(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ float2 ld2_agent(const float* p) {
+    const u64 x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)x), __uint_as_float((unsigned)(x >> 32)));
+}
+
+__device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, unsigned* status) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = 0x100u | (xcc & 0xffu);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) st_agent(hello + c, xcc);
+    int verdict = 1;
+    if (w == 0) {
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned v = lane < NC ? ld_agent(hello + lane) : xcc;
+            if (__all(v != 0)) { verdict = __all(v == xcc) ? 1 : 0; break; }
+            if (spins > SPIN_LIMIT) { st_agent(status, 5); verdict = -1; break; }
+            if ((spins & 63) == 63 && ld_agent(status) != 0) { verdict = -1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    const int dead = __syncthreads_or(verdict < 0);
+    const int same = __syncthreads_and(verdict == 1);
+    return dead ? -1 : same;
+}
+
+__device__ __forceinline__ bool wait_flags(unsigned* tflags, int NC, unsigned epoch, unsigned* status, unsigned code) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; ++spins) {
+        const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
+        if (__all(ok)) return true;
+        if (spins > SPIN_LIMIT) { st_agent(status, code); return false; }
+        if ((spins & 63) == 63 && ld_agent(status) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// block id = (dir*NC + c)*nbtp + bt  (nbtp a multiple of 8: all members of a cluster share blockIdx % 8)
+// =============================================================================== forward
+template <int KCH>      // k-chunks of 16 per wave = H/32
+__global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
+    const int bt = blockIdx.x % p.nbtp, dc = blockIdx.x / p.nbtp, c = dc % NC, dir = dc / NC;
+    if (bt * BT >= p.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4, jl = w >> 1, kh = w & 1;
+    const int jt = c * 2 + jl;
+    const int b = bt * BT + j;
+    const bool valid = b < p.B;
+    float* hs = smem;                                 // [16][LDH]
+    float* red = smem + BT * LDH;                     // [4 waves][4 gates][64][4]
+    for (int i = tid; i < BT * LDH; i += CT) hs[i] = 0.f;
+
+    f32x4 wr[4][KCH];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+            wr[g][k] = p.wp[dir][(size_t)((jt * 4 + g) * KC + kh * KCH + k) * 64 + lane];
+    const int col = jt * 16 + q * 4 + 2 * kh;
+    float2 cst = f2(0.f, 0.f), hlast = f2(0.f, 0.f);
+    const int cl = dir * p.nbtp + bt;                 // cluster index
+    const size_t pstride = (size_t)p.dirs * p.nbtp * BT * H;
+    const size_t tile_base = (size_t)cl * BT * H;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
+    unsigned* myflag = p.flags + cl * NC + c;
+    unsigned* tflags = p.flags + cl * NC;
+    const int hshift = __ffs(H) - 1;
+    const int ldsg = p.dirs * 4 * H, ldsc = p.dirs * H;
+    bool dead = false;
+    const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + cl * NC, NC, c, p.status);
+    if (sx < 0) return;
+    const bool fast = sx == 1;
+    float2 gin[4];
+    {
+        const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            gin[g] = valid ? ld2(p.gi + ((size_t)b * T + t0) * p.ldgi + dir * 4 * H + g * H + col) : f2(0.f, 0.f);
+    }
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? (T - 1 - s) : s;
+        const size_t row = (size_t)b * T + t;
+        float2 gi[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gi[g] = gin[g];
+        const bool more = s + 1 < T;
+        if (valid && more) {
+            const size_t rown = dir ? row - 1 : row + 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gin[g] = ld2(p.gi + rown * p.ldgi + dir * 4 * H + g * H + col);
+        }
+        f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+        const float* hrow = hs + j * LDH + kh * KCH * 16 + q * 4;
+        f32x4 hv[KCH];
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) hv[k] = ld4(hrow + k * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(red + ((w * 4 + g) * 64 + lane) * 4) = acc[g];
+        __syncthreads();
+        float2 tot[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float2 pv = ld2(red + (((w ^ 1) * 4 + g) * 64 + lane) * 4 + 2 * kh);
+            tot[g].x = (kh ? acc[g][2] : acc[g][0]) + pv.x + gi[g].x;
+            tot[g].y = (kh ? acc[g][3] : acc[g][1]) + pv.y + gi[g].y;
+        }
+        float2 ig, fg, gg, og, h;
+        ig.x = dep_sigmoid(tot[0].x); ig.y = dep_sigmoid(tot[0].y);
+        fg.x = dep_sigmoid(tot[1].x); fg.y = dep_sigmoid(tot[1].y);
+        gg.x = tanhf(tot[2].x); gg.y = tanhf(tot[2].y);
+        og.x = dep_sigmoid(tot[3].x); og.y = dep_sigmoid(tot[3].y);
+        cst.x = fg.x * cst.x + ig.x * gg.x; cst.y = fg.y * cst.y + ig.y * gg.y;
+        h.x = og.x * tanhf(cst.x); h.y = og.y * tanhf(cst.y);
+        hlast = h;
+        const unsigned epoch = (unsigned)s + 1u;
+        const size_t pbase = (size_t)(s & 1) * pstride + tile_base;
+        if (more) {
+            const u64 bits = (u64)__float_as_uint(h.x) | ((u64)__float_as_uint(h.y) << 32);
+            gu64* dst = (gu64*)(p.payload + pbase + (size_t)j * H + col);
+            if (fast) __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        }
+        if (valid) {
+            const size_t o = row * p.ldy + dir * H + col;
+            st2(p.y + o, h);
+            if (p.ydrop) {
+                const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+                st2(p.ydrop + o, f2(h.x * (kh ? m[2] : m[0]), h.y * (kh ? m[3] : m[1])));
+            }
+            if (p.svg) {
+                float* gs = p.svg + row * ldsg + dir * 4 * H + col;
+                st2(gs, ig); st2(gs + H, fg); st2(gs + 2 * H, gg); st2(gs + 3 * H, og);
+                st2(p.svc + row * ldsc + dir * H + col, cst);
+            }
+        }
+        if (more) {
+            if (w == 0 && !wait_flags(tflags, NC, epoch, p.status, 6)) dead = true;
+            if (__syncthreads_or(dead)) return;
+            constexpr int PER = KCH / 2;              // 16-byte pieces per thread = 16*H/4/256
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i4 = (tid + CT * k) * 4;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((pbase + i4) * 4), 0, 16 /* sc1 */);
+                f32x4 f;
+                f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+                *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
+            }
+            __syncthreads();
+        }
+    }
+    if (valid && p.h_n) st2(p.h_n + ((size_t)dir * p.B + b) * H + col, hlast);
+}
+
+// =============================================================================== backward
+struct StepIn { float2 ig, fg, gg, og, ct, cp, dy; };
+
+template <int NTW>      // output tiles per wave = H/64
+__global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 128, KCB = KS / 16, LDG = KS + LPAD;
+    const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
+    const int bt = blockIdx.x % p.nbtp, dc = blockIdx.x / p.nbtp, c = dc % NC, dir = dc / NC;
+    if (bt * BT >= p.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int jl = tid >> 7, lp = (tid >> 1) & 63, half = tid & 1;
+    const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;
+    const int col = 32 * c + ul;
+    const int b = bt * BT + j;
+    const bool valid = b < p.B;
+    float* dgs = smem;                                // [16][LDG]
+
+    f32x4 wr[NTW][KCB];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int k = 0; k < KCB; ++k)
+            wr[i][k] = p.wp[dir][(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
+    float2 dhrec = (p.dh_n && valid) ? ld2(p.dh_n + ((size_t)dir * p.B + b) * H + col) : f2(0.f, 0.f);
+    float2 dcrec = f2(0.f, 0.f);
+    float2 db[4] = {f2(0.f, 0.f), f2(0.f, 0.f), f2(0.f, 0.f), f2(0.f, 0.f)};
+    const int cl = dir * p.nbtp + bt;
+    const size_t pstride = (size_t)p.dirs * p.nbtp * NC * BT * H;
+    const size_t tile_base = (size_t)cl * NC * BT * H;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
+    unsigned* myflag = p.flags + cl * NC + c;
+    unsigned* tflags = p.flags + cl * NC;
+    const int ml = lane & 15, mq = lane >> 4;
+    const int ldsg = p.dirs * 4 * H, ldsc = p.dirs * H;
+    bool dead = false;
+    const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + cl * NC, NC, c, p.status);
+    if (sx < 0) return;
+    const bool fast = sx == 1;
+
+    auto load_step = [&](int s, StepIn& st) {
+        st.ig = st.fg = st.gg = st.og = st.ct = st.cp = st.dy = f2(0.f, 0.f);
+        if (valid && s >= 0) {
+            const int t = dir ? (T - 1 - s) : s;
+            const size_t row = (size_t)b * T + t;
+            const float* gs = p.svg + row * ldsg + dir * 4 * H + col;
+            st.ig = ld2(gs); st.fg = ld2(gs + H); st.gg = ld2(gs + 2 * H); st.og = ld2(gs + 3 * H);
+            st.ct = ld2(p.svc + row * ldsc + dir * H + col);
+            if (s > 0) { const size_t rowp = dir ? row + 1 : row - 1; st.cp = ld2(p.svc + rowp * ldsc + dir * H + col); }
+            if (p.dy) st.dy = ld2(p.dy + row * p.lddy + dir * H + col);
+        }
+    };
+    StepIn cur, nxt;
+    load_step(T - 1, cur);
+
+    for (int s = T - 1; s >= 0; --s) {
+        const int t = dir ? (T - 1 - s) : s;
+        const size_t row = (size_t)b * T + t;
+        float2 dyv = cur.dy;
+        if (p.dy && p.drop_p > 0.f && valid) {
+            const size_t o = row * p.lddy + dir * H + col;
+            const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+            dyv.x *= (half ? m[2] : m[0]); dyv.y *= (half ? m[3] : m[1]);
+        }
+        const float2 ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og, cp = cur.cp;
+        const float2 d = f2(dhrec.x + dyv.x, dhrec.y + dyv.y);
+        const float2 tc = f2(tanhf(cur.ct.x), tanhf(cur.ct.y));
+        float2 dog, dct, dig, dfg, dgg;
+        dog.x = d.x * tc.x * og.x * (1.0f - og.x); dog.y = d.y * tc.y * og.y * (1.0f - og.y);
+        dct.x = d.x * og.x * (1.0f - tc.x * tc.x) + dcrec.x; dct.y = d.y * og.y * (1.0f - tc.y * tc.y) + dcrec.y;
+        dig.x = dct.x * gg.x * ig.x * (1.0f - ig.x); dig.y = dct.y * gg.y * ig.y * (1.0f - ig.y);
+        dfg.x = dct.x * cp.x * fg.x * (1.0f - fg.x); dfg.y = dct.y * cp.y * fg.y * (1.0f - fg.y);
+        dgg.x = dct.x * ig.x * (1.0f - gg.x * gg.x); dgg.y = dct.y * ig.y * (1.0f - gg.y * gg.y);
+        dcrec.x = dct.x * fg.x; dcrec.y = dct.y * fg.y;
+        float* dl = dgs + j * LDG + ul;
+        st2(dl, dig); st2(dl + 32, dfg); st2(dl + 64, dgg); st2(dl + 96, dog);
+        if (valid) {
+            float* g = p.dgi + row * p.lddg + dir * 4 * H + col;
+            st2(g, dig); st2(g + H, dfg); st2(g + 2 * H, dgg); st2(g + 3 * H, dog);
+        }
+        db[0].x += dig.x; db[0].y += dig.y; db[1].x += dfg.x; db[1].y += dfg.y;
+        db[2].x += dgg.x; db[2].y += dgg.y; db[3].x += dog.x; db[3].y += dog.y;
+        __syncthreads();
+        if (s == 0) break;
+        load_step(s - 1, nxt);
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] = zero4();
+        const float* drow = dgs + ml * LDG + mq * 4;
+        f32x4 hv[KCB];
+#pragma unroll
+        for (int k = 0; k < KCB; ++k) hv[k] = ld4(drow + k * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KCB; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[k][e], acc[i], 0, 0, 0);
+        const unsigned epoch = (unsigned)(T - s);
+        const size_t pbase = (size_t)(s & 1) * pstride + tile_base;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const size_t fo = pbase + ((size_t)(c * NTT + w * NTW + i) * 64 + lane) * 4;
+            u32x4 v;
+            v.x = __float_as_uint(acc[i][0]); v.y = __float_as_uint(acc[i][1]);
+            v.z = __float_as_uint(acc[i][2]); v.w = __float_as_uint(acc[i][3]);
+            if (fast) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        if (w == 0 && !wait_flags(tflags, NC, epoch, p.status, 7)) dead = true;
+        if (__syncthreads_or(dead)) return;
+        const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
+        float2 part[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) part[m] = (m < NC) ? ld2_agent(src + (size_t)m * NTT * 256) : f2(0.f, 0.f);
+        float2 sum = f2(0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { sum.x += part[m].x; sum.y += part[m].y; }
+        dhrec = sum;
+        cur = nxt;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int m = 2; m <= 16; m <<= 1) { db[k].x += __shfl_xor(db[k].x, m, 64); db[k].y += __shfl_xor(db[k].y, m, 64); }
+    if (j == 0) {
+        float* o = p.dbpart + ((size_t)dir * p.nwg + bt) * 4 * H;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st2(o + k * H + col, db[k]);
+    }
+}
+
+int nofast_env() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DEP_CLUSTER_NOFAST"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
+}  // namespace
+
+bool dep_cluster_lstm_ok(int H, int B, int dirs) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("DEP_CLUSTER_LSTM"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off || H != 128) return false;                 // KCH = 4, NTW = 2, NC = 4 (backward gathers exactly 4 partials)
+    const int nbtp = (dep_cdiv(B, BT) + 7) / 8 * 8;
+    return dirs * (H / 32) * nbtp <= 256;
+}
+
+size_t dep_cluster_lstm_xbuf_bytes(int H, int B, int dirs) {
+    const int NC = H / 32, nbtp = (dep_cdiv(B, BT) + 7) / 8 * 8;
+    return PAYLOAD_OFF + (size_t)2 * dirs * nbtp * NC * BT * H * sizeof(float) + 256;
+}
+
+int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
+    const int NC = a.H / 32, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    LF p{};
+    p.B = a.B; p.T = a.T; p.H = a.H; p.dirs = a.dirs; p.nbtp = nbtp;
+    for (int d = 0; d < a.dirs; ++d) p.wp[d] = (const f32x4*)a.wp[d];
+    p.gi = a.gi; p.ldgi = a.dirs * 4 * a.H; p.y = a.y; p.ldy = a.ldy;
+    p.ydrop = (a.drop_p > 0.f) ? a.ydrop : nullptr;
+    p.drop_p = a.drop_p; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f; p.seed = a.seed; p.site = a.site;
+    p.h_n = a.h_n;
+    p.svg = a.training ? a.sv0 : nullptr; p.svc = a.sv1;
+    const size_t pay = (size_t)2 * a.dirs * nbtp * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp * NC <= 512);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
+    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+    DepProfScope prof(DEP_PROF_LSTM_FWD, a.stream);
+    const size_t lds = (size_t)(BT * (a.H + LPAD) + 4 * 4 * 64 * 4) * sizeof(float);
+    hipLaunchKernelGGL(lstm_fwd_cluster<4>, dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
+
+int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
+    const int NC = a.H / 32, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    LB p{};
+    p.B = a.B; p.T = a.T; p.H = a.H; p.dirs = a.dirs; p.nbtp = nbtp;
+    for (int d = 0; d < a.dirs; ++d) p.wp[d] = (const f32x4*)a.wpT[d];
+    p.dy = a.dy; p.lddy = a.lddy;
+    p.drop_p = a.dy ? a.drop_p : 0.f; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    p.seed = a.seed; p.site = a.site;
+    p.dh_n = a.dh_n; p.svg = a.sv0; p.svc = a.sv1;
+    p.dgi = a.dgi; p.lddg = a.dirs * 4 * a.H; p.dbpart = a.dbpart; p.nwg = nbt;
+    DEP_CHECK_ARG(a.dbpart_rows >= nbt * a.dirs);
+    const size_t pay = (size_t)2 * a.dirs * nbtp * NC * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp * NC <= 512);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
+    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+    DepProfScope prof(DEP_PROF_LSTM_BWD, a.stream);
+    const size_t lds = (size_t)(BT * (128 + LPAD)) * sizeof(float);
+    hipLaunchKernelGGL(lstm_bwd_cluster<2>, dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}

@@ -169,6 +169,8 @@ RNN_CASES = [
     ('lstm', 6, 20, 24, 16, 2),
     ('lstm', 19, 11, 40, 128, 2),       # cfg3 H
     ('lstm', 3, 5, 16, 32, 2),
+    ('lstm', 19, 11, 40, 128, 3),       # cluster-parallel BiLSTM sweeps (cfg3 H), ragged tile
+    ('lstm', 70, 300, 64, 128, 3),      # 5 tiles -> 8 padded x 2 directions x 4 members, full T
 ]
 
 
@@ -223,7 +225,7 @@ def test_rnn_stack_fwd_bwd(cell, B, T, F, H, impl, gemm_mode):
         assert relerr(host(g), Gr[n]) < 1e-4, n
 
 
-@pytest.mark.parametrize('cell,impl,H', [('gru', 2, 16), ('gru', 1, 16), ('lstm', 2, 16), ('lstm', 1, 8), ('gru', 3, 128)])
+@pytest.mark.parametrize('cell,impl,H', [('gru', 2, 16), ('gru', 1, 16), ('lstm', 2, 16), ('lstm', 1, 8), ('gru', 3, 128), ('lstm', 3, 128)])
 def test_rnn_interlayer_dropout_matches_oracle_with_same_masks(cell, impl, H):
     """nn.GRU/LSTM(dropout=p) training mode: the oracle is fed the masks the HIP path drew."""
     rng = np.random.default_rng(77 + impl + H)
