@@ -17,7 +17,8 @@ constexpr int BT = 16;
 constexpr int LPAD = 4;
 constexpr int CT = 256;
 constexpr unsigned SPIN_LIMIT = 1u << 20;
-constexpr size_t FLAG_OFF = 256, HELLO_OFF = 3328, PAYLOAD_OFF = 8192;    // up to 512 flag words + 512 hello words
+constexpr size_t FLAG_OFF = 256, HELLO_OFF = 3328, TRACE_OFF = 6144, PAYLOAD_OFF = 8192;    // up to 512 flag words + 512 hello words
+#define DEP_STAMP(slot) do { if (tr && t >= 100 && t < 104) tr[(t - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -35,6 +36,7 @@ struct F16 {
     float* sv0; float* sv1; float* sv2; float* sv3;
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
     int nofast;
+    long long* trace;
 };
 
 struct B16 {
@@ -61,6 +63,18 @@ __device__ __forceinline__ void st_local(unsigned* p, unsigned v) { __hip_atomic
 __device__ __forceinline__ float ldf_agent(const float* p) {
     return __uint_as_float(__hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, i.e. it would put every global store
+// issued earlier in the step (y, dropped y, saved gates) on the step's critical path; here those stay in flight and
+// are only drained by the explicit s_waitcnt vmcnt(0) that precedes the next flag publication.
+__device__ __forceinline__ void bar_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+// v_exp_f32 / v_rcp_f32 based gate nonlinearities: absolute error ~2e-7, far inside the 1e-4 parity budget and
+// ~4x shorter than the ocml expf / tanhf sequences that sat on the per-step critical path
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // see rnn_cluster_bwd.hip: 1 = every member runs on the same XCD, 0 = not, -1 = gave up
 __device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, unsigned* status) {
@@ -113,7 +127,9 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
     const bool valid = b < p.B;
     float* hs = smem;                                 // [16][LDH]
     float* red = smem + BT * LDH;                     // [4 waves][3 gates][64 lanes][4]
+    volatile int* deadflag = reinterpret_cast<volatile int*>(red + 4 * 3 * 64 * 4);
     for (int i = tid; i < BT * LDH; i += CT) hs[i] = 0.f;
+    if (tid == 0) *deadflag = 0;
 
     f32x4 wr[3][KCQ];
 #pragma unroll
@@ -142,14 +158,16 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
     for (int g = 0; g < 3; ++g) gin[g] = valid ? p.gi[(size_t)b * T * p.ldgi + g * H + col] : 0.f;
     __syncthreads();
 
+    long long* tr = (p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)b * T + t;
-        float gi[3];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) gi[g] = gin[g];
+        DEP_STAMP(0);
+        // next step's input projection: issued here, under the MFMAs, and complete by the drain that precedes the
+        // flag -- a load still in flight during the poll/gather would delay those (VMEM loads return in order)
+        float gnx[3] = {0.f, 0.f, 0.f};
         if (valid && t + 1 < T) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) gin[g] = p.gi[(row + 1) * p.ldgi + g * H + col];
+            for (int g = 0; g < 3; ++g) gnx[g] = p.gi[(row + 1) * p.ldgi + g * H + col];
         }
         f32x4 acc[3] = {zero4(), zero4(), zero4()};
         const float* hrow = hs + j * LDH + w * KCQ * 16 + q * 4;
@@ -164,9 +182,11 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
                     acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
+        DEP_STAMP(1);
 #pragma unroll
         for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + ((w * 3 + g) * 64 + lane) * 4) = acc[g];
-        __syncthreads();
+        bar_lds();
+        DEP_STAMP(2);
         float tot[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
@@ -175,22 +195,26 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
             for (int ww = 0; ww < 4; ++ww) s += red[((ww * 3 + g) * 64 + rsrc_lane) * 4 + rsrc_e];
             tot[g] = s;
         }
-        const float r = dep_sigmoid(gi[0] + tot[0] + bh[0]);
-        const float z = dep_sigmoid(gi[1] + tot[1] + bh[1]);
+        const float r = fast_sigmoid(gin[0] + tot[0] + bh[0]);
+        const float z = fast_sigmoid(gin[1] + tot[1] + bh[1]);
         const float hn = tot[2] + bh[2];
-        const float n = tanhf(gi[2] + r * hn);
+        const float n = fast_tanh(gin[2] + r * hn);
         const float h = (1.0f - z) * n + z * hprev;
         hprev = h; pool += h;
         const unsigned epoch = (unsigned)t + 1u;
         const size_t pbase = (size_t)(t & 1) * pstride + tile_base;
         const bool more = t + 1 < T;
+        DEP_STAMP(3);
         if (more) {
             gu32* dst = (gu32*)(p.payload + pbase + (size_t)fj * H + col);
             if (fast) __hip_atomic_store(dst, __float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(dst, __float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            DEP_STAMP(4);
+            __builtin_amdgcn_s_barrier();
             if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gin[g] = gnx[g];      // landed: the drain above waited for it
         }
         if (valid) {
             const size_t o = row * p.ldy + col;
@@ -199,8 +223,11 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
             if (p.sv0) { const size_t so = row * H + col; p.sv0[so] = r; p.sv1[so] = z; p.sv2[so] = n; p.sv3[so] = hn; }
         }
         if (more) {
-            if (w == 0 && !wait_flags(tflags, NC, epoch, p.status, 4)) dead = true;
-            if (__syncthreads_or(dead)) return;
+            if (w == 0 && !wait_flags(tflags, NC, epoch, p.status, 4)) *deadflag = 1;
+            DEP_STAMP(5);
+            bar_lds();
+            if (*deadflag) return;
+            DEP_STAMP(6);
             constexpr int PER = KCQ;                  // 16-byte pieces per thread = 16*H/4/256 = H/64
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
@@ -210,7 +237,8 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
                 f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
                 *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
             }
-            __syncthreads();
+            bar_lds();
+            DEP_STAMP(7);
         }
     }
     if (valid) {
@@ -403,9 +431,11 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC <= 512);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
+    { static int trc = -1; if (trc < 0) { const char* e = getenv("DEP_TRACE"); trc = (e && e[0] == '1') ? 1 : 0; }
+      p.trace = trc ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr; }
     if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
-    const size_t lds = (size_t)(BT * (a.H + LPAD) + 4 * 3 * 64 * 4) * sizeof(float);
+    const size_t lds = (size_t)(BT * (a.H + LPAD) + 4 * 3 * 64 * 4 + 16) * sizeof(float);
     hipLaunchKernelGGL(gru_fwd_cluster16<4>, dim3(NC * nbtp), dim3(CT), lds, a.stream, p);
     DEP_CHECK_LAUNCH();
     return DEP_OK;

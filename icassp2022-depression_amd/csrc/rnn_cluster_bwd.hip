@@ -91,6 +91,13 @@ __device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, 
     return dead ? -1 : same;
 }
 
+// LDS-only workgroup barrier (see rnn_cluster16.hip): __syncthreads() would also drain vmcnt and put this step's
+// global stores on the critical path.
+__device__ __forceinline__ void bar_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 struct StepIn { float2 r, z, n, hn, hp, dy; };
 
 // Thread -> element map (matches the fragment order of the published partials, so the gather is coalesced):
@@ -110,6 +117,8 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     const int b = bt * BT + j;
     const bool valid = b < p.B;
     float* dgs = smem;                                                     // [16][LDG]
+    volatile int* deadflag = reinterpret_cast<volatile int*>(smem + BT * LDG);
+    if (tid == 0) *deadflag = 0;
 
     f32x4 wr[NTW][KCB];
 #pragma unroll
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
             st2(p.dghn + row * H + col, dnr);
         }
         dbr.x += dr.x; dbr.y += dr.y; dbz.x += dz.x; dbz.y += dz.y; dbn.x += dn.x; dbn.y += dn.y; dbh.x += dnr.x; dbh.y += dnr.y;
-        __syncthreads();
+        bar_lds();                                   // LDS only: the dgi/dghn stores above stay in flight
         if (t == 0) break;
         load_step(t - 1, nxt);                       // independent of the recurrence: in flight under the MFMAs
         f32x4 acc[NTW];
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
             else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 16 /* sc1: write-through */);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();                // every wave drained its payload stores (vmcnt(0) above)
         if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         // wait for every member's flag (one wave polls, relaxed; flags are monotonic)
         if (w == 0) {
@@ -212,7 +221,9 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        if (__syncthreads_or(dead)) return;
+        if (dead) *deadflag = 1;
+        bar_lds();
+        if (*deadflag) return;
         // gather this thread's two columns from the NC partials, sum in member order
         float2 s = f2(0.f, 0.f);
         const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
