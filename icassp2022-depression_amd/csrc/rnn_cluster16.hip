@@ -223,10 +223,11 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
             if (p.sv0) { const size_t so = row * H + col; p.sv0[so] = r; p.sv1[so] = z; p.sv2[so] = n; p.sv3[so] = hn; }
         }
         if (more) {
-            if (w == 0 && !wait_flags(tflags, NC, epoch, p.status, 4)) *deadflag = 1;
+            // every wave polls the (L2-resident) flags itself: saves the barrier that used to broadcast wave 0's verdict.
+            // A wave that gives up leaves; the hardware barrier only counts live waves and the others give up as well
+            // (the status word is raised).
+            if (!wait_flags(tflags, NC, epoch, p.status, 4)) return;
             DEP_STAMP(5);
-            bar_lds();
-            if (*deadflag) return;
             DEP_STAMP(6);
             constexpr int PER = KCQ;                  // 16-byte pieces per thread = 16*H/4/256 = H/64
 #pragma unroll

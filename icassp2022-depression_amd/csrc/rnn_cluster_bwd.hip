@@ -212,18 +212,16 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         __builtin_amdgcn_s_barrier();                // every wave drained its payload stores (vmcnt(0) above)
         if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         // wait for every member's flag (one wave polls, relaxed; flags are monotonic)
-        if (w == 0) {
-            for (unsigned spins = 0;; ++spins) {
-                const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
-                if (__all(ok)) break;
-                if (spins > SPIN_LIMIT) { st_agent(p.status, 3); dead = true; break; }
-                if ((spins & 63) == 63 && ld_agent(p.status) != 0) { dead = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
+        // every wave polls the flags itself (no verdict-broadcast barrier); a wave that gives up leaves, the hardware
+        // barrier only counts live waves and the others give up too (status word raised)
+        for (unsigned spins = 0;; ++spins) {
+            const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
+            if (__all(ok)) break;
+            if (spins > SPIN_LIMIT) { st_agent(p.status, 3); dead = true; break; }
+            if ((spins & 63) == 63 && ld_agent(p.status) != 0) { dead = true; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (dead) *deadflag = 1;
-        bar_lds();
-        if (*deadflag) return;
+        if (dead) return;
         // gather this thread's two columns from the NC partials, sum in member order
         float2 s = f2(0.f, 0.f);
         const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
