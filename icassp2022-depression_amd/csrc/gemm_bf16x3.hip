@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int BN = 128, BK = 32, NT = 256;
 constexpr int LDK = 40;      // bf16 per LDS row: 80-byte rows -> conflict-free ds_read_b128 fragments and ds_write_b64 staging
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -31,15 +31,16 @@ struct GemmP {
     int ablate;             // debug (DEP_GEMM_ABLATE): 1 no epilogue stores, 2 no MFMA, 4 no tile reloads, 8 no LDS staging
 };
 
-// r[i][e]: !TR -> row (mn0 + rr + 32 i), k = k0 + kq*4 + e      (kq = tid&7, rr = tid>>3)
-//           TR -> k row (k0 + kg*4 + i), mn = mn0 + mq*4 + e     (kg = tid&7, mq = tid>>3)
-template <bool TR, bool VEC>
+// Operand tile of ROWS (128 or 256) rows x 32 k, 256 threads: a = tid&7, bq = tid>>3.
+//   !TR (K-contiguous rows): r[i]      = row (mn0 + bq + 32 i),            k  = k0 + a*4 + 0..3     i < ROWS/32
+//    TR (MN-contiguous)    : r[4jj + i] = k row (k0 + a*4 + i),           mn = mn0 + (bq + 32 jj)*4 + 0..3
+template <bool TR, bool VEC, int ROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int Kend,
-                                          int tid, float (&r)[4][4], int seqT, int shift) {
+                                          int tid, float (&r)[ROWS / 32][4], int seqT, int shift) {
     const int a = tid & 7, bq = tid >> 3;
     if (!TR) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < ROWS / 32; ++i) {
             const int mn = mn0 + bq + 32 * i, k = k0 + a * 4;
             const float* src = P + (size_t)mn * ld + k;
             if (VEC) {
@@ -53,20 +54,23 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + a * 4 + i, mn = mn0 + bq * 4;
-            bool ok = k < Kend;
-            if (seqT > 0) { const int tt = k % seqT + shift; ok = ok && tt >= 0 && tt < seqT; }
-            const float* src = P + ((long)k + shift) * ld + mn;
-            if (VEC) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok && mn < MN) v = *reinterpret_cast<const f32x4*>(src);
-                r[i][0] = v[0]; r[i][1] = v[1]; r[i][2] = v[2]; r[i][3] = v[3];
-            } else {
+        for (int jj = 0; jj < ROWS / 128; ++jj)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[i][e] = (ok && mn + e < MN) ? src[e] : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + a * 4 + i, mn = mn0 + (bq + 32 * jj) * 4;
+                bool ok = k < Kend;
+                if (seqT > 0) { const int tt = k % seqT + shift; ok = ok && tt >= 0 && tt < seqT; }
+                const float* src = P + ((long)k + shift) * ld + mn;
+                float (&rr)[4] = r[jj * 4 + i];
+                if (VEC) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ok && mn < MN) v = *reinterpret_cast<const f32x4*>(src);
+                    rr[0] = v[0]; rr[1] = v[1]; rr[2] = v[2]; rr[3] = v[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rr[e] = (ok && mn + e < MN) ? src[e] : 0.f;
+                }
             }
-        }
     }
 }
 
@@ -76,13 +80,13 @@ __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
     lo = __builtin_convertvector(x - back, bf16x4);
 }
 
-// LDS images Sh/Sl: [128 rows (m or n)][LDK] bf16, k contiguous
-template <bool TR>
-__device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, const float (&r)[4][4]) {
+// LDS images Sh/Sl: [ROWS rows (m or n)][LDK] bf16, k contiguous
+template <bool TR, int ROWS>
+__device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, const float (&r)[ROWS / 32][4]) {
     const int a = tid & 7, bq = tid >> 3;
     if (!TR) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < ROWS / 32; ++i) {
             f32x4 x = {r[i][0], r[i][1], r[i][2], r[i][3]};
             bf16x4 hi, lo; split4(x, hi, lo);
             const int o = (bq + 32 * i) * LDK + a * 4;
@@ -90,32 +94,35 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
         }
     } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f32x4 x = {r[0][e], r[1][e], r[2][e], r[3][e]};       // 4 consecutive k of row (bq*4 + e)
-            bf16x4 hi, lo; split4(x, hi, lo);
-            const int o = (bq * 4 + e) * LDK + a * 4;
-            *reinterpret_cast<bf16x4*>(Sh + o) = hi; *reinterpret_cast<bf16x4*>(Sl + o) = lo;
-        }
+        for (int jj = 0; jj < ROWS / 128; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x4 x = {r[jj * 4 + 0][e], r[jj * 4 + 1][e], r[jj * 4 + 2][e], r[jj * 4 + 3][e]};
+                bf16x4 hi, lo; split4(x, hi, lo);
+                const int o = ((bq + 32 * jj) * 4 + e) * LDK + a * 4;
+                *reinterpret_cast<bf16x4*>(Sh + o) = hi; *reinterpret_cast<bf16x4*>(Sl + o) = lo;
+            }
     }
 }
 
 // Persistent, cross-tile pipelined: a workgroup walks a strided list of output tiles taken from ITS XCD's contiguous
 // share of the tile order (so tiles processed together on an XCD share operand panels in that L2) and treats
 // (tile, k-tile) as one iteration space: the register prefetch issued in the last k-iteration of a tile already
-// belongs to the next tile, and a tile's epilogue stores drain while the next tile's loads are in flight.  These
-// contractions have short K per tile (256..2400), so without this every tile paid an exposed load latency up front
-// and an exposed store burst at the end (the phases of a tile were additive in an ablation, not overlapped).
-template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(NT, 3) void gemm_bf16x3(GemmP p) {
+// belongs to the next tile, and a tile's epilogue stores drain while the next tile's loads are in flight.
+// Tile = BMT x 128 (BMT = 256 for the big contractions: these kernels are bound by the L2 -> CU operand feed, not by
+// the matrix pipes, and a 256-row tile moves 25 % fewer operand bytes per flop than 128 x 128), 4 waves as 2 x 2,
+// each (BMT/2) x 64 = (BMT/64) x 2 MFMA tiles of 32x32.
+template <bool TA, bool TB, bool VEC, int BMT>
+__global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p) {
     constexpr bool A_TR = TA, B_TR = !TB;
-    __shared__ __attribute__((aligned(16))) __bf16 smem[4 * BM * LDK];
-    __bf16* Ah = smem; __bf16* Al = smem + BM * LDK; __bf16* Bh = smem + 2 * BM * LDK; __bf16* Bl = smem + 3 * BM * LDK;
+    constexpr int MI = BMT / 64;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * (BMT + BN) * LDK];
+    __bf16* Ah = smem; __bf16* Al = smem + BMT * LDK; __bf16* Bh = smem + 2 * BMT * LDK; __bf16* Bl = Bh + BN * LDK;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
-    // this workgroup's tile list: XCD x = blockIdx % 8 owns tiles [lo, hi) of the (x fastest, y, z) order
     const int ntiles = p.gx * p.gy * p.splits;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int q = ntiles / 8, r = ntiles % 8;
@@ -126,19 +133,19 @@ __global__ __launch_bounds__(NT, 3) void gemm_bf16x3(GemmP p) {
 
     auto coords = [&](int t, int& m0, int& n0, int& kb, int& ke, int& bz) {
         const int bx = t % p.gx, by = (t / p.gx) % p.gy; bz = t / (p.gx * p.gy);
-        m0 = by * BM; n0 = bx * BN; kb = bz * p.kchunk; ke = min(p.K, kb + p.kchunk);
+        m0 = by * BMT; n0 = bx * BN; kb = bz * p.kchunk; ke = min(p.K, kb + p.kchunk);
     };
     int m0, n0, kbeg, kend, bz;
     coords(tile, m0, n0, kbeg, kend, bz);
 
-    f32x16 acc[2][2];
-    float ra[4][4], rb[4][4];
-    load_tile<A_TR, VEC>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra, 0, 0);
-    load_tile<B_TR, VEC>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb, p.seqT, p.shiftB);
+    f32x16 acc[MI][2];
+    float ra[BMT / 32][4], rb[BN / 32][4];
+    load_tile<A_TR, VEC, BMT>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra, 0, 0);
+    load_tile<B_TR, VEC, BN>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb, p.seqT, p.shiftB);
 
     while (true) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -150,27 +157,27 @@ __global__ __launch_bounds__(NT, 3) void gemm_bf16x3(GemmP p) {
 
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             if (!(p.ablate & 8) || k0 == kbeg) {
-                store_tile<A_TR>(Ah, Al, tid, ra);
-                store_tile<B_TR>(Bh, Bl, tid, rb);
+                store_tile<A_TR, BMT>(Ah, Al, tid, ra);
+                store_tile<B_TR, BN>(Bh, Bl, tid, rb);
             }
             __syncthreads();
             if (!(p.ablate & 4)) {
                 if (k0 + BK < kend) {
-                    load_tile<A_TR, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0);
-                    load_tile<B_TR, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb, p.seqT, p.shiftB);
+                    load_tile<A_TR, VEC, BMT>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0);
+                    load_tile<B_TR, VEC, BN>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb, p.seqT, p.shiftB);
                 } else if (has_next) {       // first k-tile of the NEXT output tile
-                    load_tile<A_TR, VEC>(p.A, p.lda, nm0, p.M, nkb, nke, tid, ra, 0, 0);
-                    load_tile<B_TR, VEC>(p.B, p.ldb, nn0, p.N, nkb, nke, tid, rb, p.seqT, p.shiftB);
+                    load_tile<A_TR, VEC, BMT>(p.A, p.lda, nm0, p.M, nkb, nke, tid, ra, 0, 0);
+                    load_tile<B_TR, VEC, BN>(p.B, p.ldb, nn0, p.N, nkb, nke, tid, rb, p.seqT, p.shiftB);
                 }
             }
             if (!(p.ablate & 2))
 #pragma unroll
             for (int s = 0; s < BK / 16; ++s) {
                 const int ko = s * 16 + half * 8;
-                bf16x8 ah[2], al[2], bh[2], bl[2];
+                bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int ro = (wm * 64 + i * 32 + l31) * LDK + ko;
+                for (int i = 0; i < MI; ++i) {
+                    const int ro = (wm * (BMT / 2) + i * 32 + l31) * LDK + ko;
                     ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro); al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
                 }
 #pragma unroll
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_bf16x3(GemmP p) {
                     bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro); bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_bf16x3(GemmP p) {
         float* outp = split ? p.part + (size_t)bz * p.M * p.N : p.C;
         const int ldo = split ? p.N : p.ldc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + j * 32 + l31;
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_bf16x3(GemmP p) {
                 const float bv = (!split && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    const int m = m0 + wm * (BMT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                     if (m < p.M) {
                         float v = acc[i][j][e] + bv;
                         float* dst = outp + (size_t)m * ldo + n;
@@ -235,18 +242,24 @@ __global__ void splitk_reduce2(const float* __restrict__ part, int splits, int M
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
                            int splits, int kchunk, float* part, bool vec, hipStream_t s) {
-    static int abl = -1;
+    static int abl = -1, persist = -1, bm256 = -1;
     if (abl < 0) { const char* e = getenv("DEP_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
-    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BM), abl};
-    // persistent launch: at most PERSIST workgroups (a multiple of 8: one share per XCD), each walks a list of tiles
-    const int ntiles = p.gx * p.gy * splits;
-    static int persist = -1;
     if (persist < 0) { const char* e = getenv("DEP_GEMM_PERSIST"); persist = e ? atoi(e) : 768; if (persist < 8) persist = 8; persist = persist / 8 * 8; }
-    dim3 g(ntiles < persist ? (ntiles + 7) / 8 * 8 : persist);
-#define LAUNCH(TA, TB)                                                                     \
-    do {                                                                                   \
-        if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true>), g, dim3(NT), 0, s, p);    \
-        else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false>), g, dim3(NT), 0, s, p);   \
+    if (bm256 < 0) { const char* e = getenv("DEP_GEMM_BM"); bm256 = (e && atoi(e) == 128) ? 0 : 1; }
+    // measured at cfg2: 256-row tiles win 8-10 % on the NN (dX) and TN (dW) forms, lose 6 % on the short-K NT projection
+    const bool big = bm256 && M >= 512 && !(!transA && transB);
+    const int BMT = big ? 256 : 128;
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl};
+    // persistent launch: at most `persist` workgroups (a multiple of 8: one share per XCD), each walks a list of tiles
+    const int ntiles = p.gx * p.gy * splits;
+    const int cap = big ? persist * 2 / 3 : persist;              // 2 resident workgroups per CU with 256-row tiles, 3 otherwise
+    dim3 g(ntiles < cap ? (ntiles + 7) / 8 * 8 : cap / 8 * 8);
+#define LAUNCH(TA, TB)                                                                               \
+    do {                                                                                             \
+        if (big) { if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, 256>), g, dim3(NT), 0, s, p);      \
+                   else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false, 256>), g, dim3(NT), 0, s, p); }   \
+        else     { if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, 128>), g, dim3(NT), 0, s, p);      \
+                   else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false, 128>), g, dim3(NT), 0, s, p); }   \
     } while (0)
     if (!transA && transB) LAUNCH(false, true);
     else if (!transA && !transB) LAUNCH(false, false);
