@@ -9,21 +9,12 @@
 //   backward: K = 48 (the member's 3x16 gate rows) x all H output columns (4 tiles per wave), partial dh published
 //             in fragment order (16 KB), each thread sums its column over the NC partials in member order.
 // Exchange protocol, same-XCD fast path, parity double-buffering, bounded spins: identical to rnn_cluster_bwd.hip.
-#include "dep_common.h"
+#include "rnn_cluster_common.h"
 
 namespace {
+using namespace depc;
 
-constexpr int BT = 16;
-constexpr int LPAD = 4;
-constexpr int CT = 256;
-constexpr unsigned SPIN_LIMIT = 1u << 20;
-constexpr size_t FLAG_OFF = 256, HELLO_OFF = 3328, TRACE_OFF = 6144, PAYLOAD_OFF = 8192;    // up to 512 flag words + 512 hello words
 #define DEP_STAMP(slot) do { if (tr && t >= 100 && t < 104) tr[(t - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
-
-typedef unsigned long long u64;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) u64 gu64;
-typedef __attribute__((address_space(1))) unsigned gu32;
 
 struct F16 {
     int B, T, H, nbtp;
@@ -54,61 +45,6 @@ struct B16 {
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
     int nofast;
 };
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
-__device__ __forceinline__ unsigned ld_agent(unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_local(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ float ldf_agent(const float* p) {
-    return __uint_as_float(__hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, i.e. it would put every global store
-// issued earlier in the step (y, dropped y, saved gates) on the step's critical path; here those stay in flight and
-// are only drained by the explicit s_waitcnt vmcnt(0) that precedes the next flag publication.
-__device__ __forceinline__ void bar_lds() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-// v_exp_f32 / v_rcp_f32 based gate nonlinearities: absolute error ~2e-7, far inside the 1e-4 parity budget and
-// ~4x shorter than the ocml expf / tanhf sequences that sat on the per-step critical path
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
-
-// see rnn_cluster_bwd.hip: 1 = every member runs on the same XCD, 0 = not, -1 = gave up
-__device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, unsigned* status) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc = 0x100u | (xcc & 0xffu);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) st_agent(hello + c, xcc);
-    int verdict = 1;
-    if (w == 0) {
-        for (unsigned spins = 0;; ++spins) {
-            const unsigned v = lane < NC ? ld_agent(hello + lane) : xcc;
-            if (__all(v != 0)) { verdict = __all(v == xcc) ? 1 : 0; break; }
-            if (spins > SPIN_LIMIT) { st_agent(status, 5); verdict = -1; break; }
-            if ((spins & 63) == 63 && ld_agent(status) != 0) { verdict = -1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    const int dead = __syncthreads_or(verdict < 0);
-    const int same = __syncthreads_and(verdict == 1);
-    return dead ? -1 : same;
-}
-
-// wave 0 waits until the NC flags of this tile reached `epoch` (flags only grow); returns false on give-up
-__device__ __forceinline__ bool wait_flags(unsigned* tflags, int NC, unsigned epoch, unsigned* status, unsigned code) {
-    const int lane = threadIdx.x & 63;
-    for (unsigned spins = 0;; ++spins) {
-        const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
-        if (__all(ok)) return true;
-        if (spins > SPIN_LIMIT) { st_agent(status, code); return false; }
-        if ((spins & 63) == 63 && ld_agent(status) != 0) return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
 
 // =============================================================================== forward
 // matvec roles : lane = (utterance j = lane&15, k-quad q = lane>>4), wave w = K quarter
@@ -394,12 +330,6 @@ __global__ void pack_cluster16_bwd_kernel(const float* __restrict__ W, float* __
     out[idx] = W[(size_t)(g * H + 16 * c + u) * H + jt * 16 + (l & 15)];
 }
 
-int nofast_env() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DEP_CLUSTER_NOFAST"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
-
 }  // namespace
 
 // 16-unit members are used when they fit two per CU and the 32-unit clustering would leave CUs sharing nothing:
@@ -432,8 +362,7 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC <= 512);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
-    { static int trc = -1; if (trc < 0) { const char* e = getenv("DEP_TRACE"); trc = (e && e[0] == '1') ? 1 : 0; }
-      p.trace = trc ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr; }
+    p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
     if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
     const size_t lds = (size_t)(BT * (a.H + LPAD) + 4 * 3 * 64 * 4 + 16) * sizeof(float);

@@ -9,23 +9,13 @@
 // member's flag word; consumers poll the NC flags with relaxed agent-scope loads (>= epoch: flags only grow)
 // and then read their two columns of every member's partial with sc1 loads, summing in member order
 // (deterministic).  Payload buffers alternate by step parity; only the status/flag words are zeroed per launch.
-#include "dep_common.h"
+#include "rnn_cluster_common.h"
 
 namespace {
+using namespace depc;
 
-constexpr int BT = 16;
-constexpr int LPAD = 4;
-constexpr int CT = 256;
-constexpr unsigned SPIN_LIMIT = 1u << 20;
 constexpr size_t EXCLUSIVE_LDS = 84 * 1024;
-constexpr size_t HELLO_OFF = 1280;      // after up to 256 flag words
-constexpr size_t FLAG_OFF = 256, TRACE_OFF = 4096, PAYLOAD_OFF = 8192;
 #define DEP_STAMP(slot) do { if (tr && t >= 100 && t < 104) tr[(t - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
-
-typedef unsigned long long u64;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) u64 gu64;
-typedef __attribute__((address_space(1))) unsigned gu32;
 
 struct P2 {
     int B, T, H, nbtp;
@@ -43,60 +33,6 @@ struct P2 {
     int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
     long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
 };
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
-__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
-__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
-__device__ __forceinline__ float2 f2(float a, float b) { return make_float2(a, b); }
-
-__device__ __forceinline__ unsigned ld_agent(unsigned* p) {
-    return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) {
-    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ld2_agent(const float* p) {      // 8-byte sc1 load (bypasses the stale-prone L1)
-    const u64 x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)x), __uint_as_float((unsigned)(x >> 32)));
-}
-
-__device__ __forceinline__ void st_local(unsigned* p, unsigned v) {   // plain store: stays in this XCD's L2
-    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// Same-XCD fast path.  Correctness never depends on placement: every member announces the XCD it runs on through
-// the placement-independent protocol (sc1 store / sc1 polls); only if ALL members of the cluster report the same
-// XCD do the per-step payload and flag stores drop the write-through bit -- that XCD's L2 is then the coherence
-// point for writers (plain stores are acknowledged by L2) and readers (sc1 loads bypass L1 and are served by L2),
-// and a step's hand-off costs an L2 round trip instead of a trip through the fabric.  Returns -1 on timeout.
-__device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, unsigned* status) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc = 0x100u | (xcc & 0xffu);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) st_agent(hello + c, xcc);
-    int verdict = 1;
-    if (w == 0) {
-        for (unsigned spins = 0;; ++spins) {
-            const unsigned v = lane < NC ? ld_agent(hello + lane) : xcc;
-            if (__all(v != 0)) { verdict = __all(v == xcc) ? 1 : 0; break; }
-            if (spins > SPIN_LIMIT) { st_agent(status, 5); verdict = -1; break; }
-            if ((spins & 63) == 63 && ld_agent(status) != 0) { verdict = -1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    const int dead = __syncthreads_or(verdict < 0);
-    const int same = __syncthreads_and(verdict == 1);
-    return dead ? -1 : same;
-}
-
-// LDS-only workgroup barrier (see rnn_cluster16.hip): __syncthreads() would also drain vmcnt and put this step's
-// global stores on the critical path.
-__device__ __forceinline__ void bar_lds() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
 
 struct StepIn { float2 r, z, n, hn, hp, dy; };
 
@@ -117,8 +53,6 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     const int b = bt * BT + j;
     const bool valid = b < p.B;
     float* dgs = smem;                                                     // [16][LDG]
-    volatile int* deadflag = reinterpret_cast<volatile int*>(smem + BT * LDG);
-    if (tid == 0) *deadflag = 0;
 
     f32x4 wr[NTW][KCB];
 #pragma unroll
@@ -136,7 +70,6 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     unsigned* myflag = p.flags + bt * NC + c;
     unsigned* tflags = p.flags + bt * NC;
     const int ml = lane & 15, mq = lane >> 4;
-    bool dead = false;
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * NC, NC, c, p.status);
     if (sx < 0) return;
     const bool fast = sx == 1;
@@ -214,14 +147,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         // wait for every member's flag (one wave polls, relaxed; flags are monotonic)
         // every wave polls the flags itself (no verdict-broadcast barrier); a wave that gives up leaves, the hardware
         // barrier only counts live waves and the others give up too (status word raised)
-        for (unsigned spins = 0;; ++spins) {
-            const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
-            if (__all(ok)) break;
-            if (spins > SPIN_LIMIT) { st_agent(p.status, 3); dead = true; break; }
-            if ((spins & 63) == 63 && ld_agent(p.status) != 0) { dead = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (dead) return;
+        if (!wait_flags(tflags, NC, epoch, p.status, 3)) return;
         // gather this thread's two columns from the NC partials, sum in member order
         float2 s = f2(0.f, 0.f);
         const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
@@ -297,7 +223,6 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
     unsigned* myflag = p.flags + bt * NC + c;
     unsigned* tflags = p.flags + bt * NC;
     const int hshift = __ffs(H) - 1;
-    bool dead = false;
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * NC, NC, c, p.status);
     if (sx < 0) return;
     const bool fast = sx == 1;
@@ -335,7 +260,7 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
         DEP_STAMP(1);
 #pragma unroll
         for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + ((w * 3 + g) * 64 + lane) * 4) = acc[g];
-        __syncthreads();
+        bar_lds();
         DEP_STAMP(2);
         float2 tot[3];
 #pragma unroll
@@ -345,10 +270,10 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
             tot[g].y = (kh ? acc[g][3] : acc[g][1]) + pv.y;
         }
         float2 r, z, hn, n, h;
-        r.x = dep_sigmoid(gi[0].x + tot[0].x + bh[0].x); r.y = dep_sigmoid(gi[0].y + tot[0].y + bh[0].y);
-        z.x = dep_sigmoid(gi[1].x + tot[1].x + bh[1].x); z.y = dep_sigmoid(gi[1].y + tot[1].y + bh[1].y);
+        r.x = fast_sigmoid(gi[0].x + tot[0].x + bh[0].x); r.y = fast_sigmoid(gi[0].y + tot[0].y + bh[0].y);
+        z.x = fast_sigmoid(gi[1].x + tot[1].x + bh[1].x); z.y = fast_sigmoid(gi[1].y + tot[1].y + bh[1].y);
         hn.x = tot[2].x + bh[2].x; hn.y = tot[2].y + bh[2].y;
-        n.x = tanhf(gi[2].x + r.x * hn.x); n.y = tanhf(gi[2].y + r.y * hn.y);
+        n.x = fast_tanh(gi[2].x + r.x * hn.x); n.y = fast_tanh(gi[2].y + r.y * hn.y);
         h.x = (1.0f - z.x) * n.x + z.x * hprev.x; h.y = (1.0f - z.y) * n.y + z.y * hprev.y;
         hprev = h; pool.x += h.x; pool.y += h.y;
         const unsigned epoch = (unsigned)t + 1u;
@@ -361,7 +286,7 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
             else __hip_atomic_store((gu64*)(p.payload + pbase + (size_t)j * H + col), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             DEP_STAMP(4);
-            __syncthreads();
+            __builtin_amdgcn_s_barrier();
             if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         }
         if (valid) {
@@ -377,17 +302,8 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
             }
         }
         if (more) {
-            if (w == 0) {
-                for (unsigned spins = 0;; ++spins) {
-                    const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
-                    if (__all(ok)) break;
-                    if (spins > SPIN_LIMIT) { st_agent(p.status, 4); dead = true; break; }
-                    if ((spins & 63) == 63 && ld_agent(p.status) != 0) { dead = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
+            if (!wait_flags(tflags, NC, epoch, p.status, 4)) return;      // every wave polls
             DEP_STAMP(5);
-            if (__syncthreads_or(dead)) return;
             DEP_STAMP(6);
             constexpr int PER = KCH / 2;              // 16-byte pieces per thread = 16*H/4/256
 #pragma unroll
@@ -398,7 +314,7 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
                 f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
                 *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
             }
-            __syncthreads();
+            bar_lds();
             DEP_STAMP(7);
         }
     }
@@ -406,12 +322,6 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
         if (p.pooled) st2(p.pooled + (size_t)b * H + col, f2(pool.x * p.pool_scale, pool.y * p.pool_scale));
         if (p.h_n) st2(p.h_n + (size_t)b * H + col, hprev);
     }
-}
-
-int nofast_env() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DEP_CLUSTER_NOFAST"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
 }
 
 }  // namespace
@@ -437,8 +347,7 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
-    { static int tr = -1; if (tr < 0) { const char* e = getenv("DEP_TRACE"); tr = (e && e[0] == '1') ? 1 : 0; }
-      p.trace = tr ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr; }
+    p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
     if (hipMemsetAsync(xbuf, 0, p.trace ? FLAG_OFF + 2048 : PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
     // Ask for more than half of the CU's 160 KiB LDS: the dispatcher can then never co-locate two members on one

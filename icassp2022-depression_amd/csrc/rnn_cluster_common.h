@@ -1,0 +1,103 @@
+// Shared device helpers of the cluster-parallel sweeps (rnn_cluster_bwd.hip, rnn_cluster16.hip, rnn_cluster_lstm.hip):
+// the in-launch workgroup hand-off protocol (cdna_hip_programming.md Guideline 16, recipe R1) and a few small utilities.
+#pragma once
+#include "dep_common.h"
+
+namespace depc {
+
+constexpr int BT = 16;                      // utterances per tile = MFMA N
+constexpr int LPAD = 4;                     // LDS row padding (floats)
+constexpr int CT = 256;                     // compute threads per workgroup
+constexpr unsigned SPIN_LIMIT = 1u << 20;   // bounded spins: ~1 s, then the status word is raised and the kernel leaves
+// exchange buffer header (zeroed before every launch): [0] status | flags (<= 512 words) | hello (<= 512 words) | trace
+constexpr size_t FLAG_OFF = 256, HELLO_OFF = 3328, TRACE_OFF = 6144, PAYLOAD_OFF = 8192;
+
+typedef unsigned long long u64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ float2 f2(float a, float b) { return make_float2(a, b); }
+
+// agent-scope (sc1: L1 bypass, write-through) and workgroup-scope (plain) accesses of the shared words
+__device__ __forceinline__ unsigned ld_agent(unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_local(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ float ldf_agent(const float* p) {
+    return __uint_as_float(__hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ float2 ld2_agent(const float* p) {
+    const u64 x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)x), __uint_as_float((unsigned)(x >> 32)));
+}
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, i.e. it would put every global store
+// issued earlier in the step (y, dropped y, saved gates, dgi) on the step's critical path; here those stay in flight and
+// are only drained by the explicit s_waitcnt vmcnt(0) that precedes the next flag publication.
+__device__ __forceinline__ void bar_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// v_exp_f32 / v_rcp_f32 gate nonlinearities: absolute error ~2e-7, far inside the 1e-4 parity budget and several times
+// shorter than the ocml expf / tanhf sequences that sat on the per-step critical path
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+// Same-XCD fast path.  Correctness never depends on placement: every member announces the XCD it runs on through the
+// placement-independent protocol (sc1 store / sc1 polls); only if ALL members of the cluster report the same XCD do the
+// per-step payload and flag stores drop the write-through bit -- that XCD's L2 is then the coherence point for writers
+// (plain stores are acknowledged by L2) and readers (sc1 loads bypass L1 and are served by L2), and a step's hand-off
+// costs L2 round trips instead of trips through the fabric.  1 = same XCD, 0 = not, -1 = gave up (status raised).
+// Every wave of the workgroup must call it (it contains two workgroup barriers).
+__device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, unsigned* status) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = 0x100u | (xcc & 0xffu);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) st_agent(hello + c, xcc);
+    int verdict = 1;
+    if (w == 0) {
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned v = lane < NC ? ld_agent(hello + lane) : xcc;
+            if (__all(v != 0)) { verdict = __all(v == xcc) ? 1 : 0; break; }
+            if (spins > SPIN_LIMIT) { st_agent(status, 5); verdict = -1; break; }
+            if ((spins & 63) == 63 && ld_agent(status) != 0) { verdict = -1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    const int dead = __syncthreads_or(verdict < 0);
+    const int same = __syncthreads_and(verdict == 1);
+    return dead ? -1 : same;
+}
+
+// Poll the NC epoch flags of this cluster (lane i < NC reads flag i) until all reached `epoch` (flags only grow).
+// Called by every wave; returns false when the bounded spin gave up or another workgroup raised the status word --
+// the wave then simply leaves (the hardware barrier counts live waves only; the other waves give up the same way).
+__device__ __forceinline__ bool wait_flags(unsigned* tflags, int NC, unsigned epoch, unsigned* status, unsigned code) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; ++spins) {
+        const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
+        if (__all(ok)) return true;
+        if (spins > SPIN_LIMIT) { st_agent(status, code); return false; }
+        if ((spins & 63) == 63 && ld_agent(status) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+inline int nofast_env() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DEP_CLUSTER_NOFAST"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+inline int trace_env() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DEP_TRACE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
+}  // namespace depc

@@ -5,20 +5,10 @@
 // through flag-published fp32 payloads with the same-XCD fast path, parity double-buffering and bounded spins.
 // Both directions run in the same launch: at H = 128, B = 512 that is 2 x 32 tiles x 4 members = 256 workgroups.
 // Both biases are folded into the input projection by the caller (dep_rnn_forward), as in rnn_sweep.hip.
-#include "dep_common.h"
+#include "rnn_cluster_common.h"
 
 namespace {
-
-constexpr int BT = 16;
-constexpr int LPAD = 4;
-constexpr int CT = 256;
-constexpr unsigned SPIN_LIMIT = 1u << 20;
-constexpr size_t FLAG_OFF = 256, HELLO_OFF = 3328, PAYLOAD_OFF = 8192;
-
-typedef unsigned long long u64;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) u64 gu64;
-typedef __attribute__((address_space(1))) unsigned gu32;
+using namespace depc;
 
 struct LF {
     int B, T, H, dirs, nbtp;
@@ -44,51 +34,6 @@ struct LB {
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
     int nofast;
 };
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
-__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
-__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
-__device__ __forceinline__ float2 f2(float a, float b) { return make_float2(a, b); }
-__device__ __forceinline__ unsigned ld_agent(unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_local(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ float2 ld2_agent(const float* p) {
-    const u64 x = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)x), __uint_as_float((unsigned)(x >> 32)));
-}
-
-__device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, unsigned* status) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc = 0x100u | (xcc & 0xffu);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) st_agent(hello + c, xcc);
-    int verdict = 1;
-    if (w == 0) {
-        for (unsigned spins = 0;; ++spins) {
-            const unsigned v = lane < NC ? ld_agent(hello + lane) : xcc;
-            if (__all(v != 0)) { verdict = __all(v == xcc) ? 1 : 0; break; }
-            if (spins > SPIN_LIMIT) { st_agent(status, 5); verdict = -1; break; }
-            if ((spins & 63) == 63 && ld_agent(status) != 0) { verdict = -1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    const int dead = __syncthreads_or(verdict < 0);
-    const int same = __syncthreads_and(verdict == 1);
-    return dead ? -1 : same;
-}
-
-__device__ __forceinline__ bool wait_flags(unsigned* tflags, int NC, unsigned epoch, unsigned* status, unsigned code) {
-    const int lane = threadIdx.x & 63;
-    for (unsigned spins = 0;; ++spins) {
-        const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
-        if (__all(ok)) return true;
-        if (spins > SPIN_LIMIT) { st_agent(status, code); return false; }
-        if ((spins & 63) == 63 && ld_agent(status) != 0) return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
 
 // block id = (dir*NC + c)*nbtp + bt  (nbtp a multiple of 8: all members of a cluster share blockIdx % 8)
 // =============================================================================== forward
@@ -123,7 +68,6 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
     unsigned* tflags = p.flags + cl * NC;
     const int hshift = __ffs(H) - 1;
     const int ldsg = p.dirs * 4 * H, ldsc = p.dirs * H;
-    bool dead = false;
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + cl * NC, NC, c, p.status);
     if (sx < 0) return;
     const bool fast = sx == 1;
@@ -163,7 +107,7 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
                     acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(red + ((w * 4 + g) * 64 + lane) * 4) = acc[g];
-        __syncthreads();
+        bar_lds();
         float2 tot[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -172,12 +116,12 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
             tot[g].y = (kh ? acc[g][3] : acc[g][1]) + pv.y + gi[g].y;
         }
         float2 ig, fg, gg, og, h;
-        ig.x = dep_sigmoid(tot[0].x); ig.y = dep_sigmoid(tot[0].y);
-        fg.x = dep_sigmoid(tot[1].x); fg.y = dep_sigmoid(tot[1].y);
-        gg.x = tanhf(tot[2].x); gg.y = tanhf(tot[2].y);
-        og.x = dep_sigmoid(tot[3].x); og.y = dep_sigmoid(tot[3].y);
+        ig.x = fast_sigmoid(tot[0].x); ig.y = fast_sigmoid(tot[0].y);
+        fg.x = fast_sigmoid(tot[1].x); fg.y = fast_sigmoid(tot[1].y);
+        gg.x = fast_tanh(tot[2].x); gg.y = fast_tanh(tot[2].y);
+        og.x = fast_sigmoid(tot[3].x); og.y = fast_sigmoid(tot[3].y);
         cst.x = fg.x * cst.x + ig.x * gg.x; cst.y = fg.y * cst.y + ig.y * gg.y;
-        h.x = og.x * tanhf(cst.x); h.y = og.y * tanhf(cst.y);
+        h.x = og.x * fast_tanh(cst.x); h.y = og.y * fast_tanh(cst.y);
         hlast = h;
         const unsigned epoch = (unsigned)s + 1u;
         const size_t pbase = (size_t)(s & 1) * pstride + tile_base;
@@ -187,7 +131,7 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
             if (fast) __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __builtin_amdgcn_s_barrier();
             if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         }
         if (valid) {
@@ -204,8 +148,7 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
             }
         }
         if (more) {
-            if (w == 0 && !wait_flags(tflags, NC, epoch, p.status, 6)) dead = true;
-            if (__syncthreads_or(dead)) return;
+            if (!wait_flags(tflags, NC, epoch, p.status, 6)) return;      // every wave polls: no verdict-broadcast barrier
             constexpr int PER = KCH / 2;              // 16-byte pieces per thread = 16*H/4/256
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
@@ -215,7 +158,7 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
                 f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
                 *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
             }
-            __syncthreads();
+            bar_lds();
         }
     }
     if (valid && p.h_n) st2(p.h_n + ((size_t)dir * p.B + b) * H + col, hlast);
@@ -256,7 +199,6 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
     unsigned* tflags = p.flags + cl * NC;
     const int ml = lane & 15, mq = lane >> 4;
     const int ldsg = p.dirs * 4 * H, ldsc = p.dirs * H;
-    bool dead = false;
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + cl * NC, NC, c, p.status);
     if (sx < 0) return;
     const bool fast = sx == 1;
@@ -287,7 +229,7 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
         }
         const float2 ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og, cp = cur.cp;
         const float2 d = f2(dhrec.x + dyv.x, dhrec.y + dyv.y);
-        const float2 tc = f2(tanhf(cur.ct.x), tanhf(cur.ct.y));
+        const float2 tc = f2(fast_tanh(cur.ct.x), fast_tanh(cur.ct.y));
         float2 dog, dct, dig, dfg, dgg;
         dog.x = d.x * tc.x * og.x * (1.0f - og.x); dog.y = d.y * tc.y * og.y * (1.0f - og.y);
         dct.x = d.x * og.x * (1.0f - tc.x * tc.x) + dcrec.x; dct.y = d.y * og.y * (1.0f - tc.y * tc.y) + dcrec.y;
@@ -303,7 +245,7 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
         }
         db[0].x += dig.x; db[0].y += dig.y; db[1].x += dfg.x; db[1].y += dfg.y;
         db[2].x += dgg.x; db[2].y += dgg.y; db[3].x += dog.x; db[3].y += dog.y;
-        __syncthreads();
+        bar_lds();                                   // LDS only: the dgi stores above stay in flight
         if (s == 0) break;
         load_step(s - 1, nxt);
         f32x4 acc[NTW];
@@ -333,10 +275,9 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
             else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();
         if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
-        if (w == 0 && !wait_flags(tflags, NC, epoch, p.status, 7)) dead = true;
-        if (__syncthreads_or(dead)) return;
+        if (!wait_flags(tflags, NC, epoch, p.status, 7)) return;
         const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
         float2 part[4];
 #pragma unroll
@@ -356,12 +297,6 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) st2(o + k * H + col, db[k]);
     }
-}
-
-int nofast_env() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DEP_CLUSTER_NOFAST"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
 }
 
 }  // namespace
