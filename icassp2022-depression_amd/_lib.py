@@ -49,6 +49,8 @@ _SIGS = {
     'dep_set_gemm_mode': (C.c_int, [C.c_int, C.c_long]),
     'dep_get_gemm_mode': (C.c_int, []),
     'dep_layernorm_fwd': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
+    'dep_ln_fold_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    'dep_ln_fold_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     'dep_layernorm_bwd_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'dep_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     'dep_attn_fwd': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
@@ -157,6 +159,19 @@ def layernorm_fwd(x2d, gamma, beta, eps=1e-5, save=True):
     check(load().dep_layernorm_fwd(_ptr(x2d), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mr), rows, F, eps, stream()),
           'dep_layernorm_fwd')
     return y, mr
+
+
+def ln_fold_fwd(W, b, gamma, beta, Wf, bf):
+    """Wf = W*gamma, bf = b + W beta (see include/dep_rnn.h: LayerNorm's affine folded into the next linear map)."""
+    J, F = W.shape
+    check(load().dep_ln_fold_fwd(_ptr(W), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(Wf), _ptr(bf), J, F, stream()),
+          'dep_ln_fold_fwd')
+
+
+def ln_fold_bwd(W, dWf, dbf, gamma, beta, dW, db, dgamma, dbeta):
+    J, F = W.shape
+    check(load().dep_ln_fold_bwd(_ptr(W), _ptr(dWf), _ptr(dbf), _ptr(gamma), _ptr(beta), _ptr(dW), _ptr(db), _ptr(dgamma),
+                                 _ptr(dbeta), J, F, stream()), 'dep_ln_fold_bwd')
 
 
 def layernorm_bwd(dy2d, x2d, gamma, mr, dgamma, dbeta, want_dx=False):

@@ -52,8 +52,50 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = lane; i < F; i += 64) { const float d = xr[i] - mean; v = fmaf(d, d, v); }
     const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)F + eps);
     float* yr = y + row * F;
-    for (int i = lane; i < F; i += 64) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+    if (gamma) { for (int i = lane; i < F; i += 64) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i]; }
+    else       { for (int i = lane; i < F; i += 64) yr[i] = (xr[i] - mean) * rstd; }       // plain x-hat (dep_ln_fold_*)
     if (mr && lane == 0) { mr[row * 2] = mean; mr[row * 2 + 1] = rstd; }
+}
+
+// LayerNorm's affine folded into the FIRST linear map that consumes it (dep_ln_fold_fwd / dep_ln_fold_bwd):
+//     (xhat*gamma + beta) W^T + b  ==  xhat (W*gamma)^T + (b + W beta)
+// forward : Wf[j,f] = W[j,f] gamma[f] ,  bf[j] = b[j] + sum_f W[j,f] beta[f]            (one wave per row j)
+__global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ Wf, float* __restrict__ bf, int J, int F) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= J) return;
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) {
+        const float w = W[(size_t)j * F + f];
+        Wf[(size_t)j * F + f] = w * gamma[f];
+        s = fmaf(w, beta[f], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) bf[j] = b[j] + s;
+}
+// backward: given P = dL/dWf (J,F) and q = dL/dbf (J):
+//     dW[j,f] = P[j,f] gamma[f] + q[j] beta[f] ,  db = q ,  dgamma[f] = sum_j P[j,f] W[j,f] ,  dbeta[f] = sum_j W[j,f] q[j]
+// one thread per column f walks the J rows (coalesced across the block; J x F is a few hundred KB)
+__global__ __launch_bounds__(64) void ln_fold_bwd_kernel(const float* __restrict__ W, const float* __restrict__ P,
+                                                         const float* __restrict__ q, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ dW, float* __restrict__ db,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int J, int F) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f < F) {
+        const float g = gamma[f], bt = beta[f];
+        float dg = 0.f, dbt = 0.f;
+        for (int j = 0; j < J; ++j) {
+            const float w = W[(size_t)j * F + f], pj = P[(size_t)j * F + f];
+            const float qj = q[j];
+            dW[(size_t)j * F + f] = fmaf(pj, g, qj * bt);
+            dg = fmaf(pj, w, dg);
+            dbt = fmaf(w, qj, dbt);
+        }
+        dgamma[f] = dg; dbeta[f] = dbt;
+    }
+    if (blockIdx.x == 0) for (int j = threadIdx.x; j < J; j += 64) db[j] = q[j];
 }
 
 // partial[blk][2][F]: per-block column sums of dy*xhat and dy over the block's row range
@@ -334,8 +376,24 @@ inline int nblk(long n, int t = 256) { return dep_cdiv(n, t); }
 
 extern "C" int dep_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
                                  int rows, int F, float eps, void* stream) {
-    DEP_CHECK_ARG(x && gamma && beta && y && rows > 0 && F > 0);
+    DEP_CHECK_ARG(x && y && rows > 0 && F > 0 && ((gamma != nullptr) == (beta != nullptr)));
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(dep_cdiv(rows, 4)), dim3(256), 0, S_, x, gamma, beta, y, mean_rstd, rows, F, eps);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
+
+extern "C" int dep_ln_fold_fwd(const float* W, const float* b, const float* gamma, const float* beta, float* Wf,
+                               float* bf, int J, int F, void* stream) {
+    DEP_CHECK_ARG(W && b && gamma && beta && Wf && bf && J > 0 && F > 0);
+    hipLaunchKernelGGL(ln_fold_fwd_kernel, dim3(dep_cdiv(J, 4)), dim3(256), 0, S_, W, b, gamma, beta, Wf, bf, J, F);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
+
+extern "C" int dep_ln_fold_bwd(const float* W, const float* dWf, const float* dbf, const float* gamma, const float* beta,
+                               float* dW, float* db, float* dgamma, float* dbeta, int J, int F, void* stream) {
+    DEP_CHECK_ARG(W && dWf && dbf && gamma && beta && dW && db && dgamma && dbeta && J > 0 && F > 0);
+    hipLaunchKernelGGL(ln_fold_bwd_kernel, dim3(dep_cdiv(F, 64)), dim3(64), 0, S_, W, dWf, dbf, gamma, beta, dW, db, dgamma, dbeta, J, F);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

@@ -74,10 +74,25 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
+// v_cvt_pk_bf16_f32 is a quarter-rate instruction, so each PAIR of values costs exactly two of them: hi pair =
+// cvt(x0, x1); the fp32 images of the two hi halves come back with a shift / mask of the packed word (hipcc would
+// otherwise re-convert every element on its own); lo pair = cvt(x0 - hi0, x1 - hi1).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2v v = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+    const f32x2v d = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2v));
+}
 __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
-    hi = __builtin_convertvector(x, bf16x4);
-    const f32x4 back = __builtin_convertvector(hi, f32x4);
-    lo = __builtin_convertvector(x - back, bf16x4);
+    unsigned h0, h1, l0, l1;
+    split2(x[0], x[1], h0, l0);
+    split2(x[2], x[3], h1, l1);
+    const u32x2v h = {h0, h1}, l = {l0, l1};
+    hi = __builtin_bit_cast(bf16x4, h);
+    lo = __builtin_bit_cast(bf16x4, l);
 }
 
 // LDS images Sh/Sl: [ROWS rows (m or n)][LDK] bf16, k contiguous
@@ -189,9 +204,11 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        // operands swapped (D = B-rows x A-rows^T): a lane then owns ONE output row m = l31 and, per register
+                        // quad, 4 consecutive n -> the epilogue stores 16 bytes per lane instead of 4
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
                     }
             }
             __syncthreads();
@@ -200,24 +217,36 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
         const bool split = p.part != nullptr;
         float* outp = split ? p.part + (size_t)bz * p.M * p.N : p.C;
         const int ldo = split ? p.N : p.ldc;
+        const bool v4 = ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0);
+        const bool addb = !split && p.bias;
+        const bool rmw = !split && p.beta != 0.f;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (BMT / 2) + i * 32 + l31;
+            if (m >= p.M) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + l31;
-                if (n >= p.N) continue;
-                const float bv = (!split && p.bias) ? p.bias[n] : 0.f;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm * (BMT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                    if (m < p.M) {
-                        float v = acc[i][j][e] + bv;
-                        float* dst = outp + (size_t)m * ldo + n;
-                        if (!split && p.beta != 0.f) v += p.beta * *dst;
-                        if (!(p.ablate & 1) || v == 1.2345e30f) *dst = v;
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+                    if (n >= p.N) continue;
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    float* dst = outp + (size_t)m * ldo + n;
+                    if (v4 && n + 3 < p.N) {
+                        if (addb) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (rmw) v += p.beta * *reinterpret_cast<const f32x4*>(dst);
+                        if (!(p.ablate & 1) || v[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) {
+                                float x = v[e] + (addb ? p.bias[n + e] : 0.f);
+                                if (rmw) x += p.beta * dst[e];
+                                dst[e] = x;
+                            }
                     }
                 }
-            }
+        }
         if (!has_next) break;
         tile = next; m0 = nm0; n0 = nn0; kbeg = nkb; kend = nke; bz = nbz;
     }

@@ -129,6 +129,14 @@ class AudioGRU(nn.Module):
         self._finalize(init)
         self._rnn_w = [self._params[n].data for n, _ in rn]
         self._rnn_g = [self._params[n]._grad for n, _ in rn]
+        if variant == 'clf':
+            # LayerNorm's affine is folded into gru.weight_ih_l0 / bias_ih_l0 (dep_ln_fold_*): the stack runs on x-hat
+            # with the folded pair and hands back their gradients, from which dW, db, dgamma, dbeta follow exactly --
+            # no dL/d(xn) contraction and no pass over (B*T, F) for the two LayerNorm parameter gradients.
+            mk = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
+            self._fold = (mk(3 * H, F), mk(3 * H), mk(3 * H, F), mk(3 * H))          # Wf, bf, dWf, dbf
+            self._rnn_w_fold = [self._fold[0], self._rnn_w[1], self._fold[1]] + self._rnn_w[3:]
+            self._rnn_g_fold = [self._fold[2], self._rnn_g[1], self._fold[3]] + self._rnn_g[3:]
         pool = L.POOL_MEAN if variant == 'clf' else L.POOL_SUM
         self._rnns = _RnnCache(L.CELL_GRU, F, H, Lyr, 1, self.dropout, pool, self.device)
         self._head = _MLPHead(self, 'fc_audio.1', 'fc_audio.4', self.dropout, True, (L.SITE_FC0, L.SITE_FC1))
@@ -153,13 +161,15 @@ class AudioGRU(nn.Module):
         B, T, F = x.shape
         P = self._params
         if self.variant == 'clf':
-            xn, mr = L.layernorm_fwd(x.view(B * T, F), P['ln.weight'].data, P['ln.bias'].data, save=training)
+            xn, _ = L.layernorm_fwd(x.view(B * T, F), None, None, save=False)           # x-hat
+            L.ln_fold_fwd(self._rnn_w[0], self._rnn_w[2], P['ln.weight'].data, P['ln.bias'].data, *self._fold[:2])
+            weights = self._rnn_w_fold
         else:
-            xn, mr = x.view(B * T, F), None
+            xn, weights = x.view(B * T, F), self._rnn_w
         rnn = self._rnns.get(B, T, training)
         pooled = torch.empty(B, self.hidden_dims, dtype=torch.float32, device=self.device)
-        rnn.forward(xn, self._rnn_w, seed=seed, pooled=pooled)
-        return pooled, (x, xn, mr, rnn)
+        rnn.forward(xn, weights, seed=seed, pooled=pooled)
+        return pooled, (x, xn, rnn)
 
     def forward(self, x):
         x = self._to_dev(x)
@@ -174,15 +184,15 @@ class AudioGRU(nn.Module):
         return nn.Output(out, self, z)
 
     def backward(self, dz):
-        x, xn, mr, rnn = self._saved
-        B, T, F = x.shape
+        x, xn, rnn = self._saved
         dpool = self._head.backward(dz)
         P = self._params
-        need_dx = self.variant == 'clf'           # only LayerNorm's affine gradients consume dX
-        dxn = torch.empty(B * T, F, dtype=torch.float32, device=self.device) if need_dx else None
-        rnn.backward(xn, self._rnn_w, self._rnn_g, dpooled=dpool, dx=dxn)
-        if need_dx:
-            L.layernorm_bwd(dxn, x.view(B * T, F), P['ln.weight'].data, mr, P['ln.weight']._grad, P['ln.bias']._grad)
+        if self.variant == 'clf':
+            rnn.backward(xn, self._rnn_w_fold, self._rnn_g_fold, dpooled=dpool, dx=None)
+            L.ln_fold_bwd(self._rnn_w[0], self._fold[2], self._fold[3], P['ln.weight'].data, P['ln.bias'].data,
+                          self._rnn_g[0], self._rnn_g[2], P['ln.weight']._grad, P['ln.bias']._grad)
+        else:
+            rnn.backward(xn, self._rnn_w, self._rnn_g, dpooled=dpool, dx=None)
         self._grad_ready = True
         parallel.all_reduce_grads(self)
 

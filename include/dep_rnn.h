@@ -140,6 +140,18 @@ int dep_get_gemm_mode(void);
  * mean_rstd: (rows,2) saved statistics (may be NULL in inference). */
 int dep_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                       float* mean_rstd, int rows, int F, float eps, void* stream);
+/* gamma == beta == NULL: plain x-hat (no affine), used with the fold below.
+ *
+ * LayerNorm feeding a linear map (ln -> gru.weight_ih_l0, audio_gru_whole.py:104-105) with the affine folded into the map:
+ *     (xhat*gamma + beta) W^T + b  ==  xhat (W*gamma)^T + (b + W beta)
+ * dep_ln_fold_fwd builds Wf (J,F) = W*gamma and bf (J) = b + W beta; the recurrent stack then runs on x-hat with
+ * (Wf, bf) in place of (W, b) and its backward returns dWf, dbf; dep_ln_fold_bwd turns those into
+ *     dW = dWf*gamma + dbf beta^T, db = dbf, dgamma[f] = sum_j dWf[j,f] W[j,f], dbeta[f] = sum_j W[j,f] dbf[j]
+ * -- the gradients nn.LayerNorm + nn.GRU would produce, without ever forming dL/d(xn) (B*T x F) or walking it. */
+int dep_ln_fold_fwd(const float* W, const float* b, const float* gamma, const float* beta,
+                    float* Wf, float* bf, int J, int F, void* stream);
+int dep_ln_fold_bwd(const float* W, const float* dWf, const float* dbf, const float* gamma, const float* beta,
+                    float* dW, float* db, float* dgamma, float* dbeta, int J, int F, void* stream);
 /* dgamma/dbeta are written; dx may be NULL (the reference never consumes it).
  * workspace: dep_layernorm_bwd_workspace_bytes. */
 size_t dep_layernorm_bwd_workspace_bytes(int rows, int F);

@@ -135,6 +135,38 @@ def test_layernorm(rows, F):
     assert relerr(host(db), dbr) < 2e-5
 
 
+@pytest.mark.parametrize('rows,J,F', [(50, 12, 7), (300, 96, 64), (64, 768, 256)])
+def test_ln_fold_matches_explicit_layernorm_chain(rows, J, F):
+    """LayerNorm -> linear with the affine folded into the linear map (dep_ln_fold_*) against the oracle's explicit
+    chain xn = LN(x); g = xn W^T + b: same forward values, same dW, db, dgamma, dbeta."""
+    rng = np.random.default_rng(rows + J + F)
+    f64 = lambda a: a.astype(np.float32).astype(np.float64)
+    x = f64(rng.standard_normal((rows, F)) * 1.5 + 0.2)
+    W = f64(rng.standard_normal((J, F)) * 0.3); b = f64(rng.standard_normal(J))
+    g = f64(rng.standard_normal(F) + 1.0); be = f64(rng.standard_normal(F) * 0.5)
+    dG = f64(rng.standard_normal((rows, J)))
+    # oracle: explicit chain
+    xn, cache = R.layernorm_fwd(x, g, be)
+    G_ref = xn @ W.T + b
+    dxn = dG @ W
+    _, dg_ref, dbe_ref = R.layernorm_bwd(dxn, g, cache)
+    dW_ref = dG.T @ xn; db_ref = dG.sum(0)
+    # device: x-hat, folded pair
+    xhat, _ = L.layernorm_fwd(dev(x), None, None, save=False)
+    Wf = torch.empty(J, F, device=DEV); bf = torch.empty(J, device=DEV)
+    L.ln_fold_fwd(dev(W), dev(b), dev(g), dev(be), Wf, bf)
+    G_dev = host(xhat) @ host(Wf).T + host(bf)
+    assert relerr(G_dev, G_ref) < 2e-5
+    P = dG.T @ host(xhat); q = dG.sum(0)            # what the stack's backward returns for (Wf, bf)
+    dW = torch.empty(J, F, device=DEV); db = torch.empty(J, device=DEV)
+    dg = torch.empty(F, device=DEV); dbe = torch.empty(F, device=DEV)
+    L.ln_fold_bwd(dev(W), dev(P), dev(q), dev(g), dev(be), dW, db, dg, dbe)
+    assert relerr(host(dW), dW_ref) < 2e-5
+    assert relerr(host(db), db_ref) < 2e-5
+    assert relerr(host(dg), dg_ref) < 2e-5
+    assert relerr(host(dbe), dbe_ref) < 2e-5
+
+
 # ----------------------------------------------------------------------------- RNN stacks
 def make_rnn_params(rng, cell, F, H, L, dirs):
     G = 3 if cell == 'gru' else 4
