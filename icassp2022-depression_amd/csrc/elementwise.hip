@@ -57,6 +57,39 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (mr && lane == 0) { mr[row * 2] = mean; mr[row * 2 + 1] = rstd; }
 }
 
+// F = 256*NV: a row lives in NV float4 per lane -- one pass over HBM, 16-byte accesses
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                         float* __restrict__ mr, int rows, float eps) {
+    constexpr int F = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * F);
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = xr[i * 64 + lane]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    const float mean = wave_sum(s) / (float)F;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)F + eps);
+    f32x4* yr = reinterpret_cast<f32x4*>(y + row * F);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f32x4 o = (v[i] - mean) * rstd;
+        if (gamma) {
+            o = o * reinterpret_cast<const f32x4*>(gamma)[i * 64 + lane] + reinterpret_cast<const f32x4*>(beta)[i * 64 + lane];
+        }
+        yr[i * 64 + lane] = o;
+    }
+    if (mr && lane == 0) { mr[row * 2] = mean; mr[row * 2 + 1] = rstd; }
+}
+
 // LayerNorm's affine folded into the FIRST linear map that consumes it (dep_ln_fold_fwd / dep_ln_fold_bwd):
 //     (xhat*gamma + beta) W^T + b  ==  xhat (W*gamma)^T + (b + W beta)
 // forward : Wf[j,f] = W[j,f] gamma[f] ,  bf[j] = b[j] + sum_f W[j,f] beta[f]            (one wave per row j)
@@ -77,25 +110,35 @@ __global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const float* __restric
 }
 // backward: given P = dL/dWf (J,F) and q = dL/dbf (J):
 //     dW[j,f] = P[j,f] gamma[f] + q[j] beta[f] ,  db = q ,  dgamma[f] = sum_j P[j,f] W[j,f] ,  dbeta[f] = sum_j W[j,f] q[j]
-// one thread per column f walks the J rows (coalesced across the block; J x F is a few hundred KB)
-__global__ __launch_bounds__(64) void ln_fold_bwd_kernel(const float* __restrict__ W, const float* __restrict__ P,
-                                                         const float* __restrict__ q, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ dW, float* __restrict__ db,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int J, int F) {
-    const int f = blockIdx.x * 64 + threadIdx.x;
+// block = 64 columns x 16 row groups (1024 threads): coalesced row segments, 16 partial sums per column reduced in LDS
+__global__ __launch_bounds__(1024) void ln_fold_bwd_kernel(const float* __restrict__ W, const float* __restrict__ P,
+                                                           const float* __restrict__ q, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ dW,
+                                                           float* __restrict__ db, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int J, int F) {
+    __shared__ float red[2][16][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + c;
+    float dg = 0.f, dbt = 0.f;
     if (f < F) {
         const float g = gamma[f], bt = beta[f];
-        float dg = 0.f, dbt = 0.f;
-        for (int j = 0; j < J; ++j) {
-            const float w = W[(size_t)j * F + f], pj = P[(size_t)j * F + f];
-            const float qj = q[j];
+#pragma unroll 4
+        for (int j = rg; j < J; j += 16) {
+            const float w = W[(size_t)j * F + f], pj = P[(size_t)j * F + f], qj = q[j];
             dW[(size_t)j * F + f] = fmaf(pj, g, qj * bt);
             dg = fmaf(pj, w, dg);
             dbt = fmaf(w, qj, dbt);
         }
-        dgamma[f] = dg; dbeta[f] = dbt;
     }
-    if (blockIdx.x == 0) for (int j = threadIdx.x; j < J; j += 64) db[j] = q[j];
+    red[0][rg][c] = dg; red[1][rg][c] = dbt;
+    __syncthreads();
+    if (rg == 0 && f < F) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a += red[0][r][c]; b += red[1][r][c]; }
+        dgamma[f] = a; dbeta[f] = b;
+    }
+    if (blockIdx.x == 0) for (int j = threadIdx.x; j < J; j += 1024) db[j] = q[j];
 }
 
 // partial[blk][2][F]: per-block column sums of dy*xhat and dy over the block's row range
@@ -377,7 +420,12 @@ inline int nblk(long n, int t = 256) { return dep_cdiv(n, t); }
 extern "C" int dep_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
                                  int rows, int F, float eps, void* stream) {
     DEP_CHECK_ARG(x && y && rows > 0 && F > 0 && ((gamma != nullptr) == (beta != nullptr)));
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(dep_cdiv(rows, 4)), dim3(256), 0, S_, x, gamma, beta, y, mean_rstd, rows, F, eps);
+    const bool al16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+    const dim3 g(dep_cdiv(rows, 4)), b(256);
+    if (al16 && F == 256) hipLaunchKernelGGL(ln_fwd_vec_kernel<1>, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, eps);
+    else if (al16 && F == 512) hipLaunchKernelGGL(ln_fwd_vec_kernel<2>, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, eps);
+    else if (al16 && F == 1024) hipLaunchKernelGGL(ln_fwd_vec_kernel<4>, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, eps);
+    else hipLaunchKernelGGL(ln_fwd_kernel, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, F, eps);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -393,7 +441,7 @@ extern "C" int dep_ln_fold_fwd(const float* W, const float* b, const float* gamm
 extern "C" int dep_ln_fold_bwd(const float* W, const float* dWf, const float* dbf, const float* gamma, const float* beta,
                                float* dW, float* db, float* dgamma, float* dbeta, int J, int F, void* stream) {
     DEP_CHECK_ARG(W && dWf && dbf && gamma && beta && dW && db && dgamma && dbeta && J > 0 && F > 0);
-    hipLaunchKernelGGL(ln_fold_bwd_kernel, dim3(dep_cdiv(F, 64)), dim3(64), 0, S_, W, dWf, dbf, gamma, beta, dW, db, dgamma, dbeta, J, F);
+    hipLaunchKernelGGL(ln_fold_bwd_kernel, dim3(dep_cdiv(F, 64)), dim3(1024), 0, S_, W, dWf, dbf, gamma, beta, dW, db, dgamma, dbeta, J, F);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

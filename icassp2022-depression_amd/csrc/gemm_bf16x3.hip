@@ -257,8 +257,16 @@ __global__ void splitk_reduce2(const float* __restrict__ part, int splits, int M
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)M * N) return;
     const int m = (int)(idx / N), n = (int)(idx % N);
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[(size_t)z * M * N + idx];
+    // four independent partial sums: the loads of consecutive splits overlap instead of forming one dependent chain
+    const size_t MN = (size_t)M * N;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 3 < splits; z += 4) {
+        s0 += part[(size_t)z * MN + idx]; s1 += part[(size_t)(z + 1) * MN + idx];
+        s2 += part[(size_t)(z + 2) * MN + idx]; s3 += part[(size_t)(z + 3) * MN + idx];
+    }
+    for (; z < splits; ++z) s0 += part[(size_t)z * MN + idx];
+    float s = (s0 + s1) + (s2 + s3);
     if (bias) s += bias[n];
     float* dst = C + (size_t)m * ldc + n;
     if (beta != 0.f) s += beta * *dst;

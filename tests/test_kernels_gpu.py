@@ -117,7 +117,7 @@ def test_gemm_strided_views():
 
 
 # ----------------------------------------------------------------------------- LayerNorm
-@pytest.mark.parametrize('rows,F', [(37, 39), (600, 256), (9, 5)])
+@pytest.mark.parametrize('rows,F', [(37, 39), (600, 256), (9, 5), (130, 512), (66, 1024)])
 def test_layernorm(rows, F):
     rng = np.random.default_rng(rows + F)
     x = rng.standard_normal((rows, F)) * 2 + 0.3

@@ -11,6 +11,6 @@ import csv, glob, sys
 for f in glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True):
     rows = list(csv.DictReader(open(f)))
     print(f)
-    for r in rows[:16]:
+    for r in rows[:34]:
         print('%-78s calls=%-5s avg_us=%10.1f total_ms=%9.3f  %5s%%' % (r['Name'][:78], r['Calls'], float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e6, r['Percentage']))
 PY
