@@ -208,6 +208,69 @@ __global__ void gemm_naive(GemmP p, int TA, int TB) {
     *dst = s;
 }
 
+// Small problems (the heads' nn.Linear layers, the attention projection: a few hundred rows/columns): a 128x128 tile
+// grid would occupy a handful of CUs and walk K serially.  Here a workgroup owns one 32x32 output tile, its four waves
+// take a quarter of K each and feed v_mfma_f32_32x32x2_f32 straight from global memory (operand (row, k) -> lane
+// (row & 31, k & 1): no LDS staging, everything is L2-resident at these sizes), and the four partial tiles are summed
+// through LDS.  Strided element access covers all operand forms.
+struct SmallP {
+    int M, N, K;
+    const float* A; long sam, sak;
+    const float* B; long sbk, sbn;
+    float* C; int ldc;
+    const float* bias; float beta;
+};
+
+__global__ __launch_bounds__(256) void gemm_small(SmallP p) {
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int kq = ((p.K + 3) / 4 + 1) & ~1;
+    const int kb = w * kq, ke = min(p.K, kb + kq);
+    const bool mok = m0 + i < p.M, nok = n0 + i < p.N;
+    const float* ap = p.A + (long)(m0 + i) * p.sam;
+    const float* bp = p.B + (long)(n0 + i) * p.sbn;
+    auto load8 = [&](int k, float (&a)[8], float (&b)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = k + 2 * e + h;
+            a[e] = (mok && kk < ke) ? ap[(long)kk * p.sak] : 0.f;
+            b[e] = (nok && kk < ke) ? bp[(long)kk * p.sbk] : 0.f;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float a0[8], b0[8], a1[8], b1[8];
+    load8(kb, a0, b0);
+    for (int k = kb; k < ke; k += 32) {
+        load8(k + 16, a1, b1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc, 0, 0, 0);
+        load8(k + 32, a0, b0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[w][e][lane] = acc[e];
+    __syncthreads();
+    const int l = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    const int n = n0 + (l & 31);
+    if (n >= p.N) return;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = rq * 4 + rr;
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (m >= p.M) continue;
+        float v = (red[0][r][l] + red[1][r][l]) + (red[2][r][l] + red[3][r][l]) + bv;
+        float* dst = p.C + (size_t)m * p.ldc + n;
+        if (p.beta != 0.f) v += p.beta * *dst;
+        *dst = v;
+    }
+}
+
 int choose_splits(int M, int N, int K) {
     const long tiles = (long)dep_cdiv(M, BM) * dep_cdiv(N, BN);
     if (tiles >= 256 || K < 1024) return 1;
@@ -263,6 +326,14 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     if (naive_forced()) {
         dim3 g(dep_cdiv(N, 128), M);
         hipLaunchKernelGGL(gemm_naive, g, dim3(128), 0, s, p, transA, transB);
+        DEP_CHECK_LAUNCH();
+        return DEP_OK;
+    }
+    if (seq_T <= 0 && (long)dep_cdiv(M, BM) * dep_cdiv(N, BN) < 32 && K <= 8192 && (long)M * N * K <= (1L << 27)) {
+        SmallP q{M, N, K, A, transA ? 1L : (long)lda, transA ? (long)lda : 1L, B, transB ? 1L : (long)ldb,
+                 transB ? (long)ldb : 1L, C, ldc, bias, beta};
+        DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s);
+        hipLaunchKernelGGL(gemm_small, dim3(dep_cdiv(N, 32), dep_cdiv(M, 32)), dim3(256), 0, s, q);
         DEP_CHECK_LAUNCH();
         return DEP_OK;
     }

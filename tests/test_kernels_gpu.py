@@ -28,7 +28,9 @@ def relerr(a, b):
 
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('tA,tB', [(0, 1), (0, 0), (1, 0)])
-@pytest.mark.parametrize('M,N,K', [(300, 200, 64), (77, 45, 39), (128, 128, 32), (1, 5, 7), (513, 260, 100)])
+# small shapes run the 32x32-tile direct-operand kernel, (1100, 700, 96) and up the LDS-tiled 128x128 kernel
+@pytest.mark.parametrize('M,N,K', [(300, 200, 64), (77, 45, 39), (128, 128, 32), (1, 5, 7), (513, 260, 100),
+                                   (2, 256, 512), (1100, 700, 96), (1030, 770, 33)])
 def test_gemm_shapes(tA, tB, M, N, K):
     rng = np.random.default_rng(M * 7 + N * 3 + K + tA * 2 + tB)
     A = rng.standard_normal((K, M) if tA else (M, K))
