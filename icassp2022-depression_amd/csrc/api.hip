@@ -186,6 +186,15 @@ extern "C" int dep_rnn_status(const dep_rnn_desc* d, void* workspace, void* stre
     return DEP_OK;
 }
 
+// Precision of the recurrent products inside the cluster sweeps: follows the GEMM mode (include/dep_rnn.h,
+// dep_set_gemm_mode): 1 = 3-term bf16 split on the bf16 matrix cores, 0 = exact fp32 MFMA.  DEP_SWEEP_MODE=f32 pins the
+// sweeps to fp32 while leaving the GEMMs alone (A/B).
+static bool sweep_split_mode() {
+    static int pin = -1;
+    if (pin < 0) { const char* e = getenv("DEP_SWEEP_MODE"); pin = (e && e[0] == 'f') ? 1 : 0; }
+    return !pin && dep_get_gemm_mode() == 1;
+}
+
 extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const float* const* weights, float* y,
                                float* pooled, float* h_n, void* reserve, size_t reserve_bytes, void* workspace,
                                size_t workspace_bytes, void* stream) {
@@ -203,6 +212,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     const int B = d->B, T = d->T, H = d->H, D = d->dirs, G = lo.G, L = d->L;
     const int BTr = (int)lo.BT;
     const bool mfma = lo.cluster || dep_sweep_use_mfma(H, d->impl);
+    const bool split_fwd = lo.cluster16 && sweep_split_mode();
     int rc;
     for (int l = 0; l < L; ++l) {
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
@@ -212,9 +222,12 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             DEP_CHECK_ARG(wl[0] && wl[1] && wl[2] && wl[3]);
             if (mfma) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
+            if (split_fwd) { rc = dep_pack_cluster16_fwd_split(wl[1], R + lo.wp[l][dd], H, s); if (rc) return rc; }
             if (lo.cluster && d->training) {     // the cluster backward wants its own member-sliced image
+                const bool split_bwd = d->cell == DEP_CELL_GRU && !lo.cluster16_bwd && sweep_split_mode();
                 rc = lo.cluster16_bwd ? dep_pack_cluster16_bwd(wl[1], R + lo.wpT[l][dd], H, s)
-                                  : dep_pack_cluster_bwd(wl[1], R + lo.wpT[l][dd], G, H, s);
+                   : split_bwd ? dep_pack_cluster_bwd_split(wl[1], R + lo.wpT[l][dd], H, s)
+                               : dep_pack_cluster_bwd(wl[1], R + lo.wpT[l][dd], G, H, s);
                 if (rc) return rc;
             }
             const float* bias = wl[2];
@@ -231,6 +244,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         }
         dep_sweep_args a{};
         a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.training = d->training; a.impl = d->impl;
+        a.split = split_fwd ? 1 : 0;
         for (int dd = 0; dd < D; ++dd) {
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             a.w_hh[dd] = wl[1]; a.b_hh[dd] = wl[3]; a.wp[dd] = R + lo.wp[l][dd];
@@ -284,6 +298,8 @@ extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const flo
         float* dgi = W + lo.gi;
         dep_sweep_bwd_args a{};
         a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.impl = d->impl;
+        // must match the image dep_rnn_forward packed: the precision mode may not change between a forward and its backward
+        a.split = (lo.cluster && d->cell == DEP_CELL_GRU && !lo.cluster16_bwd && sweep_split_mode()) ? 1 : 0;
         for (int dd = 0; dd < D; ++dd) {
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             a.w_hh[dd] = wl[1]; a.wpT[dd] = R + lo.wpT[l][dd];

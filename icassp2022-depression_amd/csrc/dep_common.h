@@ -103,6 +103,7 @@ struct dep_sweep_args {
     const float* w_hh[2];    // (G*H, H) row-major
     const float* b_hh[2];    // (G*H)  GRU only (LSTM biases are folded into GI by the GEMM)
     const float* wp[2];      // packed fragment-order copies (MFMA path), see pack kernels
+    int split;               // cluster sweeps: recurrent product on the bf16 matrix cores (3-term split), wp packed to match
     // activations
     const float* gi;         // (B,T,dirs*G*H): input projection incl. bias_ih (LSTM: + bias_hh)
     float* y;  int ldy;      // (B,T,ldy) hidden sequence; direction d writes columns [d*H,(d+1)*H)
@@ -122,6 +123,7 @@ struct dep_sweep_bwd_args {
     int impl;
     const float* w_hh[2];
     const float* wpT[2];     // packed transposed copies (MFMA path)
+    int split;               // GRU cluster sweep: dgates W_hh on the bf16 matrix cores (3-term split), wpT packed to match
     const float* y; int ldy; // forward hidden sequence of this layer (h_{t-1} operand)
     const float* dy; int lddy;           // (B,T,lddy) grad of y (columns [d*H,(d+1)*H) per direction) or NULL
     float drop_p; uint64_t seed; uint32_t site;   // dropout applied to dy on load (p == 0: none)
@@ -156,6 +158,8 @@ size_t dep_cluster_lstm_xbuf_bytes(int H, int B, int dirs);
 int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
 int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
 int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s);
+int dep_pack_cluster16_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
+int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
 int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
 

@@ -49,10 +49,25 @@ struct B16 {
 // =============================================================================== forward
 // matvec roles : lane = (utterance j = lane&15, k-quad q = lane>>4), wave w = K quarter
 // finalise roles: thread = (utterance fj = tid>>4, unit fu = tid&15)  -> 64-byte row segments in every global access
-template <int KCQ>      // k-chunks of 16 per wave = H/64
-__global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
+//
+// SPLIT: the recurrent product h_{t-1} W_hh^T runs on the bf16 matrix cores with the 3-term split of gemm_bf16x3.hip
+// (w_hi h_lo + w_lo h_hi + w_hi h_hi, fp32 accumulate): v_mfma_f32_16x16x32_bf16 covers 32 k per 16 cycles against 4 k
+// per 32 cycles for v_mfma_f32_16x16x4_f32, so a step's 48 fp32 MFMAs (1536 cycles, ~a quarter of the step) become 18
+// (288 cycles).  W_hh stays register-resident as (hi, lo) bf16 planes (same 48 VGPRs); h travels between the members
+// already split -- one 32-bit word (hi << 16 | lo) per value, made once by the thread that owns the value -- and is kept
+// in LDS as two bf16 planes.  Everything elementwise (gates, h, saved state, pooled sum) stays fp32.
+//
+// A fifth wave owns every HBM stream of the member.  One step ahead it fetches the member's slice of the input projection
+// (3 gates x 16 utterances x 16 units per step) into a parity-double-buffered LDS block; one step behind it writes the
+// step's results (h, dropped h, saved r / z / n / hn), which the compute waves only deposit in LDS, with 16-byte stores
+// (and draws the dropout mask once per 4 values).  The four compute waves therefore never have an HBM access outstanding:
+// the s_waitcnt vmcnt(0) in front of the flag publication waits for the payload store alone, and the flag polls / gather
+// loads (VMEM returns in order) never queue behind an HBM load or a write acknowledgement.
+template <int KCQ, bool SPLIT>      // k-chunks of 16 per wave = H/64
+__global__ __launch_bounds__(CT + 64) void gru_fwd_cluster16(F16 p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 16;
+    const int LDHB = H + 8;                           // bf16 elements per row of a split plane (528-byte rows: conflict-free b128 reads)
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
     if (bt * BT >= p.B) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -61,18 +76,34 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
     const int col = c * 16 + fu;
     const int b = bt * BT + fj;
     const bool valid = b < p.B;
-    float* hs = smem;                                 // [16][LDH]
-    float* red = smem + BT * LDH;                     // [4 waves][3 gates][64 lanes][4]
-    volatile int* deadflag = reinterpret_cast<volatile int*>(red + 4 * 3 * 64 * 4);
-    for (int i = tid; i < BT * LDH; i += CT) hs[i] = 0.f;
-    if (tid == 0) *deadflag = 0;
+    float* hs = smem;                                 // [16][LDH] fp32, or (SPLIT) two bf16 planes [16][LDHB]
+    const int hs_floats = SPLIT ? BT * LDHB : BT * LDH;      // 2 planes x 2 bytes == 4 bytes per element
+    unsigned short* hs_hi = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* hs_lo = hs_hi + BT * LDHB;
+    float* red = smem + hs_floats;                    // [4 waves][3 gates][64 lanes][4]
+    float* gbuf = red + 4 * 3 * 64 * 4;               // [2 parities][3 gates][16 utterances][16 units]
+    float* obuf = gbuf + 2 * 768;                     // [2 parities][h, r, z, n, hn][16 utterances][16 units]
+    for (int i = tid; i < hs_floats; i += CT + 64) hs[i] = 0.f;
 
-    f32x4 wr[3][KCQ];
+    constexpr int KS2 = KCQ / 2;                      // 32-wide k-steps per wave (SPLIT)
+    f32x4 wr[SPLIT ? 1 : 3][SPLIT ? 1 : KCQ];
+    u32x4 wq[SPLIT ? 3 : 1][SPLIT ? KS2 : 1][2];      // [gate][k-step][hi, lo]
+    if constexpr (SPLIT) {
+        const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp);
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int k = 0; k < KCQ; ++k)
-            wr[g][k] = p.wp[(size_t)((c * 3 + g) * KC + w * KCQ + k) * 64 + lane];
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    wq[g][ks][pl] = wpq[(size_t)((((c * 3 + g) * 4 + (w & 3)) * KS2 + ks) * 2 + pl) * 64 + lane];
+    } else {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int k = 0; k < KCQ; ++k)
+                wr[g][k] = p.wp[(size_t)((c * 3 + g) * KC + (w & 3) * KCQ + k) * 64 + lane];
+    }
     float bh[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) bh[g] = p.b_hh[g * H + col];
@@ -89,6 +120,45 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * NC, NC, c, p.status);
     if (sx < 0) return;
     const bool fast = sx == 1;
+    if (tid >= CT) {                                  // ---- loader wave
+        const int ll = tid - CT, u = ll >> 2, qd = ll & 3;
+        const int bu = bt * BT + u;
+        const bool uv = bu < p.B;
+        const float* gsrc = p.gi + (size_t)bu * T * p.ldgi + c * 16 + qd * 4;
+        f32x4 v[3];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) v[g] = (uv && t < T) ? ld4(gsrc + (size_t)t * p.ldgi + g * H) : zero4();
+        };
+        auto flush = [&](int t) {                     // results of step t: LDS -> HBM
+            if (!uv) return;
+            const float* ob = obuf + (t & 1) * 1280 + u * 16 + qd * 4;
+            const size_t row = (size_t)bu * T + t;
+            const size_t o = row * p.ldy + c * 16 + qd * 4;
+            const f32x4 h4 = ld4(ob);
+            *reinterpret_cast<f32x4*>(p.y + o) = h4;
+            if (p.ydrop) *reinterpret_cast<f32x4*>(p.ydrop + o) = h4 * dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+            if (p.sv0) {
+                const size_t so = row * H + c * 16 + qd * 4;
+                *reinterpret_cast<f32x4*>(p.sv0 + so) = ld4(ob + 256); *reinterpret_cast<f32x4*>(p.sv1 + so) = ld4(ob + 512);
+                *reinterpret_cast<f32x4*>(p.sv2 + so) = ld4(ob + 768); *reinterpret_cast<f32x4*>(p.sv3 + so) = ld4(ob + 1024);
+            }
+        };
+        issue(1);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            float* gb = gbuf + ((t + 1) & 1) * 768 + u * 16 + qd * 4;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(gb + g * 256) = v[g];       // step t+1, landed
+            if (t > 0) flush(t - 1);
+            issue(t + 2);
+            bar_lds();                                // the compute waves' partial-sum barrier
+            if (t + 1 < T) { __builtin_amdgcn_s_barrier(); bar_lds(); }                       // publish / gather barriers
+        }
+        bar_lds();                                    // the last step's results are in LDS
+        flush(T - 1);
+        return;
+    }
     float gin[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) gin[g] = valid ? p.gi[(size_t)b * T * p.ldgi + g * H + col] : 0.f;
@@ -98,26 +168,40 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)b * T + t;
         DEP_STAMP(0);
-        // next step's input projection: issued here, under the MFMAs, and complete by the drain that precedes the
-        // flag -- a load still in flight during the poll/gather would delay those (VMEM loads return in order)
-        float gnx[3] = {0.f, 0.f, 0.f};
-        if (valid && t + 1 < T) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) gnx[g] = p.gi[(row + 1) * p.ldgi + g * H + col];
-        }
         f32x4 acc[3] = {zero4(), zero4(), zero4()};
-        const float* hrow = hs + j * LDH + w * KCQ * 16 + q * 4;
-        f32x4 hv[KCQ];
+        if constexpr (SPLIT) {
+            // B fragment of k-step ks: lane (utterance j, k-group q) holds h[j][64 w + 32 ks + 8 q .. +7], hi and lo
+            const int ho = j * LDHB + w * KCQ * 16 + q * 8;
+            bf16x8 hh[KS2], hl[KS2];
 #pragma unroll
-        for (int k = 0; k < KCQ; ++k) hv[k] = ld4(hrow + k * 16);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < KS2; ++ks) {
+                hh[ks] = *reinterpret_cast<const bf16x8*>(hs_hi + ho + ks * 32);
+                hl[ks] = *reinterpret_cast<const bf16x8*>(hs_lo + ho + ks * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < KCQ; ++k)
+            for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int g = 0; g < 3; ++g) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[g][ks][0]), wl = __builtin_bit_cast(bf16x8, wq[g][ks][1]);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hl[ks], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, hh[ks], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hh[ks], acc[g], 0, 0, 0);
+                }
+        } else {
+            const float* hrow = hs + j * LDH + w * KCQ * 16 + q * 4;
+            f32x4 hv[KCQ];
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
+            for (int k = 0; k < KCQ; ++k) hv[k] = ld4(hrow + k * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < KCQ; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
+        }
         DEP_STAMP(1);
 #pragma unroll
         for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + ((w * 3 + g) * 64 + lane) * 4) = acc[g];
@@ -140,23 +224,23 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
         const unsigned epoch = (unsigned)t + 1u;
         const size_t pbase = (size_t)(t & 1) * pstride + tile_base;
         const bool more = t + 1 < T;
+        {                                             // results for the streaming wave (written out during step t+1)
+            float* ob = obuf + (t & 1) * 1280 + tid;
+            ob[0] = h; ob[256] = r; ob[512] = z; ob[768] = n; ob[1024] = hn;
+        }
         DEP_STAMP(3);
         if (more) {
             gu32* dst = (gu32*)(p.payload + pbase + (size_t)fj * H + col);
-            if (fast) __hip_atomic_store(dst, __float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_store(dst, __float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned word = __float_as_uint(h);
+            if constexpr (SPLIT) word = split_word(h);        // bf16 hi << 16 | bf16 lo
+            if (fast) __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             DEP_STAMP(4);
             __builtin_amdgcn_s_barrier();
             if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
 #pragma unroll
-            for (int g = 0; g < 3; ++g) gin[g] = gnx[g];      // landed: the drain above waited for it
-        }
-        if (valid) {
-            const size_t o = row * p.ldy + col;
-            p.y[o] = h;
-            if (p.ydrop) p.ydrop[o] = h * dep_dropmask1(p.seed, p.site, o, p.drop_p, p.drop_scale);
-            if (p.sv0) { const size_t so = row * H + col; p.sv0[so] = r; p.sv1[so] = z; p.sv2[so] = n; p.sv3[so] = hn; }
+            for (int g = 0; g < 3; ++g) gin[g] = gbuf[((t + 1) & 1) * 768 + g * 256 + tid];   // written by the loader wave before this step's first barrier
         }
         if (more) {
             // every wave polls the (L2-resident) flags itself: saves the barrier that used to broadcast wave 0's verdict.
@@ -170,14 +254,23 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster16(F16 p) {
             for (int k = 0; k < PER; ++k) {
                 const int i4 = (tid + CT * k) * 4;
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((pbase + i4) * 4), 0, 16 /* sc1 */);
-                f32x4 f;
-                f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
-                *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
+                if constexpr (SPLIT) {                // four (hi << 16 | lo) words -> 8 bytes into each plane
+                    const int o = (i4 >> hshift) * LDHB + (i4 & (H - 1));
+                    uint2 hi2, lo2;
+                    hi2.x = (v.x >> 16) | (v.y & 0xffff0000u); hi2.y = (v.z >> 16) | (v.w & 0xffff0000u);
+                    lo2.x = (v.x & 0xffffu) | (v.y << 16);      lo2.y = (v.z & 0xffffu) | (v.w << 16);
+                    *reinterpret_cast<uint2*>(hs_hi + o) = hi2; *reinterpret_cast<uint2*>(hs_lo + o) = lo2;
+                } else {
+                    f32x4 f;
+                    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+                    *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
+                }
             }
             bar_lds();
             DEP_STAMP(7);
         }
     }
+    bar_lds();                                        // hands the last step's results to the streaming wave
     if (valid) {
         if (p.pooled) p.pooled[(size_t)b * H + col] = pool * p.pool_scale;
         if (p.h_n) p.h_n[(size_t)b * H + col] = hprev;
@@ -330,7 +423,38 @@ __global__ void pack_cluster16_bwd_kernel(const float* __restrict__ W, float* __
     out[idx] = W[(size_t)(g * H + 16 * c + u) * H + jt * 16 + (l & 15)];
 }
 
+// split-precision forward image (see gru_fwd_cluster16<., true>): 16-byte piece
+//   [((((c*3 + g)*4 + w)*KS2 + ks)*2 + plane)*64 + lane]  =  bf16 plane (0 hi, 1 lo) of
+//   W[(g*H + 16c + (lane&15)) * H + 64w + 32ks + 8(lane>>4) + 0..7]          (KS2 = H/128 k-steps of 32 per wave)
+__global__ void pack_cluster16_fwd_split_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int H) {
+    const int KS2 = H / 128;
+    const long n = (long)(H / 16) * 3 * 4 * KS2 * 64;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = idx & 63; long r = idx >> 6;
+    const int ks = r % KS2; r /= KS2;
+    const int w = r % 4; r /= 4;
+    const int g = r % 3; const int c = r / 3;
+    const float* src = W + (size_t)(g * H + 16 * c + (lane & 15)) * H + (H / 4) * w + 32 * ks + 8 * (lane >> 4);
+    u32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned a = split_word(src[2 * e]), b = split_word(src[2 * e + 1]);
+        hi[e] = (a >> 16) | (b & 0xffff0000u);
+        lo[e] = (a & 0xffffu) | (b << 16);
+    }
+    out[(idx - lane) * 2 + lane] = hi;
+    out[(idx - lane) * 2 + 64 + lane] = lo;
+}
+
 }  // namespace
+
+int dep_pack_cluster16_fwd_split(const float* w_hh, float* out, int H, hipStream_t s) {
+    const long n = (long)(H / 16) * 3 * 4 * (H / 128) * 64;
+    hipLaunchKernelGGL(pack_cluster16_fwd_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)out, H);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
 
 // 16-unit members are used when they fit two per CU and the 32-unit clustering would leave CUs sharing nothing:
 bool dep_cluster16_ok(int cell, int H, int B) {
@@ -365,8 +489,9 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
     p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
     if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
-    const size_t lds = (size_t)(BT * (a.H + LPAD) + 4 * 3 * 64 * 4 + 16) * sizeof(float);
-    hipLaunchKernelGGL(gru_fwd_cluster16<4>, dim3(NC * nbtp), dim3(CT), lds, a.stream, p);
+    const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 3 * 64 * 4 + 2 * 768 + 2 * 1280) * sizeof(float);
+    if (a.split) hipLaunchKernelGGL((gru_fwd_cluster16<4, true>), dim3(NC * nbtp), dim3(CT + 64), lds, a.stream, p);
+    else hipLaunchKernelGGL((gru_fwd_cluster16<4, false>), dim3(NC * nbtp), dim3(CT + 64), lds, a.stream, p);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

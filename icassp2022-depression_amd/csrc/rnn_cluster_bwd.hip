@@ -39,10 +39,16 @@ struct StepIn { float2 r, z, n, hn, hp, dy; };
 // Thread -> element map (matches the fragment order of the published partials, so the gather is coalesced):
 //   jl = tid>>7 (which of the member's two 16-column tiles), lp = (tid>>1)&63 (MFMA lane id: row lp&15, quad lp>>4),
 //   half = tid&1 -> columns (2c+jl)*16 + (lp>>4)*4 + 2*half + {0,1} of utterance row lp&15.
-template <int NTW>      // output tiles per wave = H/64
+//
+// SPLIT: dgates W_hh runs on the bf16 matrix cores with the 3-term split (see gru_fwd_cluster16): the member's 96 gate
+// rows are exactly three 32-wide k-steps (r, z, n), 4 tiles x 3 k-steps x 3 products = 36 v_mfma_f32_16x16x32_bf16
+// (576 cycles) replace 96 v_mfma_f32_16x16x4_f32 (3072 cycles, close to half of the step).  The thread that produces a
+// gate gradient splits it once and writes the (hi, lo) bf16 planes the MFMA B fragments are read from.
+template <int NTW, bool SPLIT>      // output tiles per wave = H/64
 __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 96, KCB = KS / 16, LDG = KS + LPAD;
+    constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane (208-byte rows)
     const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
     if (bt * BT >= p.B) return;
@@ -52,14 +58,28 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     const int col = 32 * c + ul;
     const int b = bt * BT + j;
     const bool valid = b < p.B;
-    float* dgs = smem;                                                     // [16][LDG]
+    float* dgs = smem;                                                     // [16][LDG] fp32, or (SPLIT) two bf16 planes [16][LDGB]
+    unsigned short* dg_hi = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* dg_lo = dg_hi + BT * LDGB;
 
-    f32x4 wr[NTW][KCB];
+    f32x4 wr[SPLIT ? 1 : NTW][SPLIT ? 1 : KCB];
+    u32x4 wq[SPLIT ? NTW : 1][SPLIT ? 3 : 1][2];       // [tile][k-step = gate][hi, lo]
+    if constexpr (SPLIT) {
+        const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp);
 #pragma unroll
-    for (int i = 0; i < NTW; ++i)
+        for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int k = 0; k < KCB; ++k)
-            wr[i][k] = p.wp[(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    wq[i][ks][pl] = wpq[(size_t)(((c * NTT + w * NTW + i) * 3 + ks) * 2 + pl) * 64 + lane];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int k = 0; k < KCB; ++k)
+                wr[i][k] = p.wp[(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
+    }
     float2 dhrec = (p.dh_n && valid) ? ld2(p.dh_n + (size_t)b * H + col) : f2(0.f, 0.f);
     float2 dpl = f2(0.f, 0.f);
     if (p.dpooled && valid) { dpl = ld2(p.dpooled + (size_t)b * H + col); dpl.x *= p.pool_scale; dpl.y *= p.pool_scale; }
@@ -103,7 +123,16 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         dr.x = dn.x * hn.x * r.x * (1.0f - r.x); dr.y = dn.y * hn.y * r.y * (1.0f - r.y);
         dnr.x = dn.x * r.x; dnr.y = dn.y * r.y;
         dzt.x = d.x * z.x; dzt.y = d.y * z.y;
-        st2(dgs + j * LDG + ul, dr); st2(dgs + j * LDG + 32 + ul, dz); st2(dgs + j * LDG + 64 + ul, dnr);
+        if constexpr (SPLIT) {                        // one (hi, lo) bf16 pair word per gate: units ul, ul+1
+            unsigned h0, l0, h1, l1, h2, l2;
+            split_pair(dr.x, dr.y, h0, l0); split_pair(dz.x, dz.y, h1, l1); split_pair(dnr.x, dnr.y, h2, l2);
+            const int o = j * LDGB + ul;
+            *reinterpret_cast<unsigned*>(dg_hi + o) = h0; *reinterpret_cast<unsigned*>(dg_lo + o) = l0;
+            *reinterpret_cast<unsigned*>(dg_hi + o + 32) = h1; *reinterpret_cast<unsigned*>(dg_lo + o + 32) = l1;
+            *reinterpret_cast<unsigned*>(dg_hi + o + 64) = h2; *reinterpret_cast<unsigned*>(dg_lo + o + 64) = l2;
+        } else {
+            st2(dgs + j * LDG + ul, dr); st2(dgs + j * LDG + 32 + ul, dz); st2(dgs + j * LDG + 64 + ul, dnr);
+        }
         if (valid) {
             float* g = p.dgi + row * p.lddg;
             st2(g + col, dr); st2(g + H + col, dz); st2(g + 2 * H + col, dn);
@@ -116,18 +145,38 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         f32x4 acc[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; ++i) acc[i] = zero4();
-        const float* drow = dgs + ml * LDG + mq * 4;
-        f32x4 hv[KCB];
+        if constexpr (SPLIT) {
+            const int go = ml * LDGB + mq * 8;        // lane (utterance ml, k-group mq): 8 consecutive k of each k-step
+            bf16x8 gh[3], gl[3];
 #pragma unroll
-        for (int k = 0; k < KCB; ++k) hv[k] = ld4(drow + k * 16);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < 3; ++ks) {
+                gh[ks] = *reinterpret_cast<const bf16x8*>(dg_hi + go + ks * 32);
+                gl[ks] = *reinterpret_cast<const bf16x8*>(dg_lo + go + ks * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < KCB; ++k) {
+            for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int i = 0; i < NTW; ++i) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[i][ks][0]), wl = __builtin_bit_cast(bf16x8, wq[i][ks][1]);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl[ks], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh[ks], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[ks], acc[i], 0, 0, 0);
+                }
+        } else {
+            const float* drow = dgs + ml * LDG + mq * 4;
+            f32x4 hv[KCB];
 #pragma unroll
-                for (int i = 0; i < NTW; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[k][e], acc[i], 0, 0, 0);
+            for (int k = 0; k < KCB; ++k) hv[k] = ld4(drow + k * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < KCB; ++k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[k][e], acc[i], 0, 0, 0);
+            }
         }
         // publish: payload[parity][tile][src c][out tile][lane][4]
         const unsigned epoch = (unsigned)(T - t);
@@ -324,7 +373,36 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
     }
 }
 
+// split-precision backward image (gru_bwd_cluster_r1<., true>): 16-byte piece
+//   [(((c*(H/16) + jt)*3 + ks)*2 + plane)*64 + lane] = bf16 plane (0 hi, 1 lo) of
+//   W[(ks*H + 32c + 8(lane>>4) + e) * H + jt*16 + (lane&15)],  e = 0..7     (k-step ks = gate, 32 units of member c)
+__global__ void pack_cluster_bwd_split_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int H) {
+    const long n = (long)(H / 32) * (H / 16) * 3 * 64;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = idx & 63; long r = idx >> 6;
+    const int ks = r % 3; r /= 3;
+    const int jt = r % (H / 16); const int c = r / (H / 16);
+    const float* src = W + (size_t)(ks * H + 32 * c + 8 * (lane >> 4)) * H + jt * 16 + (lane & 15);
+    u32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned h, l;
+        split_pair(src[(size_t)(2 * e) * H], src[(size_t)(2 * e + 1) * H], h, l);
+        hi[e] = h; lo[e] = l;
+    }
+    out[(idx - lane) * 2 + lane] = hi;
+    out[(idx - lane) * 2 + 64 + lane] = lo;
+}
+
 }  // namespace
+
+int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s) {
+    const long n = (long)(H / 32) * (H / 16) * 3 * 64;
+    hipLaunchKernelGGL(pack_cluster_bwd_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)out, H);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
 
 int dep_launch_cluster_fwd_granule(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
 
@@ -394,13 +472,17 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     const size_t lds = EXCLUSIVE_LDS;
     static bool attr_b = false;
     if (!attr_b) {
-        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_b = true;
     }
     dim3 grid(NC * nbtp);
-    if (a.H == 128) hipLaunchKernelGGL(gru_bwd_cluster_r1<2>, grid, dim3(CT), lds, a.stream, p);
-    else hipLaunchKernelGGL(gru_bwd_cluster_r1<4>, grid, dim3(CT), lds, a.stream, p);
+    if (a.H == 128) { if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<2, true>), grid, dim3(CT), lds, a.stream, p);
+                      else hipLaunchKernelGGL((gru_bwd_cluster_r1<2, false>), grid, dim3(CT), lds, a.stream, p); }
+    else            { if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true>), grid, dim3(CT), lds, a.stream, p);
+                      else hipLaunchKernelGGL((gru_bwd_cluster_r1<4, false>), grid, dim3(CT), lds, a.stream, p); }
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

@@ -48,6 +48,28 @@ __device__ __forceinline__ void bar_lds() {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
+// 3-term bf16 split of one fp32 value for the split-precision sweeps: bf16(x) << 16 | bf16(x - bf16(x))
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned split_word(float x) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+    const f2v v = {x, 0.f};
+    const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2v)) & 0xffffu;
+    const f2v d = {x - __uint_as_float(hi << 16), 0.f};
+    const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(d, b2v)) & 0xffffu;
+    return (hi << 16) | lo;
+}
+
+// two adjacent values -> packed bf16 pairs: hi = (bf16(x1) << 16 | bf16(x0)), lo likewise for the residuals
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+    const f2v v = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2v));
+    const f2v d = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(d, b2v));
+}
+
 // Same-XCD fast path.  Correctness never depends on placement: every member announces the XCD it runs on through the
 // placement-independent protocol (sc1 store / sc1 polls); only if ALL members of the cluster report the same XCD do the
 // per-step payload and flag stores drop the write-through bit -- that XCD's L2 is then the coherence point for writers
