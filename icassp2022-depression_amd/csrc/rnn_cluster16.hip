@@ -14,7 +14,9 @@
 namespace {
 using namespace depc;
 
-#define DEP_STAMP(slot) do { if (tr && t >= 100 && t < 104) tr[(t - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+// debug stamps go to LDS and are copied out after the sweep: a global store per stamp would sit in vmcnt and distort the
+// very waits being measured
+#define DEP_STAMP(slot) do { if (tr && t >= 100 && t < 104) trl[(t - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 struct F16 {
     int B, T, H, nbtp;
@@ -64,7 +66,10 @@ struct B16 {
 // the s_waitcnt vmcnt(0) in front of the flag publication waits for the payload store alone, and the flag polls / gather
 // loads (VMEM returns in order) never queue behind an HBM load or a write acknowledgement.
 template <int KCQ, bool SPLIT>      // k-chunks of 16 per wave = H/64
-__global__ __launch_bounds__(CT + 64) void gru_fwd_cluster16(F16 p) {
+// launch bounds: two 5-wave workgroups must fit on a CU wherever their wave rotations start, i.e. 4 waves on one SIMD:
+// <= 128 VGPRs.  (At 136 the second workgroup of a CU could not always be placed, part of the cluster members never became
+// resident and every step ran into the spin limit: 395 ms instead of 2.)
+__global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 16;
     const int LDHB = H + 8;                           // bf16 elements per row of a split plane (528-byte rows: conflict-free b128 reads)
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(CT + 64) void gru_fwd_cluster16(F16 p) {
     __syncthreads();
 
     long long* tr = (p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
+    long long* trl = reinterpret_cast<long long*>(obuf + 2 * 1280);
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)b * T + t;
         DEP_STAMP(0);
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(CT + 64) void gru_fwd_cluster16(F16 p) {
         }
     }
     bar_lds();                                        // hands the last step's results to the streaming wave
+    if (tr) for (int i = 0; i < 32; ++i) tr[i] = trl[i];
     if (valid) {
         if (p.pooled) p.pooled[(size_t)b * H + col] = pool * p.pool_scale;
         if (p.h_n) p.h_n[(size_t)b * H + col] = hprev;
@@ -489,7 +496,7 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
     p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
     if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
-    const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 3 * 64 * 4 + 2 * 768 + 2 * 1280) * sizeof(float);
+    const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 3 * 64 * 4 + 2 * 768 + 2 * 1280 + 64) * sizeof(float);
     if (a.split) hipLaunchKernelGGL((gru_fwd_cluster16<4, true>), dim3(NC * nbtp), dim3(CT + 64), lds, a.stream, p);
     else hipLaunchKernelGGL((gru_fwd_cluster16<4, false>), dim3(NC * nbtp), dim3(CT + 64), lds, a.stream, p);
     DEP_CHECK_LAUNCH();

@@ -53,6 +53,7 @@ def main():
         e[0].record(); fwd(i + 1); e[1].record(); bwd(); e[2].record()
         torch.cuda.synchronize()
         tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
+    rnn.check()          # raises if a cluster sweep gave up waiting for a member
     print(f'{cell} B={B} T={T} F={F} H={H}: fwd {tf / steps:.3f} ms  bwd {tb / steps:.3f} ms  '
           f'total {(tf + tb) / steps:.3f} ms  -> {B / ((tf + tb) / steps) * 1e3:.0f} utt/s (rnn only)')
 
