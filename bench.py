@@ -6,9 +6,11 @@ AdamW, dropout on) of the audio GRU-256 x2 classifier on synthetic (B,T,F) = (51
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload audio_gru|text_bilstm]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the persistent GRU sweep): algorithmic
-flops per launch / its mean launch duration measured with HIP events on the launch stream during the timed
-region, against the dense fp32-MFMA peak.  `cpu_baseline` (N=1 only) times the same train step on the host
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the persistent recurrent sweep with the largest
+total time): its algorithmic bytes and flops per launch over its mean launch duration, measured
+with HIP events on the launch stream during the timed region, against the HBM peak and against the peak of the matrix
+pipe the sweep runs on (fp32 MFMA in exact mode; the bf16 pipe / 3 for the 3-term split).  The roof the kernel sits
+closer to is reported as `bound`; both fractions are kept in the object.  `cpu_baseline` (N=1 only) times the same train step on the host
 cores with stock torch.nn (oracle/torch_cpu_baseline.py, validated against the reference's fixtures).
 """
 import argparse
@@ -23,6 +25,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6    # dense bf16 MFMA peak (no sparsity)
+PEAK_HBM_GBS = 8000.0             # HBM3E peak
 WORKLOADS = {
     # name: (module, class, B per GPU, T, F, H)
     'audio_gru': ('audio_gru_whole', 'AudioBiLSTM', 512, 300, 256, 256),
@@ -115,7 +119,18 @@ def main():
     sweeps = {k: v for k, v in cats.items() if 'sweep' in k}
     dom = max(sweeps, key=lambda k: sweeps[k][0])
     dom_ms = sweeps[dom][0] / sweeps[dom][1]
-    achieved = sweep_flops / (dom_ms * 1e-3) / 1e12
+    # algorithmic HBM bytes per (utterance, time step) of one sweep launch, averaged over the two layers:
+    #   GRU fwd : gi 12H + y 4H + saved r,z,n,hn 16H + dropped y 4H (layer 0 only)          = 34H
+    #   GRU bwd : saved 16H + h_{t-1} 4H + dy 4H (layer 0 only) + dgi 12H + dghn 4H         = 38H
+    #   LSTM fwd: (gi 16H + y 4H + gates 16H + c 4H) x 2 dirs + dropped y 8H (layer 0 only) = 84H
+    #   LSTM bwd: (gates 16H + c_t 4H + c_{t-1} 4H + dy 4H + dgi 16H) x 2 dirs              = 88H
+    per_ut = {'gru_fwd_sweep': 34 * H, 'gru_bwd_sweep': 38 * H, 'lstm_fwd_sweep': 84 * H, 'lstm_bwd_sweep': 88 * H}[dom]
+    sweep_bytes = float(per_ut) * B * T
+    split = L.get_gemm_mode() == 1 and (args.workload == 'audio_gru')       # the GRU cluster sweeps follow the GEMM mode
+    mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+    tflops = sweep_flops / (dom_ms * 1e-3) / 1e12
+    gbs = sweep_bytes / (dom_ms * 1e-3) / 1e9
+    frac_mfma, frac_hbm = tflops / mfma_peak, gbs / PEAK_HBM_GBS
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tpath):
@@ -123,13 +138,19 @@ def main():
             traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
         except Exception:
             traffic = None
-    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
-                'flops_per_launch': sweep_flops, 'avg_launch_ms': round(dom_ms, 4),
-                'kernels_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in cats.items()}}
+    if frac_hbm >= frac_mfma:
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': round(frac_hbm, 4), 'traffic': traffic}
+    else:
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tflops, 3), 'peak': round(mfma_peak, 1),
+                    'unit': 'TFLOP/s', 'frac': round(frac_mfma, 4), 'traffic': traffic}
+    roofline.update({'bytes_per_launch': sweep_bytes, 'flops_per_launch': sweep_flops, 'avg_launch_ms': round(dom_ms, 4),
+                     'frac_hbm': round(frac_hbm, 4), 'frac_mfma': round(frac_mfma, 4),
+                     'mfma_pipe': 'bf16 x3 split' if split else 'fp32',
+                     'kernels_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in cats.items()}})
     train_flops_per_utt = 1.4156e9 if args.workload == 'audio_gru' else 2.831e9
     step_tflops = train_flops_per_utt * value / 1e12 / world
-    roofline['step_mfma_frac'] = round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)
+    roofline['step_tflops_fp32_equiv'] = round(step_tflops, 2)
 
     out = {'metric': 'utterances/sec (train step) for GRU-256 on (B,T,F)=(512,300,256)' if args.workload == 'audio_gru'
            else 'utterances/sec (train step) for BiLSTM-128x2 on (B,T,F)=(512,300,1024)',

@@ -137,6 +137,11 @@ def set_gemm_mode(mode, min_macs=-1):
     check(load().dep_set_gemm_mode(int(mode), int(min_macs)), 'dep_set_gemm_mode')
 
 
+def get_gemm_mode():
+    """0 = exact fp32 MFMA everywhere, 1 = 3-term bf16 split for the large contractions and the GRU cluster sweeps."""
+    return int(load().dep_get_gemm_mode())
+
+
 def gemm_ws(transA, transB, M, N, K, device):
     n = load().dep_gemm_workspace_bytes(transA, transB, M, N, K)
     return torch.empty(max(n, 16) // 4, dtype=torch.float32, device=device)
