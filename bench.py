@@ -126,7 +126,7 @@ def main():
     #   LSTM bwd: (gates 16H + c_t 4H + c_{t-1} 4H + dy 4H + dgi 16H) x 2 dirs              = 88H
     per_ut = {'gru_fwd_sweep': 34 * H, 'gru_bwd_sweep': 38 * H, 'lstm_fwd_sweep': 84 * H, 'lstm_bwd_sweep': 88 * H}[dom]
     sweep_bytes = float(per_ut) * B * T
-    split = L.get_gemm_mode() == 1 and (args.workload == 'audio_gru')       # the GRU cluster sweeps follow the GEMM mode
+    split = L.get_gemm_mode() == 1                           # the cluster sweeps follow the GEMM precision mode
     mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
     tflops = sweep_flops / (dom_ms * 1e-3) / 1e12
     gbs = sweep_bytes / (dom_ms * 1e-3) / 1e9

@@ -213,6 +213,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     const int BTr = (int)lo.BT;
     const bool mfma = lo.cluster || dep_sweep_use_mfma(H, d->impl);
     const bool split_fwd = lo.cluster16 && sweep_split_mode();
+    const bool split_lstm = lo.cluster && d->cell == DEP_CELL_LSTM && sweep_split_mode();
     int rc;
     for (int l = 0; l < L; ++l) {
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
@@ -221,14 +222,20 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         for (int dd = 0; dd < D; ++dd) {
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             DEP_CHECK_ARG(wl[0] && wl[1] && wl[2] && wl[3]);
-            if (mfma) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
-            if (split_fwd) { rc = dep_pack_cluster16_fwd_split(wl[1], R + lo.wp[l][dd], H, s); if (rc) return rc; }
-            if (lo.cluster && d->training) {     // the cluster backward wants its own member-sliced image
-                const bool split_bwd = d->cell == DEP_CELL_GRU && !lo.cluster16_bwd && sweep_split_mode();
-                rc = lo.cluster16_bwd ? dep_pack_cluster16_bwd(wl[1], R + lo.wpT[l][dd], H, s)
-                   : split_bwd ? dep_pack_cluster_bwd_split(wl[1], R + lo.wpT[l][dd], H, s)
-                               : dep_pack_cluster_bwd(wl[1], R + lo.wpT[l][dd], G, H, s);
+            // recurrent weight images in MFMA fragment order (precision / clustering decide the format)
+            if (split_lstm) {
+                rc = dep_pack_cluster_lstm_split(wl[1], R + lo.wp[l][dd], d->training ? R + lo.wpT[l][dd] : nullptr, H, s);
                 if (rc) return rc;
+            } else {
+                if (mfma) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
+                if (split_fwd) { rc = dep_pack_cluster16_fwd_split(wl[1], R + lo.wp[l][dd], H, s); if (rc) return rc; }
+                if (lo.cluster && d->training) {     // the cluster backward wants its own member-sliced image
+                    const bool split_bwd = d->cell == DEP_CELL_GRU && !lo.cluster16_bwd && sweep_split_mode();
+                    rc = lo.cluster16_bwd ? dep_pack_cluster16_bwd(wl[1], R + lo.wpT[l][dd], H, s)
+                       : split_bwd ? dep_pack_cluster_bwd_split(wl[1], R + lo.wpT[l][dd], H, s)
+                                   : dep_pack_cluster_bwd(wl[1], R + lo.wpT[l][dd], G, H, s);
+                    if (rc) return rc;
+                }
             }
             const float* bias = wl[2];
             if (d->cell == DEP_CELL_LSTM) {          // both biases fold into the projection
@@ -244,7 +251,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         }
         dep_sweep_args a{};
         a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.training = d->training; a.impl = d->impl;
-        a.split = split_fwd ? 1 : 0;
+        a.split = (split_fwd || split_lstm) ? 1 : 0;
         for (int dd = 0; dd < D; ++dd) {
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             a.w_hh[dd] = wl[1]; a.b_hh[dd] = wl[3]; a.wp[dd] = R + lo.wp[l][dd];
@@ -299,7 +306,7 @@ extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const flo
         dep_sweep_bwd_args a{};
         a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.impl = d->impl;
         // must match the image dep_rnn_forward packed: the precision mode may not change between a forward and its backward
-        a.split = (lo.cluster && d->cell == DEP_CELL_GRU && !lo.cluster16_bwd && sweep_split_mode()) ? 1 : 0;
+        a.split = (lo.cluster && !lo.cluster16_bwd && sweep_split_mode()) ? 1 : 0;
         for (int dd = 0; dd < D; ++dd) {
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             a.w_hh[dd] = wl[1]; a.wpT[dd] = R + lo.wpT[l][dd];

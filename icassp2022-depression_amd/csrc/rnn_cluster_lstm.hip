@@ -37,10 +37,14 @@ struct LB {
 
 // block id = (dir*NC + c)*nbtp + bt  (nbtp a multiple of 8: all members of a cluster share blockIdx % 8)
 // =============================================================================== forward
-template <int KCH>      // k-chunks of 16 per wave = H/32
+// SPLIT: recurrent products on the bf16 matrix cores with the 3-term split, as in the GRU sweeps (rnn_cluster16.hip):
+// 24 v_mfma_f32_16x16x32_bf16 per wave and step instead of 64 v_mfma_f32_16x16x4_f32 (384 vs 2048 cycles); h travels
+// as (bf16 hi << 16 | bf16 lo) words and lives in LDS as two bf16 planes; gates, c and h themselves stay fp32.
+template <int KCH, bool SPLIT>      // k-chunks of 16 per wave = H/32
 __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
+    const int LDHB = H + 8;                           // bf16 elements per row of a split plane
     const int bt = blockIdx.x % p.nbtp, dc = blockIdx.x / p.nbtp, c = dc % NC, dir = dc / NC;
     if (bt * BT >= p.B) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -48,16 +52,32 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
     const int jt = c * 2 + jl;
     const int b = bt * BT + j;
     const bool valid = b < p.B;
-    float* hs = smem;                                 // [16][LDH]
-    float* red = smem + BT * LDH;                     // [4 waves][4 gates][64][4]
-    for (int i = tid; i < BT * LDH; i += CT) hs[i] = 0.f;
+    float* hs = smem;                                 // [16][LDH] fp32, or (SPLIT) two bf16 planes [16][LDHB]
+    const int hs_floats = SPLIT ? BT * LDHB : BT * LDH;
+    unsigned short* hs_hi = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* hs_lo = hs_hi + BT * LDHB;
+    float* red = smem + hs_floats;                    // [4 waves][4 gates][64][4]
+    for (int i = tid; i < hs_floats; i += CT) hs[i] = 0.f;
 
-    f32x4 wr[4][KCH];
+    constexpr int KS2 = KCH / 2;                      // 32-wide k-steps per wave (SPLIT)
+    f32x4 wr[SPLIT ? 1 : 4][SPLIT ? 1 : KCH];
+    u32x4 wq[SPLIT ? 4 : 1][SPLIT ? KS2 : 1][2];      // [gate][k-step][hi, lo]
+    if constexpr (SPLIT) {
+        const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp[dir]);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int k = 0; k < KCH; ++k)
-            wr[g][k] = p.wp[dir][(size_t)((jt * 4 + g) * KC + kh * KCH + k) * 64 + lane];
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    wq[g][ks][pl] = wpq[(size_t)((((jt * 4 + g) * 2 + kh) * KS2 + ks) * 2 + pl) * 64 + lane];
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < KCH; ++k)
+                wr[g][k] = p.wp[dir][(size_t)((jt * 4 + g) * KC + kh * KCH + k) * 64 + lane];
+    }
     const int col = jt * 16 + q * 4 + 2 * kh;
     float2 cst = f2(0.f, 0.f), hlast = f2(0.f, 0.f);
     const int cl = dir * p.nbtp + bt;                 // cluster index
@@ -93,18 +113,38 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
             for (int g = 0; g < 4; ++g) gin[g] = ld2(p.gi + rown * p.ldgi + dir * 4 * H + g * H + col);
         }
         f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-        const float* hrow = hs + j * LDH + kh * KCH * 16 + q * 4;
-        f32x4 hv[KCH];
+        if constexpr (SPLIT) {
+            const int ho = j * LDHB + kh * KCH * 16 + q * 8;
+            bf16x8 hh[KS2], hl[KS2];
 #pragma unroll
-        for (int k = 0; k < KCH; ++k) hv[k] = ld4(hrow + k * 16);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < KS2; ++ks) {
+                hh[ks] = *reinterpret_cast<const bf16x8*>(hs_hi + ho + ks * 32);
+                hl[ks] = *reinterpret_cast<const bf16x8*>(hs_lo + ho + ks * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < KCH; ++k)
+            for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int g = 0; g < 4; ++g) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[g][ks][0]), wl = __builtin_bit_cast(bf16x8, wq[g][ks][1]);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hl[ks], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, hh[ks], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hh[ks], acc[g], 0, 0, 0);
+                }
+        } else {
+            const float* hrow = hs + j * LDH + kh * KCH * 16 + q * 4;
+            f32x4 hv[KCH];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
+            for (int k = 0; k < KCH; ++k) hv[k] = ld4(hrow + k * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < KCH; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(red + ((w * 4 + g) * 64 + lane) * 4) = acc[g];
         bar_lds();
@@ -126,7 +166,8 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
         const unsigned epoch = (unsigned)s + 1u;
         const size_t pbase = (size_t)(s & 1) * pstride + tile_base;
         if (more) {
-            const u64 bits = (u64)__float_as_uint(h.x) | ((u64)__float_as_uint(h.y) << 32);
+            const u64 bits = SPLIT ? ((u64)split_word(h.x) | ((u64)split_word(h.y) << 32))
+                                   : ((u64)__float_as_uint(h.x) | ((u64)__float_as_uint(h.y) << 32));
             gu64* dst = (gu64*)(p.payload + pbase + (size_t)j * H + col);
             if (fast) __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -154,9 +195,17 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
             for (int k = 0; k < PER; ++k) {
                 const int i4 = (tid + CT * k) * 4;
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((pbase + i4) * 4), 0, 16 /* sc1 */);
-                f32x4 f;
-                f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
-                *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
+                if constexpr (SPLIT) {
+                    const int o = (i4 >> hshift) * LDHB + (i4 & (H - 1));
+                    uint2 hi2, lo2;
+                    hi2.x = (v.x >> 16) | (v.y & 0xffff0000u); hi2.y = (v.z >> 16) | (v.w & 0xffff0000u);
+                    lo2.x = (v.x & 0xffffu) | (v.y << 16);      lo2.y = (v.z & 0xffffu) | (v.w << 16);
+                    *reinterpret_cast<uint2*>(hs_hi + o) = hi2; *reinterpret_cast<uint2*>(hs_lo + o) = lo2;
+                } else {
+                    f32x4 f;
+                    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+                    *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
+                }
             }
             bar_lds();
         }
@@ -167,10 +216,11 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
 // =============================================================================== backward
 struct StepIn { float2 ig, fg, gg, og, ct, cp, dy; };
 
-template <int NTW>      // output tiles per wave = H/64
+template <int NTW, bool SPLIT>      // output tiles per wave = H/64
 __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 128, KCB = KS / 16, LDG = KS + LPAD;
+    constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane
     const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
     const int bt = blockIdx.x % p.nbtp, dc = blockIdx.x / p.nbtp, c = dc % NC, dir = dc / NC;
     if (bt * BT >= p.B) return;
@@ -180,14 +230,28 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
     const int col = 32 * c + ul;
     const int b = bt * BT + j;
     const bool valid = b < p.B;
-    float* dgs = smem;                                // [16][LDG]
+    float* dgs = smem;                                // [16][LDG] fp32, or (SPLIT) two bf16 planes [16][LDGB]
+    unsigned short* dg_hi = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* dg_lo = dg_hi + BT * LDGB;
 
-    f32x4 wr[NTW][KCB];
+    f32x4 wr[SPLIT ? 1 : NTW][SPLIT ? 1 : KCB];
+    u32x4 wq[SPLIT ? NTW : 1][SPLIT ? 4 : 1][2];      // [tile][k-step = gate][hi, lo]
+    if constexpr (SPLIT) {
+        const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp[dir]);
 #pragma unroll
-    for (int i = 0; i < NTW; ++i)
+        for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int k = 0; k < KCB; ++k)
-            wr[i][k] = p.wp[dir][(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    wq[i][ks][pl] = wpq[(size_t)(((c * NTT + w * NTW + i) * 4 + ks) * 2 + pl) * 64 + lane];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int k = 0; k < KCB; ++k)
+                wr[i][k] = p.wp[dir][(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
+    }
     float2 dhrec = (p.dh_n && valid) ? ld2(p.dh_n + ((size_t)dir * p.B + b) * H + col) : f2(0.f, 0.f);
     float2 dcrec = f2(0.f, 0.f);
     float2 db[4] = {f2(0.f, 0.f), f2(0.f, 0.f), f2(0.f, 0.f), f2(0.f, 0.f)};
@@ -237,8 +301,19 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
         dfg.x = dct.x * cp.x * fg.x * (1.0f - fg.x); dfg.y = dct.y * cp.y * fg.y * (1.0f - fg.y);
         dgg.x = dct.x * ig.x * (1.0f - gg.x * gg.x); dgg.y = dct.y * ig.y * (1.0f - gg.y * gg.y);
         dcrec.x = dct.x * fg.x; dcrec.y = dct.y * fg.y;
-        float* dl = dgs + j * LDG + ul;
-        st2(dl, dig); st2(dl + 32, dfg); st2(dl + 64, dgg); st2(dl + 96, dog);
+        if constexpr (SPLIT) {
+            unsigned hh[4], ll[4];
+            split_pair(dig.x, dig.y, hh[0], ll[0]); split_pair(dfg.x, dfg.y, hh[1], ll[1]);
+            split_pair(dgg.x, dgg.y, hh[2], ll[2]); split_pair(dog.x, dog.y, hh[3], ll[3]);
+            const int o = j * LDGB + ul;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<unsigned*>(dg_hi + o + 32 * g) = hh[g]; *reinterpret_cast<unsigned*>(dg_lo + o + 32 * g) = ll[g];
+            }
+        } else {
+            float* dl = dgs + j * LDG + ul;
+            st2(dl, dig); st2(dl + 32, dfg); st2(dl + 64, dgg); st2(dl + 96, dog);
+        }
         if (valid) {
             float* g = p.dgi + row * p.lddg + dir * 4 * H + col;
             st2(g, dig); st2(g + H, dfg); st2(g + 2 * H, dgg); st2(g + 3 * H, dog);
@@ -251,18 +326,38 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
         f32x4 acc[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; ++i) acc[i] = zero4();
-        const float* drow = dgs + ml * LDG + mq * 4;
-        f32x4 hv[KCB];
+        if constexpr (SPLIT) {
+            const int go = ml * LDGB + mq * 8;
+            bf16x8 gh[4], gl[4];
 #pragma unroll
-        for (int k = 0; k < KCB; ++k) hv[k] = ld4(drow + k * 16);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < 4; ++ks) {
+                gh[ks] = *reinterpret_cast<const bf16x8*>(dg_hi + go + ks * 32);
+                gl[ks] = *reinterpret_cast<const bf16x8*>(dg_lo + go + ks * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < KCB; ++k)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int i = 0; i < NTW; ++i) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[i][ks][0]), wl = __builtin_bit_cast(bf16x8, wq[i][ks][1]);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl[ks], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh[ks], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh[ks], acc[i], 0, 0, 0);
+                }
+        } else {
+            const float* drow = dgs + ml * LDG + mq * 4;
+            f32x4 hv[KCB];
 #pragma unroll
-                for (int i = 0; i < NTW; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[k][e], acc[i], 0, 0, 0);
+            for (int k = 0; k < KCB; ++k) hv[k] = ld4(drow + k * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < KCB; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[k][e], acc[i], 0, 0, 0);
+        }
         const unsigned epoch = (unsigned)(T - s);
         const size_t pbase = (size_t)(s & 1) * pstride + tile_base;
 #pragma unroll
@@ -299,7 +394,45 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
     }
 }
 
+// split-precision weight images (16-byte pieces of 8 bf16):
+//   forward : [((((jt*4 + g)*2 + kh)*KS2 + ks)*2 + plane)*64 + lane] = W[(g*H + jt*16 + (lane&15))*H + kh*(H/2) + 32ks + 8(lane>>4) + 0..7]
+//   backward: [(((c*(H/16) + jt)*4 + ks)*2 + plane)*64 + lane]        = W[(ks*H + 32c + 8(lane>>4) + e)*H + jt*16 + (lane&15)], e = 0..7
+__global__ void pack_lstm_split_kernel(const float* __restrict__ W, u32x4* __restrict__ fwd, u32x4* __restrict__ bwd, int H) {
+    const int KS2 = H / 64;
+    const long n = (long)(H / 16) * 4 * 2 * KS2 * 64;          // == (H/32) * (H/16) * 4 * 64 pieces in either image
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = idx & 63;
+    u32x4 hi, lo;
+    {
+        long r = idx >> 6;
+        const int ks = r % KS2; r /= KS2;
+        const int kh = r % 2; r /= 2;
+        const int g = r % 4; const int jt = r / 4;
+        const float* src = W + (size_t)(g * H + jt * 16 + (lane & 15)) * H + kh * (H / 2) + 32 * ks + 8 * (lane >> 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsigned h, l; split_pair(src[2 * e], src[2 * e + 1], h, l); hi[e] = h; lo[e] = l; }
+        fwd[(idx - lane) * 2 + lane] = hi; fwd[(idx - lane) * 2 + 64 + lane] = lo;
+    }
+    if (bwd) {
+        long r = idx >> 6;
+        const int ks = r % 4; r /= 4;
+        const int jt = r % (H / 16); const int c = r / (H / 16);
+        const float* src = W + (size_t)(ks * H + 32 * c + 8 * (lane >> 4)) * H + jt * 16 + (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsigned h, l; split_pair(src[(size_t)(2 * e) * H], src[(size_t)(2 * e + 1) * H], h, l); hi[e] = h; lo[e] = l; }
+        bwd[(idx - lane) * 2 + lane] = hi; bwd[(idx - lane) * 2 + 64 + lane] = lo;
+    }
+}
+
 }  // namespace
+
+int dep_pack_cluster_lstm_split(const float* w_hh, float* wp, float* wpT, int H, hipStream_t s) {
+    const long n = (long)(H / 16) * 4 * 2 * (H / 64) * 64;
+    hipLaunchKernelGGL(pack_lstm_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)wp, (u32x4*)wpT, H);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
 
 bool dep_cluster_lstm_ok(int H, int B, int dirs) {
     static int off = -1;
@@ -330,8 +463,9 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_LSTM_FWD, a.stream);
-    const size_t lds = (size_t)(BT * (a.H + LPAD) + 4 * 4 * 64 * 4) * sizeof(float);
-    hipLaunchKernelGGL(lstm_fwd_cluster<4>, dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
+    const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 4 * 64 * 4) * sizeof(float);
+    if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true>), dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
+    else hipLaunchKernelGGL((lstm_fwd_cluster<4, false>), dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -353,8 +487,9 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_LSTM_BWD, a.stream);
-    const size_t lds = (size_t)(BT * (128 + LPAD)) * sizeof(float);
-    hipLaunchKernelGGL(lstm_bwd_cluster<2>, dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
+    const size_t lds = (size_t)(BT * (128 + 8)) * sizeof(float);
+    if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true>), dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
+    else hipLaunchKernelGGL((lstm_bwd_cluster<2, false>), dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

@@ -17,7 +17,7 @@ for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
             if r.get('Counter_Name') != ctr: continue
-            k = r['Kernel_Name'].split('(')[0][-60:]
+            k = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:60]
             acc[k][0] += float(r['Counter_Value']); acc[k][1] += 1
         for k, (v, n) in acc.items():
             res[k][ctr] = v / n; res[k]['launches'] = n
