@@ -19,7 +19,7 @@ using namespace depc;
 #define DEP_STAMP(slot) do { if (tr && t >= 100 && t < 104) trl[(t - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 struct F16 {
-    int B, T, H, nbtp;
+    int B, T, H, nbtp, b0;      // b0: first utterance of this launch's batch chunk (B is the whole batch)
     const f32x4* wp; const float* b_hh;
     const float* gi; int ldgi;
     float* y; int ldy;
@@ -33,7 +33,7 @@ struct F16 {
 };
 
 struct B16 {
-    int B, T, H, nbtp;
+    int B, T, H, nbtp, b0;
     const f32x4* wp;
     const float* y; int ldy;
     const float* dy; int lddy;
@@ -74,12 +74,12 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 16;
     const int LDHB = H + 8;                           // bf16 elements per row of a split plane (528-byte rows: conflict-free b128 reads)
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
-    if (bt * BT >= p.B) return;
+    if (p.b0 + bt * BT >= p.B) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int fj = tid >> 4, fu = tid & 15;
     const int col = c * 16 + fu;
-    const int b = bt * BT + fj;
+    const int b = p.b0 + bt * BT + fj;
     const bool valid = b < p.B;
     float* hs = smem;                                 // [16][LDH] fp32, or (SPLIT) two bf16 planes [16][LDHB]
     const int hs_floats = SPLIT ? BT * LDHB : BT * LDH;      // 2 planes x 2 bytes == 4 bytes per element
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
     const bool fast = sx == 1;
     if (tid >= CT) {                                  // ---- loader wave
         const int ll = tid - CT, u = ll >> 2, qd = ll & 3;
-        const int bu = bt * BT + u;
+        const int bu = p.b0 + bt * BT + u;
         const bool uv = bu < p.B;
         const float* gsrc = p.gi + (size_t)bu * T * p.ldgi + c * 16 + qd * 4;
         f32x4 v[3];
@@ -293,11 +293,11 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster16(B16 p) {
     constexpr int KS = 48, KCB = KS / 16, LDG = KS + LPAD;
     const int H = p.H, T = p.T, NC = H / 16, NTT = H / 16;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
-    if (bt * BT >= p.B) return;
+    if (p.b0 + bt * BT >= p.B) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fj = tid >> 4, fu = tid & 15;
     const int col = 16 * c + fu;
-    const int b = bt * BT + fj;
+    const int b = p.b0 + bt * BT + fj;
     const bool valid = b < p.B;
     float* dgs = smem;                                // [16][LDG]
 
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster16(B16 p) {
     if (tid < 64) {
         const int k = tid >> 4, u = tid & 15;
         const float s = smem[(0 * 4 + k) * 16 + u] + smem[(1 * 4 + k) * 16 + u] + smem[(2 * 4 + k) * 16 + u] + smem[(3 * 4 + k) * 16 + u];
-        p.dbpart[(size_t)bt * 4 * H + k * H + 16 * c + u] = s;
+        p.dbpart[(size_t)(p.b0 / BT + bt) * 4 * H + k * H + 16 * c + u] = s;
     }
 }
 
@@ -468,8 +468,8 @@ bool dep_cluster16_ok(int cell, int H, int B) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("DEP_CLUSTER16"); off = (e && e[0] == '0') ? 1 : 0; }
     if (off || cell != DEP_CELL_GRU || H != 256) return false;
-    const int nbtp = (dep_cdiv(B, BT) + 7) / 8 * 8;
-    return (H / 16) * nbtp <= 512;
+    (void)B;                                          // any batch: launches cover chunks of at most 512 utterances
+    return true;
 }
 
 int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s) {
@@ -480,33 +480,41 @@ int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s) 
 }
 
 int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
-    const int NC = a.H / 16, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    // co-residency bounds a launch to 512 workgroups = 32 tiles = 512 utterances; larger batches run chunk after chunk
+    const int NC = a.H / 16, CH = 512;
+    const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     F16 p{};
-    p.B = a.B; p.T = a.T; p.H = a.H; p.nbtp = nbtp;
+    p.B = a.B; p.T = a.T; p.H = a.H;
     p.wp = (const f32x4*)a.wp[0]; p.b_hh = a.b_hh[0];
     p.gi = a.gi; p.ldgi = 3 * a.H; p.y = a.y; p.ldy = a.ldy;
     p.ydrop = (a.drop_p > 0.f) ? a.ydrop : nullptr;
     p.drop_p = a.drop_p; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f; p.seed = a.seed; p.site = a.site;
     p.pooled = a.pooled; p.pool_scale = a.pool_scale; p.h_n = a.h_n;
     p.sv0 = a.training ? a.sv0 : nullptr; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
-    const size_t pay = (size_t)2 * nbtp * BT * a.H * sizeof(float);
-    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC <= 512);
+    const size_t pay = (size_t)2 * nbtp_max * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 512);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
-    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
     const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 3 * 64 * 4 + 2 * 768 + 2 * 1280 + 64) * sizeof(float);
-    if (a.split) hipLaunchKernelGGL((gru_fwd_cluster16<4, true>), dim3(NC * nbtp), dim3(CT + 64), lds, a.stream, p);
-    else hipLaunchKernelGGL((gru_fwd_cluster16<4, false>), dim3(NC * nbtp), dim3(CT + 64), lds, a.stream, p);
-    DEP_CHECK_LAUNCH();
+    for (int b0 = 0; b0 < a.B; b0 += CH) {
+        const int cb = a.B - b0 < CH ? a.B - b0 : CH;
+        p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
+        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
+        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        if (a.split) hipLaunchKernelGGL((gru_fwd_cluster16<4, true>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
+        else hipLaunchKernelGGL((gru_fwd_cluster16<4, false>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
+        DEP_CHECK_LAUNCH();
+    }
     return DEP_OK;
 }
 
 int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
-    const int NC = a.H / 16, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    const int NC = a.H / 16, CH = 512, nbt = dep_cdiv(a.B, BT);
+    const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     B16 p{};
-    p.B = a.B; p.T = a.T; p.H = a.H; p.nbtp = nbtp;
+    p.B = a.B; p.T = a.T; p.H = a.H;
     p.wp = (const f32x4*)a.wpT[0];
     p.y = a.y; p.ldy = a.ldy; p.dy = a.dy; p.lddy = a.lddy;
     p.drop_p = a.dy ? a.drop_p : 0.f; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
@@ -515,14 +523,19 @@ int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbu
     p.sv0 = a.sv0; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
     p.dgi = a.dgi; p.lddg = 3 * a.H; p.dghn = a.dghn; p.dbpart = a.dbpart;
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
-    const size_t pay = (size_t)2 * nbtp * NC * BT * a.H * sizeof(float);
-    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC <= 512);
+    const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 512);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
-    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
     const size_t lds = (size_t)(BT * (48 + LPAD) + 64) * sizeof(float);
-    hipLaunchKernelGGL(gru_bwd_cluster16<4>, dim3(NC * nbtp), dim3(CT), lds, a.stream, p);
-    DEP_CHECK_LAUNCH();
+    for (int b0 = 0; b0 < a.B; b0 += CH) {
+        const int cb = a.B - b0 < CH ? a.B - b0 : CH;
+        p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
+        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
+        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        hipLaunchKernelGGL(gru_bwd_cluster16<4>, dim3(NC * p.nbtp), dim3(CT), lds, a.stream, p);
+        DEP_CHECK_LAUNCH();
+    }
     return DEP_OK;
 }

@@ -18,7 +18,7 @@ constexpr size_t EXCLUSIVE_LDS = 84 * 1024;
 #define DEP_STAMP(slot) do { if (tr && t >= 100 && t < 104) tr[(t - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 struct P2 {
-    int B, T, H, nbtp;
+    int B, T, H, nbtp, b0;      // b0: first utterance of this launch's batch chunk (B is the whole batch)
     const f32x4* wp;
     const float* y; int ldy;
     const float* dy; int lddy;
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane (208-byte rows)
     const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
-    if (bt * BT >= p.B) return;
+    if (p.b0 + bt * BT >= p.B) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jl = tid >> 7, lp = (tid >> 1) & 63, half = tid & 1;
     const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;      // unit inside the member's 32
     const int col = 32 * c + ul;
-    const int b = bt * BT + j;
+    const int b = p.b0 + bt * BT + j;
     const bool valid = b < p.B;
     float* dgs = smem;                                                     // [16][LDG] fp32, or (SPLIT) two bf16 planes [16][LDGB]
     unsigned short* dg_hi = reinterpret_cast<unsigned short*>(smem);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
 #pragma unroll
         for (int m = 2; m <= 16; m <<= 1) { a[k].x += __shfl_xor(a[k].x, m, 64); a[k].y += __shfl_xor(a[k].y, m, 64); }
     if (j == 0) {
-        float* o = p.dbpart + (size_t)bt * 4 * H;
+        float* o = p.dbpart + (size_t)(p.b0 / BT + bt) * 4 * H;
         st2(o + col, a[0]); st2(o + H + col, a[1]); st2(o + 2 * H + col, a[2]); st2(o + 3 * H + col, a[3]);
     }
 }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
 // sc1 store, the workgroup drains + barriers, one lane raises the member's flag; after the NC flags are seen the
 // whole 16xH block is read once with 16-byte sc1 loads into LDS (no per-value polling traffic).
 struct F2 {
-    int B, T, H, nbtp;
+    int B, T, H, nbtp, b0;      // b0: first utterance of this launch's batch chunk (B is the whole batch)
     const f32x4* wp; const float* b_hh;
     const float* gi; int ldgi;
     float* y; int ldy;
@@ -245,11 +245,11 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
-    if (bt * BT >= p.B) return;
+    if (p.b0 + bt * BT >= p.B) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4, jl = w >> 1, kh = w & 1;
     const int jt = c * 2 + jl;
-    const int b = bt * BT + j;
+    const int b = p.b0 + bt * BT + j;
     const bool valid = b < p.B;
     float* hs = smem;                                 // [16][LDH]
     float* red = smem + BT * LDH;                     // [4][3][64][4]
@@ -404,29 +404,24 @@ int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t
     return DEP_OK;
 }
 
-int dep_launch_cluster_fwd_granule(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
-
 int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
-    static int use_granule = -1;
-    if (use_granule < 0) { const char* e = getenv("DEP_CLUSTER_FWD"); use_granule = (e && e[0] == 'g') ? 1 : 0; }
-    if (use_granule) return dep_launch_cluster_fwd_granule(a, xbuf, xbuf_bytes);
     DEP_CHECK_ARG(dep_cluster_ok(a.cell, a.H, a.B, a.dirs) && xbuf && xbuf_bytes >= dep_cluster_xbuf_bytes(a.cell, a.H, a.B, a.dirs));
-    const int NC = a.H / 32, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    const int NC = a.H / 32, CH = 256 / NC * BT;      // one workgroup per CU: 256 / NC tiles per launch, larger batches in chunks
+    const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     F2 p{};
-    p.B = a.B; p.T = a.T; p.H = a.H; p.nbtp = nbtp;
+    p.B = a.B; p.T = a.T; p.H = a.H;
     p.wp = (const f32x4*)a.wp[0]; p.b_hh = a.b_hh[0];
     p.gi = a.gi; p.ldgi = 3 * a.H; p.y = a.y; p.ldy = a.ldy;
     p.ydrop = (a.drop_p > 0.f) ? a.ydrop : nullptr;
     p.drop_p = a.drop_p; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f; p.seed = a.seed; p.site = a.site;
     p.pooled = a.pooled; p.pool_scale = a.pool_scale; p.h_n = a.h_n;
     p.sv0 = a.training ? a.sv0 : nullptr; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
-    const size_t pay = (size_t)2 * nbtp * BT * a.H * sizeof(float);
-    DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC * 4 <= PAYLOAD_OFF - FLAG_OFF);
+    const size_t pay = (size_t)2 * nbtp_max * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 256);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
     p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
-    if (hipMemsetAsync(xbuf, 0, p.trace ? FLAG_OFF + 2048 : PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
     // Ask for more than half of the CU's 160 KiB LDS: the dispatcher can then never co-locate two members on one
     // CU (they would share the four matrix pipes and stretch every step of BOTH clusters).
@@ -437,23 +432,25 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
         (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_f = true;
     }
-    dim3 grid(NC * nbtp);
-    if (a.H == 128) hipLaunchKernelGGL(gru_fwd_cluster_r1<4>, grid, dim3(CT), lds, a.stream, p);
-    else hipLaunchKernelGGL(gru_fwd_cluster_r1<8>, grid, dim3(CT), lds, a.stream, p);
-    DEP_CHECK_LAUNCH();
+    for (int b0 = 0; b0 < a.B; b0 += CH) {
+        const int cb = a.B - b0 < CH ? a.B - b0 : CH;
+        p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
+        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
+        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        dim3 grid(NC * p.nbtp);
+        if (a.H == 128) hipLaunchKernelGGL(gru_fwd_cluster_r1<4>, grid, dim3(CT), lds, a.stream, p);
+        else hipLaunchKernelGGL(gru_fwd_cluster_r1<8>, grid, dim3(CT), lds, a.stream, p);
+        DEP_CHECK_LAUNCH();
+    }
     return DEP_OK;
 }
 
-int dep_launch_cluster_bwd_granule(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
-
 int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
-    static int use_granule = -1;
-    if (use_granule < 0) { const char* e = getenv("DEP_CLUSTER_BWD"); use_granule = (e && e[0] == 'g') ? 1 : 0; }
-    if (use_granule) return dep_launch_cluster_bwd_granule(a, xbuf, xbuf_bytes);
     DEP_CHECK_ARG(dep_cluster_ok(a.cell, a.H, a.B, a.dirs) && xbuf && xbuf_bytes >= dep_cluster_xbuf_bytes(a.cell, a.H, a.B, a.dirs));
-    const int NC = a.H / 32, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    const int NC = a.H / 32, CH = 256 / NC * BT, nbt = dep_cdiv(a.B, BT);
+    const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     P2 p{};
-    p.B = a.B; p.T = a.T; p.H = a.H; p.nbtp = nbtp;
+    p.B = a.B; p.T = a.T; p.H = a.H;
     p.wp = (const f32x4*)a.wpT[0];
     p.y = a.y; p.ldy = a.ldy; p.dy = a.dy; p.lddy = a.lddy;
     p.drop_p = a.dy ? a.drop_p : 0.f; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
@@ -462,12 +459,11 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.sv0 = a.sv0; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
     p.dgi = a.dgi; p.lddg = 3 * a.H; p.dghn = a.dghn; p.dbpart = a.dbpart;
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
-    const size_t pay = (size_t)2 * nbtp * NC * BT * a.H * sizeof(float);
-    DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp * NC * 4 <= PAYLOAD_OFF - FLAG_OFF);
+    const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 256);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
-    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
     const size_t lds = EXCLUSIVE_LDS;
     static bool attr_b = false;
@@ -478,11 +474,17 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_b = true;
     }
-    dim3 grid(NC * nbtp);
-    if (a.H == 128) { if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<2, true>), grid, dim3(CT), lds, a.stream, p);
-                      else hipLaunchKernelGGL((gru_bwd_cluster_r1<2, false>), grid, dim3(CT), lds, a.stream, p); }
-    else            { if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true>), grid, dim3(CT), lds, a.stream, p);
-                      else hipLaunchKernelGGL((gru_bwd_cluster_r1<4, false>), grid, dim3(CT), lds, a.stream, p); }
-    DEP_CHECK_LAUNCH();
+    for (int b0 = 0; b0 < a.B; b0 += CH) {
+        const int cb = a.B - b0 < CH ? a.B - b0 : CH;
+        p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
+        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
+        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        dim3 grid(NC * p.nbtp);
+        if (a.H == 128) { if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<2, true>), grid, dim3(CT), lds, a.stream, p);
+                          else hipLaunchKernelGGL((gru_bwd_cluster_r1<2, false>), grid, dim3(CT), lds, a.stream, p); }
+        else            { if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true>), grid, dim3(CT), lds, a.stream, p);
+                          else hipLaunchKernelGGL((gru_bwd_cluster_r1<4, false>), grid, dim3(CT), lds, a.stream, p); }
+        DEP_CHECK_LAUNCH();
+    }
     return DEP_OK;
 }

@@ -11,7 +11,7 @@ namespace {
 using namespace depc;
 
 struct LF {
-    int B, T, H, dirs, nbtp;
+    int B, T, H, dirs, nbtp, b0;      // b0: first utterance of this launch's batch chunk (B is the whole batch)
     const f32x4* wp[2];
     const float* gi; int ldgi;
     float* y; int ldy;
@@ -23,7 +23,7 @@ struct LF {
 };
 
 struct LB {
-    int B, T, H, dirs, nbtp;
+    int B, T, H, dirs, nbtp, b0;      // b0: first utterance of this launch's batch chunk (B is the whole batch)
     const f32x4* wp[2];
     const float* dy; int lddy;
     float drop_p, drop_scale; uint64_t seed; uint32_t site;
@@ -46,11 +46,11 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
     const int LDHB = H + 8;                           // bf16 elements per row of a split plane
     const int bt = blockIdx.x % p.nbtp, dc = blockIdx.x / p.nbtp, c = dc % NC, dir = dc / NC;
-    if (bt * BT >= p.B) return;
+    if (p.b0 + bt * BT >= p.B) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4, jl = w >> 1, kh = w & 1;
     const int jt = c * 2 + jl;
-    const int b = bt * BT + j;
+    const int b = p.b0 + bt * BT + j;
     const bool valid = b < p.B;
     float* hs = smem;                                 // [16][LDH] fp32, or (SPLIT) two bf16 planes [16][LDHB]
     const int hs_floats = SPLIT ? BT * LDHB : BT * LDH;
@@ -223,12 +223,12 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane
     const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
     const int bt = blockIdx.x % p.nbtp, dc = blockIdx.x / p.nbtp, c = dc % NC, dir = dc / NC;
-    if (bt * BT >= p.B) return;
+    if (p.b0 + bt * BT >= p.B) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jl = tid >> 7, lp = (tid >> 1) & 63, half = tid & 1;
     const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;
     const int col = 32 * c + ul;
-    const int b = bt * BT + j;
+    const int b = p.b0 + bt * BT + j;
     const bool valid = b < p.B;
     float* dgs = smem;                                // [16][LDG] fp32, or (SPLIT) two bf16 planes [16][LDGB]
     unsigned short* dg_hi = reinterpret_cast<unsigned short*>(smem);
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
 #pragma unroll
         for (int m = 2; m <= 16; m <<= 1) { db[k].x += __shfl_xor(db[k].x, m, 64); db[k].y += __shfl_xor(db[k].y, m, 64); }
     if (j == 0) {
-        float* o = p.dbpart + ((size_t)dir * p.nwg + bt) * 4 * H;
+        float* o = p.dbpart + ((size_t)dir * p.nwg + p.b0 / BT + bt) * 4 * H;
 #pragma unroll
         for (int k = 0; k < 4; ++k) st2(o + k * H + col, db[k]);
     }
@@ -437,43 +437,50 @@ int dep_pack_cluster_lstm_split(const float* w_hh, float* wp, float* wpT, int H,
 bool dep_cluster_lstm_ok(int H, int B, int dirs) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("DEP_CLUSTER_LSTM"); off = (e && e[0] == '0') ? 1 : 0; }
-    if (off || H != 128) return false;                 // KCH = 4, NTW = 2, NC = 4 (backward gathers exactly 4 partials)
-    const int nbtp = (dep_cdiv(B, BT) + 7) / 8 * 8;
-    return dirs * (H / 32) * nbtp <= 256;
+    (void)B; (void)dirs;                               // any batch: the launchers chunk it
+    return !off && H == 128;                           // KCH = 4, NTW = 2, NC = 4 (backward gathers exactly 4 partials)
 }
 
 size_t dep_cluster_lstm_xbuf_bytes(int H, int B, int dirs) {
-    const int NC = H / 32, nbtp = (dep_cdiv(B, BT) + 7) / 8 * 8;
+    const int NC = H / 32, CH = 256 / (dirs * NC) * BT;
+    const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
     return PAYLOAD_OFF + (size_t)2 * dirs * nbtp * NC * BT * H * sizeof(float) + 256;
 }
 
 int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
-    const int NC = a.H / 32, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    const int NC = a.H / 32, CH = 256 / (a.dirs * NC) * BT;      // one workgroup per CU per launch; larger batches in chunks
+    const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     LF p{};
-    p.B = a.B; p.T = a.T; p.H = a.H; p.dirs = a.dirs; p.nbtp = nbtp;
+    p.B = a.B; p.T = a.T; p.H = a.H; p.dirs = a.dirs;
     for (int d = 0; d < a.dirs; ++d) p.wp[d] = (const f32x4*)a.wp[d];
     p.gi = a.gi; p.ldgi = a.dirs * 4 * a.H; p.y = a.y; p.ldy = a.ldy;
     p.ydrop = (a.drop_p > 0.f) ? a.ydrop : nullptr;
     p.drop_p = a.drop_p; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f; p.seed = a.seed; p.site = a.site;
     p.h_n = a.h_n;
     p.svg = a.training ? a.sv0 : nullptr; p.svc = a.sv1;
-    const size_t pay = (size_t)2 * a.dirs * nbtp * BT * a.H * sizeof(float);
-    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp * NC <= 512);
+    const size_t pay = (size_t)2 * a.dirs * nbtp_max * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp_max * NC <= 256);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
-    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_LSTM_FWD, a.stream);
     const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 4 * 64 * 4) * sizeof(float);
-    if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true>), dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
-    else hipLaunchKernelGGL((lstm_fwd_cluster<4, false>), dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
-    DEP_CHECK_LAUNCH();
+    for (int b0 = 0; b0 < a.B; b0 += CH) {
+        const int cb = a.B - b0 < CH ? a.B - b0 : CH;
+        p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
+        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
+        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
+        else hipLaunchKernelGGL((lstm_fwd_cluster<4, false>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
+        DEP_CHECK_LAUNCH();
+    }
     return DEP_OK;
 }
 
 int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
-    const int NC = a.H / 32, nbt = dep_cdiv(a.B, BT), nbtp = (nbt + 7) / 8 * 8;
+    const int NC = a.H / 32, CH = 256 / (a.dirs * NC) * BT, nbt = dep_cdiv(a.B, BT);
+    const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     LB p{};
-    p.B = a.B; p.T = a.T; p.H = a.H; p.dirs = a.dirs; p.nbtp = nbtp;
+    p.B = a.B; p.T = a.T; p.H = a.H; p.dirs = a.dirs;
     for (int d = 0; d < a.dirs; ++d) p.wp[d] = (const f32x4*)a.wpT[d];
     p.dy = a.dy; p.lddy = a.lddy;
     p.drop_p = a.dy ? a.drop_p : 0.f; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
@@ -481,15 +488,20 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
     p.dh_n = a.dh_n; p.svg = a.sv0; p.svc = a.sv1;
     p.dgi = a.dgi; p.lddg = a.dirs * 4 * a.H; p.dbpart = a.dbpart; p.nwg = nbt;
     DEP_CHECK_ARG(a.dbpart_rows >= nbt * a.dirs);
-    const size_t pay = (size_t)2 * a.dirs * nbtp * NC * BT * a.H * sizeof(float);
-    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp * NC <= 512);
+    const size_t pay = (size_t)2 * a.dirs * nbtp_max * NC * BT * a.H * sizeof(float);
+    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp_max * NC <= 256);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
-    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     DepProfScope prof(DEP_PROF_LSTM_BWD, a.stream);
     const size_t lds = (size_t)(BT * (128 + 8)) * sizeof(float);
-    if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true>), dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
-    else hipLaunchKernelGGL((lstm_bwd_cluster<2, false>), dim3(a.dirs * NC * nbtp), dim3(CT), lds, a.stream, p);
-    DEP_CHECK_LAUNCH();
+    for (int b0 = 0; b0 < a.B; b0 += CH) {
+        const int cb = a.B - b0 < CH ? a.B - b0 : CH;
+        p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
+        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
+        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
+        else hipLaunchKernelGGL((lstm_bwd_cluster<2, false>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
+        DEP_CHECK_LAUNCH();
+    }
     return DEP_OK;
 }

@@ -205,6 +205,9 @@ RNN_CASES = [
     ('lstm', 3, 5, 16, 32, 2),
     ('lstm', 19, 11, 40, 128, 3),       # cluster-parallel BiLSTM sweeps (cfg3 H), ragged tile
     ('lstm', 70, 300, 64, 128, 3),      # 5 tiles -> 8 padded x 2 directions x 4 members, full T
+    ('gru', 530, 4, 16, 256, 3),        # more utterances than one co-resident launch holds: chunks of 512 + 18
+    ('gru', 1040, 3, 8, 128, 3),        # H = 128: chunks of 1024 + 16
+    ('lstm', 530, 3, 8, 128, 3),        # BiLSTM: chunks of 512 + 18
 ]
 
 
