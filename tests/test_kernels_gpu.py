@@ -208,6 +208,10 @@ RNN_CASES = [
     ('gru', 530, 4, 16, 256, 3),        # more utterances than one co-resident launch holds: chunks of 512 + 18
     ('gru', 1040, 3, 8, 128, 3),        # H = 128: chunks of 1024 + 16
     ('lstm', 530, 3, 8, 128, 3),        # BiLSTM: chunks of 512 + 18
+    ('gru', 1, 1, 8, 256, 3),           # degenerate: one utterance, one step (no exchange at all)
+    ('gru', 3, 2, 8, 128, 3),           # two steps: a single exchange
+    ('lstm', 2, 1, 8, 128, 3),
+    ('gru', 2, 1, 5, 16, 2), ('lstm', 1, 1, 3, 8, 1),
 ]
 
 
