@@ -106,9 +106,14 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     };
     StepIn cur, nxt;
     load_step(T - 1, cur);
+    // debug stamps (DEP_TRACE=1, tools/trace_bwd.py): buffered in otherwise unused LDS, copied out after the sweep
+    long long* trb = (p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
+    long long* trlb = reinterpret_cast<long long*>(smem + 8192);
+#define BSTAMP(slot) do { if (trb && t <= 199 && t > 195) trlb[(199 - t) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
     for (int t = T - 1; t >= 0; --t) {
         const size_t row = (size_t)b * T + t;
+        BSTAMP(0);
         float2 dyv = cur.dy;
         if (p.dy && p.drop_p > 0.f && valid) {
             const size_t o = row * p.lddy + col;
@@ -140,6 +145,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         }
         dbr.x += dr.x; dbr.y += dr.y; dbz.x += dz.x; dbz.y += dz.y; dbn.x += dn.x; dbn.y += dn.y; dbh.x += dnr.x; dbh.y += dnr.y;
         bar_lds();                                   // LDS only: the dgi/dghn stores above stay in flight
+        BSTAMP(1);
         if (t == 0) break;
         load_step(t - 1, nxt);                       // independent of the recurrence: in flight under the MFMAs
         f32x4 acc[NTW];
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[k][e], acc[i], 0, 0, 0);
             }
         }
+        BSTAMP(2);
         // publish: payload[parity][tile][src c][out tile][lane][4]
         const unsigned epoch = (unsigned)(T - t);
         const size_t pbase = (size_t)(t & 1) * pstride + tile_base;
@@ -191,12 +198,15 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
             else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 16 /* sc1: write-through */);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+        BSTAMP(3);
         __builtin_amdgcn_s_barrier();                // every wave drained its payload stores (vmcnt(0) above)
         if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        BSTAMP(4);
         // wait for every member's flag (one wave polls, relaxed; flags are monotonic)
         // every wave polls the flags itself (no verdict-broadcast barrier); a wave that gives up leaves, the hardware
         // barrier only counts live waves and the others give up too (status word raised)
         if (!wait_flags(tflags, NC, epoch, p.status, 3)) return;
+        BSTAMP(5);
         // gather this thread's two columns from the NC partials, sum in member order
         float2 s = f2(0.f, 0.f);
         const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
@@ -208,7 +218,9 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         for (int m = 0; m < 8; ++m) { s.x += part[m].x; s.y += part[m].y; }
         dhrec = f2(dzt.x + s.x, dzt.y + s.y);
         cur = nxt;
+        BSTAMP(6);
     }
+    if (trb) for (int i = 0; i < 32; ++i) trb[i] = trlb[i];
     // bias-gradient partials dbpart[bt][4][H]: sum over the 16 utterance rows = lanes that differ in bits 1..4
     float2 a[4] = {dbr, dbz, dbn, dbh};
 #pragma unroll
@@ -464,6 +476,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
+    p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
     const size_t lds = EXCLUSIVE_LDS;
     static bool attr_b = false;
