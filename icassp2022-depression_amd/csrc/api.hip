@@ -117,14 +117,15 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     lo.biastmp = w; w += al(G * H);
     // split-K scratch: the largest weight-gradient contraction
     size_t gb = 0;
-    {
-        const int Ks[2] = {d->F, (int)(D * H)};
-        for (int i = 0; i < 2; ++i) {
-            size_t b1 = dep_gemm_workspace_bytes(1, 0, (int)(G * H), Ks[i], (int)lo.BT);
-            if (b1 > gb) gb = b1;
-        }
-        size_t b2 = dep_gemm_workspace_bytes(1, 0, (int)(G * H), (int)H, (int)lo.BT);
-        if (b2 > gb) gb = b2;
+    {   // every (rows, cols) block dep_rnn_backward contracts over B*T: dW_ih (G H x F | D H), dW_hh whole or as the GRU's
+        // (2H x H) + (H x H) pair -- the split count depends on the block shape, so take the maximum over all of them
+        const int Ms[3] = {(int)(G * H), (int)(2 * H), (int)H};
+        const int Ns[3] = {d->F, (int)(D * H), (int)H};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const size_t b1 = dep_gemm_workspace_bytes(1, 0, Ms[i], Ns[j], (int)lo.BT);
+                if (b1 > gb) gb = b1;
+            }
     }
     lo.gemm = w; lo.gemm_bytes = gb; w += al(gb / sizeof(float) + 64);
     // impl: 0 auto (cluster > tile-MFMA > generic), 1 generic, 2 tile-MFMA, 3 cluster (must be supported)

@@ -274,7 +274,12 @@ __global__ __launch_bounds__(256) void gemm_small(SmallP p) {
 int choose_splits(int M, int N, int K) {
     const long tiles = (long)dep_cdiv(M, BM) * dep_cdiv(N, BN);
     if (tiles >= 256 || K < 1024) return 1;
-    long s = (768 + tiles - 1) / tiles;
+    // fill the persistent bf16x3 grid without spilling into a second round: its 256x128 tiles run two per CU (512 slots),
+    // i.e. 1024 tile-chunks counted in 128x128 tiles, rounded DOWN (measured on dW at cfg2: 504 workgroup-tiles 0.271 ms,
+    // 384 -> 0.306 ms, 516 -> 0.366 ms)
+    static long target = -1;
+    if (target < 0) { const char* e = getenv("DEP_GEMM_SPLIT_TARGET"); target = e ? atol(e) : 1024; }
+    long s = target / tiles;
     const long maxs = K / 256;
     if (s > maxs) s = maxs;
     if (s > 128) s = 128;
@@ -338,7 +343,10 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
         return DEP_OK;
     }
     int splits = choose_splits(M, N, K);
-    if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float))) splits = 1;
+    if (splits > 1) {       // a smaller workspace than dep_gemm_workspace_bytes asked for lowers the split count, it does not drop it
+        const size_t fit = ws ? ws_bytes / ((size_t)M * N * sizeof(float)) : 0;
+        if (fit < (size_t)splits) splits = fit < 1 ? 1 : (int)fit;
+    }
     int kchunk = K;
     if (splits > 1) {
         kchunk = dep_cdiv(dep_cdiv(K, splits), BK) * BK;
