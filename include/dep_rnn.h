@@ -56,7 +56,8 @@ typedef struct {
     uint64_t seed;       /* Philox key for this call's dropout masks */
     int32_t pool;        /* GRU only: DEP_POOL_* over T of the top layer (fused in the sweep) */
     int32_t impl;        /* 0 auto (cluster > tile-MFMA > generic), 1 generic kernels, 2 one-workgroup-per-tile
-                            MFMA kernels, 3 cluster-parallel MFMA kernels (GRU, H in {128,256}) */
+                            MFMA kernels, 3 cluster-parallel MFMA kernels (GRU with H in {128,256}, BiLSTM with
+                            H = 128; any B -- batches beyond one co-resident launch run as consecutive chunks) */
 } dep_rnn_desc;
 
 size_t dep_rnn_reserve_bytes(const dep_rnn_desc* d);     /* activations kept fwd -> bwd */
@@ -67,13 +68,14 @@ size_t dep_rnn_reserve_y_offset(const dep_rnn_desc* d, int layer);
 /* Same for the dropped-out copy that feeds layer+1 (training && dropout_p > 0 only). */
 size_t dep_rnn_reserve_ydrop_offset(const dep_rnn_desc* d, int layer);
 
-/* Health of the cluster-parallel sweeps that last ran on `workspace` (desc.impl 0/3 with H in {128,256}):
+/* Health of the cluster-parallel sweeps that last ran on `workspace` (desc.impl 0/3 with a supported H):
  * they exchange data between workgroups inside one launch with bounded spins; if a spin ever gives up
  * the kernels exit early and this returns DEP_ERR_HIP.  Synchronises `stream`.  Always DEP_OK for the
  * single-workgroup kernels. */
 int dep_rnn_status(const dep_rnn_desc* d, void* workspace, void* stream);
 /* Debug tooling: byte offset of the cluster exchange buffer inside the workspace ((size_t)-1 if unused).
- * With DEP_TRACE=1 workgroup 0 of the forward sweep leaves shader-clock stamps of its phases at +4096. */
+ * With DEP_TRACE=1 workgroup 0 of the GRU sweeps leaves shader-clock stamps of its phases at +6144
+ * (tools/trace_fwd.py, tools/trace_bwd.py). */
 size_t dep_rnn_workspace_xbuf_offset(const dep_rnn_desc* d);
 
 /* ------------------------------------------------------------------ RNN stacks ----- */
@@ -81,6 +83,10 @@ size_t dep_rnn_workspace_xbuf_offset(const dep_rnn_desc* d);
  * (l*dirs+d)*4 + {0,1,2,3}): weight_ih (G*H, in), weight_hh (G*H, H), bias_ih (G*H), bias_hh (G*H),
  * in = F for l = 0 else H*dirs; G = 3 (GRU) or 4 (LSTM)  -- the tensors of
  * state_dict()['lstm_net_audio.weight_ih_l0'] ... / ['lstm_net.weight_ih_l0_reverse'] ...
+ *
+ * Precision: the recurrent products of the cluster sweeps follow the GEMM mode (dep_set_gemm_mode below): 3-term bf16
+ * split by default, exact fp32 MFMA in mode 0.  The packed recurrent weights in the reserve are mode-specific, so the
+ * mode must not change between a dep_rnn_forward and the dep_rnn_backward that consumes its reserve.
  *
  * dep_rnn_forward replaces `x, _ = self.lstm_net_audio(x)` (audio_gru_whole.py:105) and
  * `output, (h_n, _) = self.lstm_net(x)` (text_bilstm_whole.py:105).
