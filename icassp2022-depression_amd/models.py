@@ -47,7 +47,13 @@ class _RnnCache:
                 self.cache.clear()
             r = L.Rnn(cell, B, T, F, H, Lyr, dirs, training, p if training else 0.0, pool, device)
             self.cache[key] = r
+        self.last = r
         return r
+
+    def check(self):
+        """dep_rnn_status of the most recently used stack (synchronises; raises DepError if a sweep gave up)."""
+        if getattr(self, 'last', None) is not None:
+            self.last.check()
 
 
 class _MLPHead:
@@ -156,6 +162,9 @@ class AudioGRU(nn.Module):
         sd = {k: v for k, v in sd.items() if k not in self._buffers}
         return super().load_state_dict(sd, strict)
 
+    def check_health(self):
+        self._rnns.check()
+
     # encoder part shared with FusionNet
     def encode(self, x, training, seed):
         B, T, F = x.shape
@@ -229,6 +238,9 @@ class TextBiLSTM(nn.Module):
         self._rnn_g = [self._params[n]._grad for n, _ in rn]
         self._rnns = _RnnCache(L.CELL_LSTM, F, H, Lyr, 2, self.dropout, L.POOL_NONE, self.device)
         self._head = _MLPHead(self, self._fc[0], self._fc[1], self.dropout, variant == 'reg', (L.SITE_FC0, L.SITE_FC1))
+
+    def check_health(self):
+        self._rnns.check()
 
     def encode(self, x, training, seed):
         B, T, F = x.shape
@@ -309,6 +321,9 @@ class FusionNet(nn.Module):
         self._rnn_a = _RnnCache(L.CELL_GRU, Fa, Ha, Lyr, 1, self.dropout, L.POOL_SUM, self.device)
         self.fc_final = [self._params['fc_final.0.weight']]       # `model.fc_final[0].weight`-style access
         self._params['fc_final.0.weight'].weight = self._params['fc_final.0.weight']
+
+    def check_health(self):
+        self._rnn_t.check(); self._rnn_a.check()
 
     def _split(self, x):
         """Accept the reference's list of (audio_i, text_i) pairs or an (audio, text) pair of arrays."""
@@ -411,4 +426,5 @@ class MyLoss:
             L.gemm(1, 0, Cc, Ha, B, dza, Cc, audio_feature, Ha, g[:, Ht:], D)      # dW[:, Ht:] = dza^T audio
             model._grad_ready = True
             parallel.all_reduce_grads(model)
-        return nn.Loss(val, bw if train else None, reduce=train and parallel.world_size() > 1)
+        return nn.Loss(val, bw if train else None, reduce=train and parallel.world_size() > 1,
+                       health=getattr(model, 'check_health', None))

@@ -65,6 +65,11 @@ class Module:
         self._flat = None
         self._flat_grad = None
 
+    def check_health(self):
+        """Raise if a kernel of the last step reported trouble (the recurrent cluster sweeps bound their in-launch
+        waits and raise a status word instead of hanging).  Called from Loss.item(), i.e. at the host sync the training
+        loops already have; models that own recurrent stacks override it."""
+
     # -- construction ------------------------------------------------------------------
     def _add(self, name, shape, live=True):
         p = Parameter(name, shape, self)
@@ -178,10 +183,11 @@ class Output:
 
 
 class Loss:
-    def __init__(self, value_dev, backward_fn, reduce=False):
+    def __init__(self, value_dev, backward_fn, reduce=False, health=None):
         self._v = value_dev
         self._bw = backward_fn
         self._reduce = reduce               # data parallel: the local part of a global batch mean
+        self._health = health               # model.check_health: the host sync below is where a failed sweep surfaces
 
     def item(self):
         """Host sync point, as in the reference (loss.item()).  Under data parallelism every rank calls it
@@ -189,7 +195,10 @@ class Loss:
         if self._reduce:
             parallel.all_reduce_sum(self._v)
             self._reduce = False
-        return float(self._v.item())
+        v = float(self._v.item())
+        if self._health is not None:
+            self._health()
+        return v
 
     def backward(self):
         if self._bw is None:
@@ -226,7 +235,8 @@ class _HeadLoss:
         L.head_loss(self.kind, z, t, None, rows, dz, norm)
         val = torch.zeros(1, dtype=torch.float32, device=dev)
         L.reduce_loss(rows, norm, val)
-        return Loss(val, (lambda: owner.backward(dz)) if train else None, reduce=train and parallel.world_size() > 1)
+        return Loss(val, (lambda: owner.backward(dz)) if train else None, reduce=train and parallel.world_size() > 1,
+                    health=getattr(owner, 'check_health', None))
 
 
 class CrossEntropyLoss(_HeadLoss):
