@@ -106,6 +106,15 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     };
     StepIn cur, nxt;
     load_step(T - 1, cur);
+    // inter-layer dropout on the incoming dy: the Philox draw of step t-1 is made while step t waits for the other members
+    // (it depends on nothing but the position), so it never sits on the step's critical path
+    const bool masked = p.dy && p.drop_p > 0.f && valid;
+    auto draw = [&](int t) {
+        const size_t o = ((size_t)b * T + t) * p.lddy + col;
+        const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+        return f2(half ? m[2] : m[0], half ? m[3] : m[1]);
+    };
+    float2 mk = masked ? draw(T - 1) : f2(1.f, 1.f);
     // debug stamps (DEP_TRACE=1, tools/trace_bwd.py): buffered in otherwise unused LDS, copied out after the sweep
     long long* trb = (p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
     long long* trlb = reinterpret_cast<long long*>(smem + 8192);
@@ -114,12 +123,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     for (int t = T - 1; t >= 0; --t) {
         const size_t row = (size_t)b * T + t;
         BSTAMP(0);
-        float2 dyv = cur.dy;
-        if (p.dy && p.drop_p > 0.f && valid) {
-            const size_t o = row * p.lddy + col;
-            const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
-            dyv.x *= (half ? m[2] : m[0]); dyv.y *= (half ? m[3] : m[1]);
-        }
+        const float2 dyv = f2(cur.dy.x * mk.x, cur.dy.y * mk.y);
         const float2 r = cur.r, z = cur.z, n = cur.n, hn = cur.hn, hp = cur.hp;
         const float2 d = f2(dhrec.x + dpl.x + dyv.x, dhrec.y + dpl.y + dyv.y);
         float2 dn, dz, dr, dnr, dzt;
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         BSTAMP(3);
         __builtin_amdgcn_s_barrier();                // every wave drained its payload stores (vmcnt(0) above)
         if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        if (masked) mk = draw(t - 1);                // next step's mask, in the shadow of the wait below
         BSTAMP(4);
         // wait for every member's flag (one wave polls, relaxed; flags are monotonic)
         // every wave polls the flags itself (no verdict-broadcast barrier); a wave that gives up leaves, the hardware

@@ -281,16 +281,20 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
     };
     StepIn cur, nxt;
     load_step(T - 1, cur);
+    // dropout mask of the incoming dy: drawn one step ahead while waiting for the other members (see rnn_cluster_bwd.hip)
+    const bool masked = p.dy && p.drop_p > 0.f && valid;
+    auto draw = [&](int s) {
+        const int t = dir ? (T - 1 - s) : s;
+        const size_t o = ((size_t)b * T + t) * p.lddy + dir * H + col;
+        const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+        return f2(half ? m[2] : m[0], half ? m[3] : m[1]);
+    };
+    float2 mk = masked ? draw(T - 1) : f2(1.f, 1.f);
 
     for (int s = T - 1; s >= 0; --s) {
         const int t = dir ? (T - 1 - s) : s;
         const size_t row = (size_t)b * T + t;
-        float2 dyv = cur.dy;
-        if (p.dy && p.drop_p > 0.f && valid) {
-            const size_t o = row * p.lddy + dir * H + col;
-            const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
-            dyv.x *= (half ? m[2] : m[0]); dyv.y *= (half ? m[3] : m[1]);
-        }
+        const float2 dyv = f2(cur.dy.x * mk.x, cur.dy.y * mk.y);
         const float2 ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og, cp = cur.cp;
         const float2 d = f2(dhrec.x + dyv.x, dhrec.y + dyv.y);
         const float2 tc = f2(fast_tanh(cur.ct.x), fast_tanh(cur.ct.y));
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        if (masked) mk = draw(s - 1);                // next step's mask, in the shadow of the wait below
         if (!wait_flags(tflags, NC, epoch, p.status, 7)) return;
         const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
         float2 part[4];
