@@ -159,13 +159,6 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restri
         partial[((size_t)blockIdx.x * 2 + 1) * F + c] = db;
     }
 }
-__global__ void ln_bwd_finish_kernel(const float* __restrict__ partial, int nblk, int F, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * F) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * 2 * F + c];
-    if (c < F) dgamma[c] = s; else dbeta[c - F] = s;
-}
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ mr,
                                                         float* __restrict__ dx, int rows, int F) {

@@ -121,7 +121,6 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
     const int hshift = __ffs(H) - 1;
     // where the finalising thread finds its element inside the fragment-ordered partial sums
     const int rsrc_lane = (fu >> 2) * 16 + fj, rsrc_e = fu & 3;
-    bool dead = false;
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * NC, NC, c, p.status);
     if (sx < 0) return;
     const bool fast = sx == 1;
@@ -172,7 +171,6 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
     long long* tr = (p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
     long long* trl = reinterpret_cast<long long*>(obuf + 2 * 1280);
     for (int t = 0; t < T; ++t) {
-        const size_t row = (size_t)b * T + t;
         DEP_STAMP(0);
         f32x4 acc[3] = {zero4(), zero4(), zero4()};
         if constexpr (SPLIT) {
