@@ -214,6 +214,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     const int BTr = (int)lo.BT;
     const bool mfma = lo.cluster || dep_sweep_use_mfma(H, d->impl);
     const bool split_fwd = lo.cluster16 && sweep_split_mode();
+    const bool split_fwd32 = lo.cluster && !lo.cluster16 && d->cell == DEP_CELL_GRU && sweep_split_mode();     // 32-unit members
     const bool split_lstm = lo.cluster && d->cell == DEP_CELL_LSTM && sweep_split_mode();
     int rc;
     for (int l = 0; l < L; ++l) {
@@ -230,6 +231,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             } else {
                 if (mfma) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
                 if (split_fwd) { rc = dep_pack_cluster16_fwd_split(wl[1], R + lo.wp[l][dd], H, s); if (rc) return rc; }
+                if (split_fwd32) { rc = dep_pack_cluster_fwd_split(wl[1], R + lo.wp[l][dd], H, s); if (rc) return rc; }
                 if (lo.cluster && d->training) {     // the cluster backward wants its own member-sliced image
                     const bool split_bwd = d->cell == DEP_CELL_GRU && !lo.cluster16_bwd && sweep_split_mode();
                     rc = lo.cluster16_bwd ? dep_pack_cluster16_bwd(wl[1], R + lo.wpT[l][dd], H, s)
@@ -252,7 +254,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         }
         dep_sweep_args a{};
         a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.training = d->training; a.impl = d->impl;
-        a.split = (split_fwd || split_lstm) ? 1 : 0;
+        a.split = (split_fwd || split_fwd32 || split_lstm) ? 1 : 0;
         for (int dd = 0; dd < D; ++dd) {
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             a.w_hh[dd] = wl[1]; a.b_hh[dd] = wl[3]; a.wp[dd] = R + lo.wp[l][dd];

@@ -257,7 +257,7 @@ struct F2 {
     long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
 };
 
-template <int KCH>
+template <int KCH, bool SPLIT>      // SPLIT: 3-term bf16 split of the recurrent product, as in gru_fwd_cluster16
 __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
@@ -268,16 +268,33 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
     const int jt = c * 2 + jl;
     const int b = p.b0 + bt * BT + j;
     const bool valid = b < p.B;
-    float* hs = smem;                                 // [16][LDH]
-    float* red = smem + BT * LDH;                     // [4][3][64][4]
-    for (int i = tid; i < BT * LDH; i += CT) hs[i] = 0.f;
+    const int LDHB = H + 8;                           // bf16 elements per row of a split plane
+    float* hs = smem;                                 // [16][LDH] fp32, or (SPLIT) two bf16 planes [16][LDHB]
+    const int hs_floats = SPLIT ? BT * LDHB : BT * LDH;
+    unsigned short* hs_hi = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* hs_lo = hs_hi + BT * LDHB;
+    float* red = smem + hs_floats;                    // [4][3][64][4]
+    for (int i = tid; i < hs_floats; i += CT) hs[i] = 0.f;
 
-    f32x4 wr[3][KCH];
+    constexpr int KS2 = KCH / 2;                      // 32-wide k-steps per wave (SPLIT)
+    f32x4 wr[SPLIT ? 1 : 3][SPLIT ? 1 : KCH];
+    u32x4 wq[SPLIT ? 3 : 1][SPLIT ? KS2 : 1][2];      // [gate][k-step][hi, lo]
+    if constexpr (SPLIT) {
+        const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp);
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int k = 0; k < KCH; ++k)
-            wr[g][k] = p.wp[(size_t)((jt * 3 + g) * KC + kh * KCH + k) * 64 + lane];
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    wq[g][ks][pl] = wpq[(size_t)((((jt * 3 + g) * 2 + kh) * KS2 + ks) * 2 + pl) * 64 + lane];
+    } else {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int k = 0; k < KCH; ++k)
+                wr[g][k] = p.wp[(size_t)((jt * 3 + g) * KC + kh * KCH + k) * 64 + lane];
+    }
     const int col = jt * 16 + q * 4 + 2 * kh;
     float2 bh[3];
 #pragma unroll
@@ -310,18 +327,38 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
             for (int g = 0; g < 3; ++g) gin[g] = ld2(p.gi + (row + 1) * p.ldgi + g * H + col);
         }
         f32x4 acc[3] = {zero4(), zero4(), zero4()};
-        const float* hrow = hs + j * LDH + kh * KCH * 16 + q * 4;
-        f32x4 hv[KCH];                                 // all B fragments first: one LDS latency, not KCH of them
+        if constexpr (SPLIT) {
+            const int ho = j * LDHB + kh * KCH * 16 + q * 8;
+            bf16x8 hh[KS2], hl[KS2];
 #pragma unroll
-        for (int k = 0; k < KCH; ++k) hv[k] = ld4(hrow + k * 16);
-        __builtin_amdgcn_sched_barrier(0);             // keep the loads grouped: hipcc otherwise sinks each next to its MFMAs
+            for (int ks = 0; ks < KS2; ++ks) {
+                hh[ks] = *reinterpret_cast<const bf16x8*>(hs_hi + ho + ks * 32);
+                hl[ks] = *reinterpret_cast<const bf16x8*>(hs_lo + ho + ks * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < KCH; ++k) {
+            for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int g = 0; g < 3; ++g) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[g][ks][0]), wl = __builtin_bit_cast(bf16x8, wq[g][ks][1]);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hl[ks], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, hh[ks], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hh[ks], acc[g], 0, 0, 0);
+                }
+        } else {
+            const float* hrow = hs + j * LDH + kh * KCH * 16 + q * 4;
+            f32x4 hv[KCH];                             // all B fragments first: one LDS latency, not KCH of them
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
+            for (int k = 0; k < KCH; ++k) hv[k] = ld4(hrow + k * 16);
+            __builtin_amdgcn_sched_barrier(0);         // keep the loads grouped: hipcc otherwise sinks each next to its MFMAs
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][k][e], hv[k][e], acc[g], 0, 0, 0);
+            }
         }
         DEP_STAMP(1);
 #pragma unroll
@@ -347,7 +384,8 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
         const bool more = t + 1 < T;
         DEP_STAMP(3);
         if (more) {       // publish first: it is on the critical path of the other members
-            const u64 bits = (u64)__float_as_uint(h.x) | ((u64)__float_as_uint(h.y) << 32);
+            const u64 bits = SPLIT ? ((u64)split_word(h.x) | ((u64)split_word(h.y) << 32))
+                                   : ((u64)__float_as_uint(h.x) | ((u64)__float_as_uint(h.y) << 32));
             if (fast) __hip_atomic_store((gu64*)(p.payload + pbase + (size_t)j * H + col), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store((gu64*)(p.payload + pbase + (size_t)j * H + col), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -376,9 +414,17 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
             for (int k = 0; k < PER; ++k) {
                 const int i4 = (tid + CT * k) * 4;    // float index inside the 16xH block
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((pbase + i4) * 4), 0, 16 /* sc1 */);
-                f32x4 f;
-                f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
-                *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
+                if constexpr (SPLIT) {
+                    const int o = (i4 >> hshift) * LDHB + (i4 & (H - 1));
+                    uint2 hi2, lo2;
+                    hi2.x = (v.x >> 16) | (v.y & 0xffff0000u); hi2.y = (v.z >> 16) | (v.w & 0xffff0000u);
+                    lo2.x = (v.x & 0xffffu) | (v.y << 16);      lo2.y = (v.z & 0xffffu) | (v.w << 16);
+                    *reinterpret_cast<uint2*>(hs_hi + o) = hi2; *reinterpret_cast<uint2*>(hs_lo + o) = lo2;
+                } else {
+                    f32x4 f;
+                    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+                    *reinterpret_cast<f32x4*>(hs + (i4 >> hshift) * LDH + (i4 & (H - 1))) = f;
+                }
             }
             bar_lds();
             DEP_STAMP(7);
@@ -412,7 +458,33 @@ __global__ void pack_cluster_bwd_split_kernel(const float* __restrict__ W, u32x4
     out[(idx - lane) * 2 + 64 + lane] = lo;
 }
 
+// split-precision forward image of the 32-unit-member kernel (gru_fwd_cluster_r1<., true>): 16-byte piece
+//   [((((jt*3 + g)*2 + kh)*KS2 + ks)*2 + plane)*64 + lane] = bf16 plane of W[(g*H + jt*16 + (lane&15))*H + kh*(H/2) + 32ks + 8(lane>>4) + 0..7]
+__global__ void pack_cluster_fwd_split_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int H) {
+    const int KS2 = H / 64;
+    const long n = (long)(H / 16) * 3 * 2 * KS2 * 64;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = idx & 63; long r = idx >> 6;
+    const int ks = r % KS2; r /= KS2;
+    const int kh = r % 2; r /= 2;
+    const int g = r % 3; const int jt = r / 3;
+    const float* src = W + (size_t)(g * H + jt * 16 + (lane & 15)) * H + kh * (H / 2) + 32 * ks + 8 * (lane >> 4);
+    u32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { unsigned h, l; split_pair(src[2 * e], src[2 * e + 1], h, l); hi[e] = h; lo[e] = l; }
+    out[(idx - lane) * 2 + lane] = hi;
+    out[(idx - lane) * 2 + 64 + lane] = lo;
+}
+
 }  // namespace
+
+int dep_pack_cluster_fwd_split(const float* w_hh, float* out, int H, hipStream_t s) {
+    const long n = (long)(H / 16) * 3 * 2 * (H / 64) * 64;
+    hipLaunchKernelGGL(pack_cluster_fwd_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)out, H);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
 
 int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s) {
     const long n = (long)(H / 32) * (H / 16) * 3 * 64;
@@ -445,8 +517,10 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
     const size_t lds = EXCLUSIVE_LDS;
     static bool attr_f = false;
     if (!attr_f) {
-        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_f = true;
     }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
@@ -455,8 +529,10 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
         // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
         if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
         dim3 grid(NC * p.nbtp);
-        if (a.H == 128) hipLaunchKernelGGL(gru_fwd_cluster_r1<4>, grid, dim3(CT), lds, a.stream, p);
-        else hipLaunchKernelGGL(gru_fwd_cluster_r1<8>, grid, dim3(CT), lds, a.stream, p);
+        if (a.H == 128) { if (a.split) hipLaunchKernelGGL((gru_fwd_cluster_r1<4, true>), grid, dim3(CT), lds, a.stream, p);
+                          else hipLaunchKernelGGL((gru_fwd_cluster_r1<4, false>), grid, dim3(CT), lds, a.stream, p); }
+        else            { if (a.split) hipLaunchKernelGGL((gru_fwd_cluster_r1<8, true>), grid, dim3(CT), lds, a.stream, p);
+                          else hipLaunchKernelGGL((gru_fwd_cluster_r1<8, false>), grid, dim3(CT), lds, a.stream, p); }
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
