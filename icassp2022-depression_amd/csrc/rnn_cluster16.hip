@@ -16,6 +16,7 @@ using namespace depc;
 
 // debug stamps go to LDS and are copied out after the sweep: a global store per stamp would sit in vmcnt and distort the
 // very waits being measured
+constexpr int RED_BLK = 4 * 80;      // floats per (wave, gate) partial-sum fragment in LDS, see gru_fwd_cluster16
 #define DEP_STAMP(slot) do { if (tr && t >= 100 && t < 104) trl[(t - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 struct F16 {
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
     unsigned short* hs_hi = reinterpret_cast<unsigned short*>(smem);
     unsigned short* hs_lo = hs_hi + BT * LDHB;
     float* red = smem + hs_floats;                    // [4 waves][3 gates][64 lanes][4]
-    float* gbuf = red + 4 * 3 * 64 * 4;               // [2 parities][3 gates][16 utterances][16 units]
+    float* gbuf = red + 4 * 3 * RED_BLK;              // [2 parities][3 gates][16 utterances][16 units]
     float* obuf = gbuf + 2 * 768;                     // [2 parities][h, r, z, n, hn][16 utterances][16 units]
     for (int i = tid; i < hs_floats; i += CT + 64) hs[i] = 0.f;
 
@@ -120,7 +121,10 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
     unsigned* tflags = p.flags + bt * NC;
     const int hshift = __ffs(H) - 1;
     // where the finalising thread finds its element inside the fragment-ordered partial sums
-    const int rsrc_lane = (fu >> 2) * 16 + fj, rsrc_e = fu & 3;
+    // (fragment lane (fu>>2)*16 + fj, register fu&3).  A fragment block is stored as 4 quads of 16 lanes x 4 floats with 16
+    // floats of padding after each quad: unpadded, the 32 lanes of a read group hit 8 banks 4 ways (measured: 42 % of
+    // the kernel's LDS cycles were bank-conflict cycles)
+    const int rsrc_off = (fu >> 2) * 80 + fj * 4 + (fu & 3);
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * NC, NC, c, p.status);
     if (sx < 0) return;
     const bool fast = sx == 1;
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
         }
         DEP_STAMP(1);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + ((w * 3 + g) * 64 + lane) * 4) = acc[g];
+        for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + (w * 3 + g) * RED_BLK + (lane >> 4) * 80 + (lane & 15) * 4) = acc[g];
         bar_lds();
         DEP_STAMP(2);
         float tot[3];
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
         for (int g = 0; g < 3; ++g) {
             float s = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) s += red[((ww * 3 + g) * 64 + rsrc_lane) * 4 + rsrc_e];
+            for (int ww = 0; ww < 4; ++ww) s += red[(ww * 3 + g) * RED_BLK + rsrc_off];
             tot[g] = s;
         }
         const float r = fast_sigmoid(gin[0] + tot[0] + bh[0]);
@@ -495,7 +499,7 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
-    const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 3 * 64 * 4 + 2 * 768 + 2 * 1280 + 64) * sizeof(float);
+    const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 3 * RED_BLK + 2 * 768 + 2 * 1280 + 64) * sizeof(float);
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
