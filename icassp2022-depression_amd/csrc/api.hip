@@ -229,11 +229,13 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
                 rc = dep_pack_cluster_lstm_split(wl[1], R + lo.wp[l][dd], d->training ? R + lo.wpT[l][dd] : nullptr, H, s);
                 if (rc) return rc;
             } else {
-                if (mfma) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
+                const bool split_bwd = lo.cluster && d->cell == DEP_CELL_GRU && !lo.cluster16_bwd && sweep_split_mode();
+                // the fp32 fragment images are only needed by kernels that are not running on split-precision images
+                const bool need_f32 = mfma && !((split_fwd || split_fwd32) && (split_bwd || !d->training));
+                if (need_f32) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
                 if (split_fwd) { rc = dep_pack_cluster16_fwd_split(wl[1], R + lo.wp[l][dd], H, s); if (rc) return rc; }
                 if (split_fwd32) { rc = dep_pack_cluster_fwd_split(wl[1], R + lo.wp[l][dd], H, s); if (rc) return rc; }
                 if (lo.cluster && d->training) {     // the cluster backward wants its own member-sliced image
-                    const bool split_bwd = d->cell == DEP_CELL_GRU && !lo.cluster16_bwd && sweep_split_mode();
                     rc = lo.cluster16_bwd ? dep_pack_cluster16_bwd(wl[1], R + lo.wpT[l][dd], H, s)
                        : split_bwd ? dep_pack_cluster_bwd_split(wl[1], R + lo.wpT[l][dd], H, s)
                                    : dep_pack_cluster_bwd(wl[1], R + lo.wpT[l][dd], G, H, s);
