@@ -157,6 +157,9 @@ bool dep_cluster_lstm_ok(int H, int B, int dirs);
 size_t dep_cluster_lstm_xbuf_bytes(int H, int B, int dirs);
 int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
 int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
+// Utterances one co-resident cluster launch may cover: `members` workgroups per 16-utterance tile, `per_cu` of them resident
+// per CU (rnn_cluster.hip; CU count from the device, DEP_NUM_CUS overrides), at most `max_wgs` workgroups (flag words).
+int dep_cluster_chunk(int members, int per_cu, int max_wgs);
 int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster16_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s);

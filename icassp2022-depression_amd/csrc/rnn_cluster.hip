@@ -38,6 +38,30 @@ __global__ void pack_cluster_bwd_kernel(const float* __restrict__ W, float* __re
 }  // namespace
 
 // ------------------------------------------------------------------------------- host side
+// Every member of every cluster of a launch must be resident at the same time (they wait for each other inside the launch),
+// so the number of tiles per launch follows the number of CUs actually present (a partitioned or harvested device has fewer
+// than 256); larger batches run as consecutive chunks.
+static int num_cus() {
+    static int n = -1;
+    if (n < 0) {
+        const char* e = getenv("DEP_NUM_CUS");
+        int dev = 0, v = 0;
+        if (e && atoi(e) > 0) n = atoi(e);
+        else if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+int dep_cluster_chunk(int members, int per_cu, int max_wgs) {
+    long wgs = (long)num_cus() * per_cu;
+    if (wgs > max_wgs) wgs = max_wgs;
+    long tiles = wgs / members;
+    if (tiles >= 8) tiles = tiles / 8 * 8;             // whole groups of 8 tiles: block id -> XCD stays member-invariant
+    if (tiles < 1) tiles = 1;
+    return (int)tiles * BT;
+}
+
 bool dep_cluster_ok(int cell, int H, int B, int dirs) {
     (void)B; (void)dirs;                              // any batch: the launchers chunk it
     return cell == DEP_CELL_GRU && (H == 128 || H == 256);     // KCH = H/32 in {4,8}; NTW = H/64 in {2,4}
@@ -46,7 +70,7 @@ bool dep_cluster_ok(int cell, int H, int B, int dirs) {
 // header + the largest (backward) exchange of one launch chunk
 size_t dep_cluster_xbuf_bytes(int cell, int H, int B, int dirs) {
     if (!dep_cluster_ok(cell, H, B, dirs)) return 0;
-    const int NC = H / 32, CH = 256 / NC * BT;
+    const int NC = H / 32, CH = dep_cluster_chunk(NC, 1, 256);
     const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
     return 16384 + (size_t)2 * nbtp * NC * BT * H * sizeof(float) * 2;
 }

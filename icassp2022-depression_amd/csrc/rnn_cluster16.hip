@@ -482,8 +482,9 @@ int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s) 
 }
 
 int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
-    // co-residency bounds a launch to 512 workgroups = 32 tiles = 512 utterances; larger batches run chunk after chunk
-    const int NC = a.H / 16, CH = 512;
+    // co-residency bounds a launch to two workgroups per CU (512 = 32 tiles = 512 utterances on a full MI355X); larger
+    // batches run chunk after chunk
+    const int NC = a.H / 16, CH = dep_cluster_chunk(NC, 2, 512);
     const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     F16 p{};
     p.B = a.B; p.T = a.T; p.H = a.H;
@@ -513,7 +514,7 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
 }
 
 int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
-    const int NC = a.H / 16, CH = 512, nbt = dep_cdiv(a.B, BT);
+    const int NC = a.H / 16, CH = dep_cluster_chunk(NC, 2, 512), nbt = dep_cdiv(a.B, BT);
     const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     B16 p{};
     p.B = a.B; p.T = a.T; p.H = a.H;

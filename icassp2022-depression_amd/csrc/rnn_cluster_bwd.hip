@@ -495,7 +495,7 @@ int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t
 
 int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
     DEP_CHECK_ARG(dep_cluster_ok(a.cell, a.H, a.B, a.dirs) && xbuf && xbuf_bytes >= dep_cluster_xbuf_bytes(a.cell, a.H, a.B, a.dirs));
-    const int NC = a.H / 32, CH = 256 / NC * BT;      // one workgroup per CU: 256 / NC tiles per launch, larger batches in chunks
+    const int NC = a.H / 32, CH = dep_cluster_chunk(NC, 1, 256);      // one workgroup per CU: 256 / NC tiles per launch, larger batches in chunks
     const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     F2 p{};
     p.B = a.B; p.T = a.T; p.H = a.H;
@@ -540,7 +540,7 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
 
 int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
     DEP_CHECK_ARG(dep_cluster_ok(a.cell, a.H, a.B, a.dirs) && xbuf && xbuf_bytes >= dep_cluster_xbuf_bytes(a.cell, a.H, a.B, a.dirs));
-    const int NC = a.H / 32, CH = 256 / NC * BT, nbt = dep_cdiv(a.B, BT);
+    const int NC = a.H / 32, CH = dep_cluster_chunk(NC, 1, 256), nbt = dep_cdiv(a.B, BT);
     const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     P2 p{};
     p.B = a.B; p.T = a.T; p.H = a.H;

@@ -447,13 +447,13 @@ bool dep_cluster_lstm_ok(int H, int B, int dirs) {
 }
 
 size_t dep_cluster_lstm_xbuf_bytes(int H, int B, int dirs) {
-    const int NC = H / 32, CH = 256 / (dirs * NC) * BT;
+    const int NC = H / 32, CH = dep_cluster_chunk(dirs * NC, 1, 256);
     const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
     return PAYLOAD_OFF + (size_t)2 * dirs * nbtp * NC * BT * H * sizeof(float) + 256;
 }
 
 int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
-    const int NC = a.H / 32, CH = 256 / (a.dirs * NC) * BT;      // one workgroup per CU per launch; larger batches in chunks
+    const int NC = a.H / 32, CH = dep_cluster_chunk(a.dirs * NC, 1, 256);      // one workgroup per CU per launch; larger batches in chunks
     const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     LF p{};
     p.B = a.B; p.T = a.T; p.H = a.H; p.dirs = a.dirs;
@@ -482,7 +482,7 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
 }
 
 int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
-    const int NC = a.H / 32, CH = 256 / (a.dirs * NC) * BT, nbt = dep_cdiv(a.B, BT);
+    const int NC = a.H / 32, CH = dep_cluster_chunk(a.dirs * NC, 1, 256), nbt = dep_cdiv(a.B, BT);
     const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
     LB p{};
     p.B = a.B; p.T = a.T; p.H = a.H; p.dirs = a.dirs;
