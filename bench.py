@@ -6,12 +6,18 @@ AdamW, dropout on) of the audio GRU-256 x2 classifier on synthetic (B,T,F) = (51
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload audio_gru|text_bilstm|fusion]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under torch.distributed.run (one rank per
+GPU, 127.0.0.1 rendezvous); the process group's size must equal --gpus or the run aborts.
+
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the persistent recurrent sweep with the largest
-total time): its algorithmic bytes and flops per launch over its mean launch duration, measured
-with HIP events on the launch stream during the timed region, against the HBM peak and against the peak of the matrix
-pipe the sweep runs on (fp32 MFMA in exact mode; the bf16 pipe / 3 for the 3-term split).  The roof the kernel sits
-closer to is reported as `bound`; both fractions are kept in the object.  `cpu_baseline` (N=1 only) times the same train step on the host
-cores with stock torch.nn (oracle/torch_cpu_baseline.py, validated against the reference's fixtures).
+total time): SURVEY 8(d)'s algorithmic flops per launch over its mean launch duration, measured with HIP events on the
+launch stream during the timed region, against the peak of the matrix pipe the sweep runs on (fp32 MFMA in exact mode; the
+bf16 pipe / 3 for the 3-term split) -- 8(d) shows the path is matrix-pipe bound, not HBM bound.  Beside it: `achieved_hbm`
+with 8(d)'s compulsory bytes AND this design's bytes (both labelled), the serial floor (dependent steps at 1 us), and
+`traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), refused when the
+kernel sources changed since they were measured.  `eval_forward` is the forward-only rate.  `cpu_baseline` (N=1 only)
+times the same step on the host cores with stock torch.nn (oracle/torch_cpu_baseline.py, validated against the reference's
+fixtures): median of 5 steps after 2 warm-ups.
 """
 import argparse
 import json
@@ -50,6 +56,38 @@ def usable_cores():
     return max(1, n)
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(n, argv):
+    """`bench.py --gpus N` started as a plain process: become N ranks (one per GPU) of one torch.distributed.run job."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ); env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.execvpe(cmd[0], cmd, env)
+
+
+def launch_check(args):
+    """CPU-testable part of the multi-rank launch (tests/test_host_cpu.py): join the group with the requested backend,
+    check its size against --gpus, all-reduce one number, print one JSON line from rank 0."""
+    from icassp2022_depression_amd import parallel
+    parallel.init_from_env(args.backend)
+    world = parallel.world_size()
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the process group has {world} ranks')
+    t = torch.ones(1)
+    if args.backend == 'nccl':
+        t = t.cuda()
+    parallel.all_reduce_sum(t)
+    parallel.barrier()
+    if parallel.rank() == 0:
+        print(json.dumps({'launch_check': True, 'world': world, 'sum': float(t.item()), 'backend': args.backend}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -57,16 +95,40 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='audio_gru', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (gloo: launch check on CPU)')
+    ap.add_argument('--launch-check', action='store_true', help='only exercise the N-rank launch + one all-reduce')
     args = ap.parse_args()
+
+    world_env = int(os.environ.get('WORLD_SIZE', '0'))
+    if args.gpus > 1 and world_env == 0:
+        relaunch_under_torchrun(args.gpus, sys.argv[1:])          # does not return
+    if args.launch_check:
+        return launch_check(args)
 
     from icassp2022_depression_amd import _lib as L, nn, parallel
     import importlib
-    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    comm_kind = 'none'
     if world_env > 1:
         parallel.init_from_env('nccl')
+        # gradient transport: the C-ABI's own RCCL communicator (per-layer ranges overlapped with the backward pass); if it
+        # cannot be built on EVERY rank the job falls back -- visibly, in `config.backend` -- to torch.distributed's all-reduce
+        ok = 1
+        try:
+            ok = 1 if parallel.init_native_comm() is not None else 0
+        except Exception as e:                                   # noqa: BLE001
+            print(f'[rank {os.environ.get("RANK")}] native RCCL communicator failed: {e}', file=sys.stderr)
+            ok = 0
+        import torch.distributed as dist
+        flag = torch.tensor([ok], device='cuda'); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            comm_kind = 'rccl via dep_comm_* (layer ranges overlapped with backward)'
+        else:
+            parallel.destroy_native_comm()
+            comm_kind = 'rccl via torch.distributed (single bucket after backward)'
     rank, world = parallel.rank(), parallel.world_size()
-    if world != args.gpus and rank == 0:
-        print(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the process group has {world} ranks '
+                         f'(WORLD_SIZE={os.environ.get("WORLD_SIZE")}): refusing to report an N={args.gpus} number')
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(dev)
 
@@ -130,6 +192,18 @@ def main():
     dt = float(tmax.item())
     final_loss = loss.item()
 
+    # forward-only (evaluate) rate, outside the headline region: eval-mode kernels, nothing saved for a backward
+    model.eval()
+    eval_fn = (lambda: model.pretrained_feature((xa, xt))) if args.workload == 'fusion' else (lambda: model(x))
+    eval_fn(); torch.cuda.synchronize()
+    n_eval = max(3, min(args.steps, 10))
+    t1 = time.perf_counter()
+    for _ in range(n_eval):
+        eval_fn()
+    torch.cuda.synchronize()
+    eval_ms = (time.perf_counter() - t1) / n_eval * 1e3
+    model.train()
+
     if rank != 0:
         return
     ms_per_step = dt / args.steps * 1e3
@@ -145,38 +219,57 @@ def main():
         G, dirs, H = 4, 2, 128                                # the text encoder's hidden size in every workload
     else:
         G, dirs = 3, 1
-    sweep_flops = 2.0 * B * T * (G * H) * H * dirs           # one layer sweep launch (fwd or bwd): gates x H MACs
-    # algorithmic HBM bytes per (utterance, time step) of one sweep launch, averaged over the two layers:
-    #   GRU fwd : gi 12H + y 4H + saved r,z,n,hn 16H + dropped y 4H (layer 0 only)          = 34H
-    #   GRU bwd : saved 16H + h_{t-1} 4H + dy 4H (layer 0 only) + dgi 12H + dghn 4H         = 38H
-    #   LSTM fwd: (gi 16H + y 4H + gates 16H + c 4H) x 2 dirs + dropped y 8H (layer 0 only) = 84H
-    #   LSTM bwd: (gates 16H + c_t 4H + c_{t-1} 4H + dy 4H + dgi 16H) x 2 dirs              = 88H
-    #   fusion (encoders forward only, nothing saved): GRU gi 12H + y 4H + dropped y 4H/2 = 18H ; LSTM (16H + 4H) x 2 + 4H = 44H
-    per_ut = ({'gru_fwd_sweep': 18 * H, 'lstm_fwd_sweep': 44 * H} if args.workload == 'fusion' else
-              {'gru_fwd_sweep': 34 * H, 'gru_bwd_sweep': 38 * H, 'lstm_fwd_sweep': 84 * H, 'lstm_bwd_sweep': 88 * H})[dom]
-    sweep_bytes = float(per_ut) * B * T
+    launches_per_step = sweeps[dom][1] / args.steps          # 2 for per-layer sweeps, 1 for a launch that carries both layers
+    layers_per_launch = 2.0 / launches_per_step
+    # SURVEY 8(d) algorithmic work of ONE launch of the dominant sweep: recurrent flops 2 * T * (G H) * H per utterance, layer
+    # and direction; COMPULSORY HBM bytes per (utterance, step, layer, direction): the hidden sequence once -- written by the
+    # forward sweep, read by the backward sweep (8d: "hidden sequences written once in fwd and read once in bwd, nothing else,
+    # gates recomputed") = 4H bytes in fp32.  The DESIGN bytes count what this implementation chose to move instead (saved
+    # gate tensors, the materialised input projection and its gradient), DESIGN.md section 4.
+    sweep_flops = 2.0 * B * T * (G * H) * H * dirs * layers_per_launch
+    fusion = args.workload == 'fusion'
+    design_per_ut = ({'gru_fwd_sweep': 18 * H, 'lstm_fwd_sweep': 44 * H} if fusion else
+                     {'gru_fwd_sweep': 34 * H, 'gru_bwd_sweep': 38 * H, 'lstm_fwd_sweep': 84 * H, 'lstm_bwd_sweep': 88 * H})[dom]
+    compulsory_per_ut = 4 * H * dirs
+    design_bytes = float(design_per_ut) * B * T * layers_per_launch
+    compulsory_bytes = float(compulsory_per_ut) * B * T * layers_per_launch
     split = L.get_gemm_mode() == 1                           # the cluster sweeps follow the GEMM precision mode
     mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-    tflops = sweep_flops / (dom_ms * 1e-3) / 1e12
-    gbs = sweep_bytes / (dom_ms * 1e-3) / 1e9
-    frac_mfma, frac_hbm = tflops / mfma_peak, gbs / PEAK_HBM_GBS
-    traffic = None
+    sec = dom_ms * 1e-3
+    tflops = sweep_flops / sec / 1e12
+    frac_mfma = tflops / mfma_peak
+    # serial floor: the dependent recurrent steps of this launch at 1 us per hand-off
+    serial_steps = T + (layers_per_launch - 1)
+    serial_floor_ms = serial_steps * 1e-3
+    traffic, traffic_note = None, 'no PMC record for this workload / kernel'
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
-        except Exception:
-            traffic = None
-    if frac_hbm >= frac_mfma:
-        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': round(frac_hbm, 4), 'traffic': traffic}
-    else:
-        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tflops, 3), 'peak': round(mfma_peak, 1),
-                    'unit': 'TFLOP/s', 'frac': round(frac_mfma, 4), 'traffic': traffic}
-    roofline.update({'bytes_per_launch': sweep_bytes, 'flops_per_launch': sweep_flops, 'avg_launch_ms': round(dom_ms, 4),
-                     'frac_hbm': round(frac_hbm, 4), 'frac_mfma': round(frac_mfma, 4),
-                     'mfma_pipe': 'bf16 x3 split' if split else 'fp32',
-                     'kernels_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in cats.items()}})
+    try:
+        rec = json.load(open(tpath))
+        stamp = open(os.path.join(ROOT, 'icassp2022-depression_amd', 'libdep_rnn.so.stamp')).read().strip()
+        ent = rec.get('workloads', {}).get(args.workload, {}).get(dom)
+        if ent is not None and rec.get('kernel_digest') == stamp:
+            traffic, traffic_note = ent, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit {rec.get('commit')}, same kernel digest"
+        elif ent is not None:
+            traffic_note = 'PMC record is from other kernel sources (digest mismatch): refused'
+    except Exception:
+        pass
+    # intensity is far above the ridge, so the matrix pipe is the binding roof of this kernel; the HBM fractions
+    # (compulsory and design bytes) and the serial floor are reported beside it.
+    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tflops, 3), 'peak': round(mfma_peak, 1), 'unit': 'TFLOP/s',
+                'frac': round(frac_mfma, 4), 'traffic': traffic, 'traffic_note': traffic_note,
+                'mfma_pipe': 'bf16 x3 split (peak = bf16 dense / 3)' if split else 'fp32',
+                'flops_per_launch': sweep_flops, 'avg_launch_ms': round(dom_ms, 4), 'launches_per_step': launches_per_step,
+                'achieved_mfma': {'tflops': round(tflops, 3), 'frac': round(frac_mfma, 4)},
+                'achieved_hbm': {'compulsory_bytes_per_launch': compulsory_bytes,
+                                 'compulsory_gbs': round(compulsory_bytes / sec / 1e9, 1),
+                                 'compulsory_frac': round(compulsory_bytes / sec / 1e9 / PEAK_HBM_GBS, 4),
+                                 'design_bytes_per_launch': design_bytes,
+                                 'design_gbs': round(design_bytes / sec / 1e9, 1),
+                                 'design_frac': round(design_bytes / sec / 1e9 / PEAK_HBM_GBS, 4),
+                                 'peak_gbs': PEAK_HBM_GBS},
+                'serial_floor': {'dependent_steps_per_launch': serial_steps, 'us_per_step': round(dom_ms * 1e3 / serial_steps, 3),
+                                 'floor_ms_at_1us': round(serial_floor_ms, 4), 'serial_floor_frac': round(serial_floor_ms / dom_ms, 4)},
+                'kernels_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in cats.items()}}
     train_flops_per_utt = {'audio_gru': 1.4156e9, 'text_bilstm': 2.831e9,           # SURVEY 8(d); fusion = the two forwards
                            'fusion': (1.4156e9 + 2.831e9) / 3.0}[args.workload]
     step_tflops = train_flops_per_utt * value / 1e12 / world
@@ -190,18 +283,30 @@ def main():
            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': (f'{modname}.{cls} train step, B={B}/GPU T={T} F={F} H={H_model} L=2 dropout={cfg["dropout"]} '
-                                   + ('Adam, MyLoss (split-weight CE)' if args.workload == 'fusion' else 'AdamW, CE-on-softmax')),
-                      'global_batch': B * world, 'parallelism': f'dp{world}'},
-           'final_loss': round(final_loss, 6), 'roofline': roofline}
+                                   + ('Adam, MyLoss (split-weight CE)' if fusion else 'AdamW, CE-on-softmax')),
+                      'global_batch': B * world, 'parallelism': f'dp{world}', 'ranks': world,
+                      'backend': comm_kind},
+           'final_loss': round(final_loss, 6),
+           'eval_forward': {'value': round(B / (eval_ms * 1e-3), 1), 'unit': 'utterances/s', 'ms_per_batch': round(eval_ms, 3),
+                            'note': 'forward only (evaluate), rank 0, outside the headline region'},
+           'roofline': roofline}
 
-    if world == 1 and not args.no_cpu_baseline and args.workload != 'fusion':      # (no CPU port of the fusion step is kept)
+    if world == 1 and not args.no_cpu_baseline:
+        import platform
         from oracle import torch_cpu_baseline as tb
         threads = usable_cores()
-        kind = 'audio' if args.workload == 'audio_gru' else 'text'
-        ups, sec, nthr = tb.time_train_step(kind, B, T, F, H, steps=3, warmup=1, threads=threads, lr=cfg['learning_rate'])
+        kind = {'audio_gru': 'audio', 'text_bilstm': 'text', 'fusion': 'fusion'}[args.workload]
+        # bounded sample: median of 5 full-size steps after 2 warm-ups (audio ~2.6 s/step, text ~3.3 s, fusion forward ~1.5 s)
+        ups, sec_step, nthr = tb.time_train_step(kind, B, T, F, H_model, steps=5, warmup=2, threads=threads, lr=cfg['learning_rate'])
+        cpu_model = ''
+        try:
+            cpu_model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
+        except Exception:
+            cpu_model = platform.processor()
         out['cpu_baseline'] = {'value': round(ups, 1), 'unit': 'utterances/s', 'cores': nthr, 'kind': 'port',
-                               'sample': f'same train step (stock torch.nn CPU, fp32), B={B} T={T}, median of 3 steps after 1 warm-up, '
-                                         f'{sec:.2f} s/step'}
+                               'cpu_model': cpu_model, 'torch': torch.__version__,
+                               'sample': f'same train step (stock torch.nn CPU, fp32), B={B} T={T}, median of 5 steps after 2 warm-ups, '
+                                         f'{sec_step:.2f} s/step'}
     print(json.dumps(out))
 
 

@@ -28,6 +28,14 @@ class RnnDesc(C.Structure):
 
 
 _P = C.c_void_p
+
+
+class GradSync(C.Structure):
+    """dep_grad_sync (include/dep_rnn.h): per-layer ranges of the flat gradient buffer for the overlapped all-reduce."""
+    _fields_ = [('comm', _P), ('comm_stream', _P), ('range_ptr', _P * 8), ('range_count', C.c_long * 8)]
+
+
+_BWD_ARGS = [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, C.POINTER(_P), _P, _P, C.c_size_t, _P, C.c_size_t, _P]
 _SIGS = {
     'dep_last_error': (C.c_char_p, []),
     'dep_version': (C.c_int, []),
@@ -39,8 +47,15 @@ _SIGS = {
     'dep_rnn_status': (C.c_int, [C.POINTER(RnnDesc), _P, _P]),
     'dep_rnn_workspace_xbuf_offset': (C.c_size_t, [C.POINTER(RnnDesc)]),
     'dep_rnn_forward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
-    'dep_rnn_backward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, C.POINTER(_P), _P, _P,
-                                   C.c_size_t, _P, C.c_size_t, _P]),
+    'dep_rnn_backward': (C.c_int, _BWD_ARGS),
+    'dep_rnn_backward_overlapped': (C.c_int, _BWD_ARGS + [C.POINTER(GradSync)]),
+    'dep_comm_unique_id': (C.c_int, [_P, C.c_size_t]),
+    'dep_comm_init': (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, _P, C.c_size_t, C.c_int]),
+    'dep_comm_world': (C.c_int, [_P]),
+    'dep_comm_rank': (C.c_int, [_P]),
+    'dep_comm_allreduce': (C.c_int, [_P, _P, C.c_long, _P]),
+    'dep_comm_allreduce_ranges': (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_long), C.c_int, _P]),
+    'dep_comm_destroy': (C.c_int, [_P]),
     'dep_gemm_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
     'dep_gemm_f32': (C.c_int, [C.c_int] * 5 + [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_float, C.c_int, C.c_int,
                                _P, C.c_size_t, _P]),
@@ -316,14 +331,18 @@ class Rnn:
                                        _ptr(self.reserve), self.reserve.numel() * 4, _ptr(self.workspace),
                                        self.workspace.numel() * 4, stream()), 'dep_rnn_forward')
 
-    def backward(self, x, weights, dweights, dy=None, dpooled=None, dh_n=None, dx=None):
+    def backward(self, x, weights, dweights, dy=None, dpooled=None, dh_n=None, dx=None, grad_sync=None):
+        """grad_sync: a GradSync (data parallel) -> dep_rnn_backward_overlapped: layer l's range of the flat gradient
+        buffer is all-reduced on the communication stream while the layers below are still in their sweeps."""
         for i, (w, g) in enumerate(zip(weights, dweights)):
             self._warr[i] = w.data_ptr()
             self._garr[i] = g.data_ptr()
-        check(self.lib.dep_rnn_backward(C.byref(self.desc), _ptr(x), self._warr, _ptr(dy), _ptr(dpooled), _ptr(dh_n),
-                                        self._garr, _ptr(dx), _ptr(self.reserve), self.reserve.numel() * 4,
-                                        _ptr(self.workspace), self.workspace.numel() * 4, stream()),
-              'dep_rnn_backward')
+        args = (C.byref(self.desc), _ptr(x), self._warr, _ptr(dy), _ptr(dpooled), _ptr(dh_n), self._garr, _ptr(dx),
+                _ptr(self.reserve), self.reserve.numel() * 4, _ptr(self.workspace), self.workspace.numel() * 4, stream())
+        if grad_sync is None:
+            check(self.lib.dep_rnn_backward(*args), 'dep_rnn_backward')
+        else:
+            check(self.lib.dep_rnn_backward_overlapped(*args, C.byref(grad_sync)), 'dep_rnn_backward_overlapped')
 
 
 PROF_CATS = ('gru_fwd_sweep', 'gru_bwd_sweep', 'lstm_fwd_sweep', 'lstm_bwd_sweep', 'gemm_nt', 'gemm_nn', 'gemm_tn')

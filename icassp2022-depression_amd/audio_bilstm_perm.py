@@ -72,6 +72,10 @@ def train(epoch):
     for lo, hi in _common.minibatches(X_train.shape[0], config['batch_size']):
         a, b = _common.rank_slice(lo, hi)
         parallel.set_global_count(hi - lo)
+        if b <= a:                                  # empty shard of a small (ragged) mini-batch: zero-contribution step
+            total_loss += nn.empty_shard_step(model, optimizer).item()
+            pred = np.hstack((pred, parallel.all_reduce_sum(torch.zeros(hi - lo, device=model.device)).cpu().numpy()))
+            continue
         x = torch.from_numpy(np.ascontiguousarray(X_train[a:b])).type(torch.FloatTensor)
         y = torch.from_numpy(np.ascontiguousarray(Y_train[a:b])).type(torch.FloatTensor)
         optimizer.zero_grad()

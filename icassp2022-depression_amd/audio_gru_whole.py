@@ -77,8 +77,10 @@ def train(epoch, train_idxs):
     for lo, hi in _common.minibatches(X_train.shape[0], config['batch_size']):
         a, b = _common.rank_slice(lo, hi)
         parallel.set_global_count(hi - lo)
-        if b <= a:
-            raise RuntimeError('mini-batch smaller than the data-parallel world size')
+        if b <= a:                                  # this rank owns no row of a small (ragged) mini-batch: zero-contribution step
+            total_loss += nn.empty_shard_step(model, optimizer).item()
+            correct += int(parallel.all_reduce_sum(torch.zeros((), dtype=torch.int64, device=model.device)).item())
+            continue
         x = torch.from_numpy(np.ascontiguousarray(X_train[a:b])).type(torch.FloatTensor)
         y = torch.from_numpy(np.ascontiguousarray(Y_train[a:b]))
         optimizer.zero_grad()

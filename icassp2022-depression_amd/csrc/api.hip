@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <utility>
 #include <vector>
 #include "dep_common.h"
@@ -196,6 +197,28 @@ static bool sweep_split_mode() {
     return !pin && dep_get_gemm_mode() == 1;
 }
 
+// Precision mode of the packed recurrent-weight images a reserve holds (host-side record, no device traffic): the
+// backward must run the kernels of the SAME mode, so dep_rnn_backward refuses a reserve whose forward ran in the other
+// mode (a caller flipping dep_set_gemm_mode in between would otherwise get silently wrong gradients).  Small ring: the
+// newest record of a pointer wins; a reserve with no record (evicted after 256 other forwards) is trusted.
+namespace {
+struct ModeRec { const void* p; int mode; };
+ModeRec g_modes[256];
+int g_mode_next = 0;
+std::mutex g_mode_mu;
+void record_reserve_mode(const void* reserve, int mode) {
+    std::lock_guard<std::mutex> lk(g_mode_mu);
+    for (auto& r : g_modes) if (r.p == reserve) { r.mode = mode; return; }
+    g_modes[g_mode_next] = {reserve, mode};
+    g_mode_next = (g_mode_next + 1) % 256;
+}
+int lookup_reserve_mode(const void* reserve) {
+    std::lock_guard<std::mutex> lk(g_mode_mu);
+    for (auto& r : g_modes) if (r.p == reserve) return r.mode;
+    return -1;
+}
+}  // namespace
+
 extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const float* const* weights, float* y,
                                float* pooled, float* h_n, void* reserve, size_t reserve_bytes, void* workspace,
                                size_t workspace_bytes, void* stream) {
@@ -217,6 +240,9 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     const bool split_fwd32 = lo.cluster && !lo.cluster16 && d->cell == DEP_CELL_GRU && sweep_split_mode();     // 32-unit members
     const bool split_lstm = lo.cluster && d->cell == DEP_CELL_LSTM && sweep_split_mode();
     int rc;
+    if (lo.cluster) { rc = dep_cluster_reset_status(W + lo.xbuf, s); if (rc) return rc; }
+    // the recurrent-weight images packed below are precision-mode specific: remember which mode this reserve holds
+    record_reserve_mode(reserve, sweep_split_mode() ? 1 : 0);
     for (int l = 0; l < L; ++l) {
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
         const int Kl = l == 0 ? d->F : D * H;
@@ -283,10 +309,10 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     return DEP_OK;
 }
 
-extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const float* const* weights, const float* dy,
-                                const float* dpooled, const float* dh_n, float* const* dweights, float* dx,
-                                void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
-                                void* stream) {
+static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float* const* weights, const float* dy,
+                             const float* dpooled, const float* dh_n, float* const* dweights, float* dx,
+                             void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                             void* stream, const dep_grad_sync* gs) {
     Layout lo;
     DEP_CHECK_ARG(make_layout(d, lo));
     DEP_CHECK_ARG(d->training);
@@ -296,6 +322,15 @@ extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const flo
     if (reserve_bytes < lo.reserve_floats * sizeof(float) || workspace_bytes < lo.ws_floats * sizeof(float)) {
         dep_set_error("dep_rnn_backward: reserve/workspace too small");
         return DEP_ERR_WORKSPACE;
+    }
+    if (lo.cluster) {
+        const int fm = lookup_reserve_mode(reserve);
+        if (fm >= 0 && fm != (sweep_split_mode() ? 1 : 0)) {
+            dep_set_error("dep_rnn_backward: the reserve was produced by a forward in %s mode, the current mode is %s "
+                          "(dep_set_gemm_mode / DEP_SWEEP_MODE must not change between a forward and its backward)",
+                          fm ? "bf16x3" : "f32", fm ? "f32" : "bf16x3");
+            return DEP_ERR_ARG;
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     float* R = (float*)reserve; float* W = (float*)workspace;
@@ -338,8 +373,16 @@ extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const flo
         rc = dep_finish_db(a, dbi, dbh);
         if (rc) return rc;
         float* dxl = l == 0 ? dx : W + lo.dx[l & 1];
+        // dX (B*T, Kl) (+)= dG * W_ih first: it is the only product the next layer's sweep waits for
+        if (dxl) {
+            for (int dd = 0; dd < D; ++dd) {
+                const float* const* wl = weights + (size_t)(l * D + dd) * 4;
+                rc = dep_gemm_internal(0, 0, BTr, Kl, G * H, dgi + (size_t)dd * G * H, D * G * H, wl[0], Kl, dxl, Kl, nullptr,
+                                       dd == 0 ? 0.f : 1.f, 0, 0, nullptr, 0, s);
+                if (rc) return rc;
+            }
+        }
         for (int dd = 0; dd < D; ++dd) {
-            const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             float* const* gl = dweights + (size_t)(l * D + dd) * 4;
             const float* dg = dgi + (size_t)dd * G * H;
             const int ldg = D * G * H;
@@ -359,13 +402,30 @@ extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const flo
                 rc = dep_gemm_internal(1, 0, 4 * H, H, BTr, dg, ldg, yl, D * H, gl[1], H, nullptr, 0.f, T, shift, gws, gwsb, s);
                 if (rc) return rc;
             }
-            // dX (B*T, Kl) (+)= dG * W_ih
-            if (dxl) {
-                rc = dep_gemm_internal(0, 0, BTr, Kl, G * H, dg, ldg, wl[0], Kl, dxl, Kl, nullptr, dd == 0 ? 0.f : 1.f, 0, 0,
-                                       nullptr, 0, s);
-                if (rc) return rc;
-            }
+        }
+        // data parallel: layer l's gradients are complete -- hand their range of the caller's flat gradient buffer to RCCL on
+        // the communication stream; it travels over xGMI while the layers below are still in their backward sweeps
+        if (gs && gs->comm && gs->range_ptr[l] && gs->range_count[l] > 0) {
+            rc = dep_comm_enqueue_after((dep_comm*)gs->comm, gs->range_ptr[l], gs->range_count[l], s, (hipStream_t)gs->comm_stream);
+            if (rc) return rc;
         }
     }
     return DEP_OK;
+}
+
+extern "C" int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const float* const* weights, const float* dy,
+                                const float* dpooled, const float* dh_n, float* const* dweights, float* dx,
+                                void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    return rnn_backward_impl(d, x, weights, dy, dpooled, dh_n, dweights, dx, reserve, reserve_bytes, workspace, workspace_bytes,
+                             stream, nullptr);
+}
+
+extern "C" int dep_rnn_backward_overlapped(const dep_rnn_desc* d, const float* x, const float* const* weights, const float* dy,
+                                           const float* dpooled, const float* dh_n, float* const* dweights, float* dx,
+                                           void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                           void* stream, const dep_grad_sync* gs) {
+    DEP_CHECK_ARG(gs && gs->comm && gs->comm_stream && gs->comm_stream != stream);
+    return rnn_backward_impl(d, x, weights, dy, dpooled, dh_n, dweights, dx, reserve, reserve_bytes, workspace, workspace_bytes,
+                             stream, gs);
 }

@@ -160,6 +160,10 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
 // Utterances one co-resident cluster launch may cover: `members` workgroups per 16-utterance tile, `per_cu` of them resident
 // per CU (rnn_cluster.hip; CU count from the device, DEP_NUM_CUS overrides), at most `max_wgs` workgroups (flag words).
 int dep_cluster_chunk(int members, int per_cu, int max_wgs);
+// comm.hip: all-reduce of [buf, buf+n) on comm_stream after everything enqueued so far on `compute`
+int dep_comm_enqueue_after(dep_comm* c, float* buf, long n, hipStream_t compute, hipStream_t comm_stream);
+// clears the sticky status word of a cluster exchange buffer (once per dep_rnn_forward; the sweeps themselves never clear it)
+int dep_cluster_reset_status(void* xbuf, hipStream_t s);
 int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster16_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s);

@@ -75,6 +75,14 @@ size_t dep_cluster_xbuf_bytes(int cell, int H, int B, int dirs) {
     return 16384 + (size_t)2 * nbtp * NC * BT * H * sizeof(float) * 2;
 }
 
+// The status word (first 256 bytes of the exchange buffer header, see rnn_cluster_common.h) is raised by any sweep whose
+// bounded spin gave up and is STICKY: later sweeps of the same step see it at kernel entry and leave at once, so a failure
+// in the layer-0 forward is still there when the host reads dep_rnn_status after the whole step.
+int dep_cluster_reset_status(void* xbuf, hipStream_t s) {
+    if (hipMemsetAsync(xbuf, 0, 256, s) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+    return DEP_OK;
+}
+
 int dep_pack_cluster_bwd(const float* w_hh, float* out, int G, int H, hipStream_t s) {
     const long n = (long)G * H * H;
     hipLaunchKernelGGL(pack_cluster_bwd_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, out, G, H);

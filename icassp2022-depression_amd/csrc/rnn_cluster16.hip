@@ -76,6 +76,7 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
     const int LDHB = H + 8;                           // bf16 elements per row of a split plane (528-byte rows: conflict-free b128 reads)
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
     if (p.b0 + bt * BT >= p.B) return;
+    if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int fj = tid >> 4, fu = tid & 15;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster16(B16 p) {
     const int H = p.H, T = p.T, NC = H / 16, NTT = H / 16;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
     if (p.b0 + bt * BT >= p.B) return;
+    if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fj = tid >> 4, fu = tid & 15;
     const int col = 16 * c + fu;
@@ -504,8 +506,8 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
-        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
-        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
+        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
         if (a.split) hipLaunchKernelGGL((gru_fwd_cluster16<4, true>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
         else hipLaunchKernelGGL((gru_fwd_cluster16<4, false>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
         DEP_CHECK_LAUNCH();
@@ -535,8 +537,8 @@ int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbu
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
-        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
-        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
+        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
         hipLaunchKernelGGL(gru_bwd_cluster16<4>, dim3(NC * p.nbtp), dim3(CT), lds, a.stream, p);
         DEP_CHECK_LAUNCH();
     }

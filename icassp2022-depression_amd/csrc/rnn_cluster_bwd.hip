@@ -52,6 +52,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
     if (p.b0 + bt * BT >= p.B) return;
+    if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jl = tid >> 7, lp = (tid >> 1) & 63, half = tid & 1;
     const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;      // unit inside the member's 32
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
     if (p.b0 + bt * BT >= p.B) return;
+    if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4, jl = w >> 1, kh = w & 1;
     const int jt = c * 2 + jl;
@@ -526,8 +528,8 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
-        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
-        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
+        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
         dim3 grid(NC * p.nbtp);
         if (a.H == 128) { if (a.split) hipLaunchKernelGGL((gru_fwd_cluster_r1<4, true>), grid, dim3(CT), lds, a.stream, p);
                           else hipLaunchKernelGGL((gru_fwd_cluster_r1<4, false>), grid, dim3(CT), lds, a.stream, p); }
@@ -571,8 +573,8 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
-        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
-        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
+        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
         dim3 grid(NC * p.nbtp);
         if (a.H == 128) { if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<2, true>), grid, dim3(CT), lds, a.stream, p);
                           else hipLaunchKernelGGL((gru_bwd_cluster_r1<2, false>), grid, dim3(CT), lds, a.stream, p); }

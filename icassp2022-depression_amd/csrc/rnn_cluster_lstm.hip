@@ -47,6 +47,7 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
     const int LDHB = H + 8;                           // bf16 elements per row of a split plane
     const int bt = blockIdx.x % p.nbtp, dc = blockIdx.x / p.nbtp, c = dc % NC, dir = dc / NC;
     if (p.b0 + bt * BT >= p.B) return;
+    if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4, jl = w >> 1, kh = w & 1;
     const int jt = c * 2 + jl;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
     const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
     const int bt = blockIdx.x % p.nbtp, dc = blockIdx.x / p.nbtp, c = dc % NC, dir = dc / NC;
     if (p.b0 + bt * BT >= p.B) return;
+    if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jl = tid >> 7, lp = (tid >> 1) & 63, half = tid & 1;
     const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;
@@ -472,8 +474,8 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
-        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
-        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
+        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
         if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
         else hipLaunchKernelGGL((lstm_fwd_cluster<4, false>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
         DEP_CHECK_LAUNCH();
@@ -502,8 +504,8 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
-        // later chunks keep the status word of the earlier ones (dep_rnn_status reports any give-up of the whole sweep)
-        if (hipMemsetAsync((char*)xbuf + (b0 ? FLAG_OFF : 0), 0, PAYLOAD_OFF - (b0 ? FLAG_OFF : 0), a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
+        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
         if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
         else hipLaunchKernelGGL((lstm_bwd_cluster<2, false>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
         DEP_CHECK_LAUNCH();

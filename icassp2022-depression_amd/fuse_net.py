@@ -100,6 +100,10 @@ def train(model, epoch):
         a, b = _common.rank_slice(lo, hi)
         parallel.set_global_count(hi - lo)
         x, y = X_train[a:b], Y_train[a:b]
+        if b <= a:                                  # empty shard of a small mini-batch: zero-contribution step
+            total_loss += nn.empty_shard_step(model, optimizer).item()
+            pred = np.hstack((pred, parallel.all_reduce_sum(torch.zeros(hi - lo, device=model.device)).cpu().numpy()))
+            continue
         optimizer.zero_grad()
         text_feature, audio_feature = model.pretrained_feature(x)
         output = model(torch.cat((text_feature, audio_feature), dim=1))

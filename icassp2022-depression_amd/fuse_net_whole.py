@@ -108,6 +108,10 @@ def train(epoch, train_idxs):
     for lo, hi in _common.minibatches(len(X_train), config['batch_size']):
         x, y = _batch(X_train, Y_train, lo, hi)
         parallel.set_global_count(hi - lo)
+        if len(x) == 0:                             # empty shard of a small mini-batch (batch_size 2 < world): zero-contribution step
+            total_loss += nn.empty_shard_step(model, optimizer).item()
+            correct += int(parallel.all_reduce_sum(torch.zeros((), dtype=torch.int64, device=model.device)).item())
+            continue
         optimizer.zero_grad()
         text_feature, audio_feature = model.pretrained_feature(x)
         concat_x = torch.cat((text_feature, audio_feature), dim=1)

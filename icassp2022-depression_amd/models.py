@@ -192,18 +192,33 @@ class AudioGRU(nn.Module):
         self._saved = enc
         return nn.Output(out, self, z)
 
+    def sync_plan(self):
+        """Flat layout [l0 | l1 | .. | fc_audio | ln]: the top layer's range ends with the head (final before the stack's
+        backward starts); layer 0 of the classifier is final only after dep_ln_fold_bwd, with the LayerNorm pair."""
+        Lyr, px = self.rnn_layers, 'lstm_net_audio'
+        in_call, post = {}, []
+        for l in range(Lyr):
+            first, last = f'{px}.weight_ih_l{l}', ('fc_audio.4.bias' if l == Lyr - 1 else f'{px}.bias_hh_l{l}')
+            if l == 0 and self.variant == 'clf':
+                post.append(self._span(first, last)); post.append(self._span('ln.weight', 'ln.bias'))
+            else:
+                in_call[l] = self._span(first, last)
+        return in_call, post
+
     def backward(self, dz):
         x, xn, rnn = self._saved
         dpool = self._head.backward(dz)
         P = self._params
+        in_call, post = self.sync_plan()
+        gs = parallel.make_grad_sync(self, in_call)
         if self.variant == 'clf':
-            rnn.backward(xn, self._rnn_w_fold, self._rnn_g_fold, dpooled=dpool, dx=None)
+            rnn.backward(xn, self._rnn_w_fold, self._rnn_g_fold, dpooled=dpool, dx=None, grad_sync=gs)
             L.ln_fold_bwd(self._rnn_w[0], self._fold[2], self._fold[3], P['ln.weight'].data, P['ln.bias'].data,
                           self._rnn_g[0], self._rnn_g[2], P['ln.weight']._grad, P['ln.bias']._grad)
         else:
-            rnn.backward(xn, self._rnn_w, self._rnn_g, dpooled=dpool, dx=None)
+            rnn.backward(xn, self._rnn_w, self._rnn_g, dpooled=dpool, dx=None, grad_sync=gs)
         self._grad_ready = True
-        parallel.all_reduce_grads(self)
+        parallel.finish_grad_sync(self, in_call, post)
 
 
 class TextBiLSTM(nn.Module):
@@ -242,6 +257,17 @@ class TextBiLSTM(nn.Module):
     def check_health(self):
         self._rnns.check()
 
+    def sync_plan(self):
+        """Flat layout [attention | l0 (both directions) | l1 .. | fc_out]: the attention pair (final before the stack's
+        backward) rides with layer 0, the head with the top layer."""
+        Lyr, px = self.rnn_layers, 'lstm_net'
+        in_call = {}
+        for l in range(Lyr):
+            first = 'attention_layer.0.weight' if l == 0 else f'{px}.weight_ih_l{l}'
+            last = (self._fc[1] + '.bias') if l == Lyr - 1 else f'{px}.bias_hh_l{l}_reverse'
+            in_call[l] = self._span(first, last)
+        return in_call, []
+
     def encode(self, x, training, seed):
         B, T, F = x.shape
         P = self._params
@@ -273,9 +299,10 @@ class TextBiLSTM(nn.Module):
         dctx = self._head.backward(dz)
         dout, dh_n = L.attn_bwd(dctx, out, P['attention_layer.0.weight'].data, att, 2 * self.rnn_layers,
                                 P['attention_layer.0.weight']._grad, P['attention_layer.0.bias']._grad)
-        rnn.backward(x, self._rnn_w, self._rnn_g, dy=dout, dh_n=dh_n, dx=None)
+        in_call, post = self.sync_plan()
+        rnn.backward(x, self._rnn_w, self._rnn_g, dy=dout, dh_n=dh_n, dx=None, grad_sync=parallel.make_grad_sync(self, in_call))
         self._grad_ready = True
-        parallel.all_reduce_grads(self)
+        parallel.finish_grad_sync(self, in_call, post)
 
 
 class FusionNet(nn.Module):
@@ -425,6 +452,6 @@ class MyLoss:
             L.gemm(1, 0, Cc, Ht, B, dzt, Cc, text_feature, Ht, g, D)               # dW[:, :Ht] = dzt^T text
             L.gemm(1, 0, Cc, Ha, B, dza, Cc, audio_feature, Ha, g[:, Ht:], D)      # dW[:, Ht:] = dza^T audio
             model._grad_ready = True
-            parallel.all_reduce_grads(model)
+            parallel.finish_grad_sync(model, *model.sync_plan())
         return nn.Loss(val, bw if train else None, reduce=train and parallel.world_size() > 1,
                        health=getattr(model, 'check_health', None))

@@ -141,6 +141,19 @@ class Module:
         return self
 
     # -- helpers -------------------------------------------------------------------------
+    def _span(self, first, last):
+        """(start, count) of the contiguous run of live parameters from `first` to `last` in the flat gradient buffer."""
+        a, b = self._params[first], self._params[last]
+        start, end = a.offset, b.offset + (b.numel + 3) // 4 * 4
+        if not (a.live and b.live and 0 <= start < end <= self._n_live):
+            raise RuntimeError(f'gradient span {first}..{last} is not inside the live bucket')
+        return start, end - start
+
+    def sync_plan(self):
+        """({layer: (start, count)} reduced inside dep_rnn_backward_overlapped, [(start, count), ...] reduced after the
+        backward).  Default: the whole live bucket after the backward."""
+        return {}, [(0, self._n_live)]
+
     def live_grad_bucket(self):
         """The single contiguous gradient bucket the data-parallel all-reduce operates on."""
         return self._flat_grad[:self._n_live]
@@ -255,6 +268,20 @@ class SmoothL1Loss(_HeadLoss):
     """nn.SmoothL1Loss on the ReLU output (Regression/text_bilstm_perm.py:247)."""
     kind = L.LOSS_SMOOTHL1_RELU
     target_dtype = 'float'
+
+
+def empty_shard_step(model, optimizer):
+    """Data parallel, global mini-batch smaller than the world size: this rank owns no row of it.  It still joins every
+    collective of the step with a zero contribution (gradient ranges in the same order as the working ranks, the lazy loss
+    reduce in Loss.item) and applies the same optimizer update, so the replicas stay identical and nobody hangs."""
+    optimizer.zero_grad()
+    model.live_grad_bucket().zero_()
+    model._grad_ready = True
+    in_call, post = model.sync_plan()
+    parallel.reduce_zero_contribution(model, in_call, post)
+    optimizer.step()
+    val = torch.zeros(1, dtype=torch.float32, device=model.device)
+    return Loss(val, None, reduce=parallel.world_size() > 1)
 
 
 # ----------------------------------------------------------------------------- optimizers

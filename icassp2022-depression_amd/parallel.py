@@ -7,8 +7,15 @@ loss is a batch mean, so the path shards naturally:
   * every rank normalises its loss gradient by the GLOBAL batch size (`global_count`), so the SUM
     all-reduce of the single flat gradient bucket reproduces the reference's batch-mean gradient
     exactly, ragged last batches included;
-  * one collective per step: `all_reduce_grads(model)` on `model.live_grad_bucket()`
-    (3.4 MB audio / 6.4 MB text / 3 KB fusion) -- latency-bound, so one bucket, no ring tuning.
+  * the gradient exchange is a SUM all-reduce of the model's flat gradient buffer.  With the native RCCL communicator
+    (`init_native_comm`, the C-ABI's dep_comm_* entry points; default on GPUs) it is cut at layer boundaries and
+    overlapped with the backward pass: the top layer's range [layer L-1 | head] is enqueued on a communication stream as
+    soon as its weight gradients exist and travels over xGMI while the layers below are still in their backward sweeps
+    (dep_rnn_backward_overlapped); what becomes final later (layer 0, LayerNorm) follows as one grouped operation, and the
+    compute stream waits for the communication stream before the optimizer reads the gradients.  Without it (gloo tests,
+    DEP_COMM=torch) the whole bucket is reduced in one torch.distributed all-reduce after the backward.
+    Every rank issues the same sequence of collectives each step -- also a rank whose shard of a small mini-batch is
+    empty (`nn.empty_shard_step`).
 """
 import os
 
@@ -78,10 +85,127 @@ def all_reduce_sum(t):
 
 
 def all_reduce_grads(model):
-    """SUM all-reduce of the model's single contiguous live-gradient bucket (RCCL over xGMI)."""
+    """SUM all-reduce of the model's single contiguous live-gradient bucket (torch.distributed transport)."""
     d = _dist()
     if d and model._grad_ready:
         d.all_reduce(model.live_grad_bucket(), op=d.ReduceOp.SUM)
+
+
+# ----------------------------------------------------------------------------- native RCCL communicator (C-ABI)
+_native = {'comm': None, 'stream': None, 'world': 1}
+
+
+def init_native_comm(force_single=False):
+    """Create the RCCL communicator through the C-ABI (dep_comm_unique_id / dep_comm_init): rank 0 obtains the id, the
+    torch.distributed group (already initialised by init_from_env) carries it to the other ranks.  force_single builds a
+    one-rank communicator (tests on a single GPU)."""
+    import ctypes as C
+    from . import _lib as L
+    if _native['comm'] is not None:
+        return _native['comm']
+    d = _dist()
+    world, rk = world_size(), rank()
+    if world == 1 and not force_single:
+        return None
+    if os.environ.get('DEP_COMM', 'rccl') == 'torch':
+        return None
+    lib = L.load()
+    dev = torch.cuda.current_device()
+    idbuf = (C.c_char * 128)()
+    if rk == 0:
+        L.check(lib.dep_comm_unique_id(idbuf, 128), 'dep_comm_unique_id')
+    t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone().cuda()
+    if d and world > 1:
+        d.broadcast(t, src=0)
+    raw = bytes(t.cpu().numpy().tobytes())
+    comm = C.c_void_p()
+    L.check(lib.dep_comm_init(C.byref(comm), world, rk, raw, 128, dev), 'dep_comm_init')
+    _native.update(comm=comm, stream=torch.cuda.Stream(), world=world)
+    return comm
+
+
+def native_comm():
+    return _native['comm']
+
+
+def destroy_native_comm():
+    from . import _lib as L
+    if _native['comm'] is not None:
+        torch.cuda.synchronize()
+        L.load().dep_comm_destroy(_native['comm'])
+        _native.update(comm=None, stream=None, world=1)
+
+
+def layer_buckets(spans, n_live):
+    """Pure helper (CPU-testable): `spans` = ordered list of (start, count) ranges of the flat live-gradient buffer in the
+    order they become final during the backward; checks they are disjoint and cover [0, n_live) exactly."""
+    marks = sorted((s, s + c) for s, c in spans if c > 0)
+    pos = 0
+    for a, b in marks:
+        if a != pos:
+            raise ValueError(f'gradient ranges leave a gap or overlap at {pos} (next range starts at {a})')
+        pos = b
+    if pos != n_live:
+        raise ValueError(f'gradient ranges cover {pos} of {n_live} live floats')
+    return [(s, c) for s, c in spans if c > 0]
+
+
+def make_grad_sync(model, in_call):
+    """GradSync for dep_rnn_backward_overlapped, or None without a native communicator.  in_call: {layer: (start, count)}."""
+    if _native['comm'] is None or not in_call:
+        return None
+    from . import _lib as L
+    gs = L.GradSync()
+    gs.comm = _native['comm']
+    gs.comm_stream = _native['stream'].cuda_stream
+    base = model._flat_grad.data_ptr()
+    for l, (start, count) in in_call.items():
+        gs.range_ptr[l] = base + 4 * start
+        gs.range_count[l] = count
+    return gs
+
+
+def finish_grad_sync(model, in_call, post):
+    """After the model's backward: reduce what is still local and join the streams.
+    native communicator: `post` ranges (final only now) as one grouped RCCL operation on the communication stream, then the
+    compute stream waits for that stream; otherwise one torch.distributed all-reduce of the whole bucket."""
+    if _native['comm'] is None:
+        all_reduce_grads(model)
+        return
+    import ctypes as C
+    from . import _lib as L
+    layer_buckets(list(in_call.values()) + list(post), model._n_live)          # every live float is reduced exactly once
+    cs = _native['stream']
+    cur = torch.cuda.current_stream()
+    ev = torch.cuda.Event(); ev.record(cur)
+    cs.wait_event(ev)
+    post = [(s, c) for s, c in post if c > 0]
+    if post:
+        base = model._flat_grad.data_ptr()
+        ptrs = (C.c_void_p * len(post))(*[base + 4 * s for s, _ in post])
+        cnts = (C.c_long * len(post))(*[c for _, c in post])
+        L.check(L.load().dep_comm_allreduce_ranges(_native['comm'], ptrs, cnts, len(post), cs.cuda_stream),
+                'dep_comm_allreduce_ranges')
+    ev2 = torch.cuda.Event(); ev2.record(cs)
+    cur.wait_event(ev2)
+
+
+def reduce_zero_contribution(model, in_call, post):
+    """A rank whose shard is empty: same collectives, in the same order, on a zeroed gradient buffer."""
+    if _native['comm'] is None:
+        all_reduce_grads(model)
+        return
+    from . import _lib as L
+    cs = _native['stream']
+    cur = torch.cuda.current_stream()
+    ev = torch.cuda.Event(); ev.record(cur)
+    cs.wait_event(ev)
+    base = model._flat_grad.data_ptr()
+    for l in sorted(in_call, reverse=True):                                    # the backward walks the layers top -> bottom
+        s, c = in_call[l]
+        if c > 0:
+            L.check(L.load().dep_comm_allreduce(_native['comm'], base + 4 * s, c, cs.cuda_stream), 'dep_comm_allreduce')
+    finish_grad_sync(model, in_call, post)
 
 
 def broadcast_params(model, src=0):

@@ -68,10 +68,12 @@ size_t dep_rnn_reserve_y_offset(const dep_rnn_desc* d, int layer);
 /* Same for the dropped-out copy that feeds layer+1 (training && dropout_p > 0 only). */
 size_t dep_rnn_reserve_ydrop_offset(const dep_rnn_desc* d, int layer);
 
-/* Health of the cluster-parallel sweeps that last ran on `workspace` (desc.impl 0/3 with a supported H):
- * they exchange data between workgroups inside one launch with bounded spins; if a spin ever gives up
- * the kernels exit early and this returns DEP_ERR_HIP.  Synchronises `stream`.  Always DEP_OK for the
- * single-workgroup kernels. */
+/* Health of the cluster-parallel sweeps that ran on `workspace` since the last dep_rnn_forward (desc.impl 0/3 with a
+ * supported H): they exchange data between workgroups inside one launch with bounded spins; if a spin ever gives up
+ * the kernels exit early and this returns DEP_ERR_HIP.  The status is STICKY over a step: dep_rnn_forward clears it once,
+ * every later sweep (the other layers, the whole backward) leaves it alone and exits at entry when it is raised, so one
+ * query after forward + backward sees a failure of any of the step's sweeps.  Synchronises `stream`.  Always DEP_OK for
+ * the single-workgroup kernels. */
 int dep_rnn_status(const dep_rnn_desc* d, void* workspace, void* stream);
 /* Debug tooling: byte offset of the cluster exchange buffer inside the workspace ((size_t)-1 if unused).
  * With DEP_TRACE=1 workgroup 0 of the GRU sweeps leaves shader-clock stamps of its phases at +6144
@@ -86,7 +88,8 @@ size_t dep_rnn_workspace_xbuf_offset(const dep_rnn_desc* d);
  *
  * Precision: the recurrent products of the cluster sweeps follow the GEMM mode (dep_set_gemm_mode below): 3-term bf16
  * split by default, exact fp32 MFMA in mode 0.  The packed recurrent weights in the reserve are mode-specific, so the
- * mode must not change between a dep_rnn_forward and the dep_rnn_backward that consumes its reserve.
+ * mode must not change between a dep_rnn_forward and the dep_rnn_backward that consumes its reserve: the library records
+ * the mode each reserve was produced in and dep_rnn_backward returns DEP_ERR_ARG on a mismatch.
  *
  * dep_rnn_forward replaces `x, _ = self.lstm_net_audio(x)` (audio_gru_whole.py:105) and
  * `output, (h_n, _) = self.lstm_net(x)` (text_bilstm_whole.py:105).
@@ -113,6 +116,50 @@ int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const float* const* 
                      float* const* dweights, float* dx,
                      void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
                      void* stream);
+
+/* ------------------------------------------------------------------ data parallel -- */
+/* RCCL over xGMI, one process per GPU (north_star; SURVEY 8b `dep_comm_{init,allreduce,destroy}`, 8e).  The reference has no
+ * distributed code: these entry points are what a data-parallel `train()` binds -- the utterances of every global
+ * mini-batch are split over the ranks, every rank normalises its loss gradient by the GLOBAL batch size, and the flat
+ * fp32 gradient buffer is SUM all-reduced (the reference's `loss.backward(); optimizer.step()`,
+ * Classification/audio_gru_whole.py:190-191, then sees the batch-mean gradient on every rank).
+ * librccl is loaded at the first call (dlopen): single-GPU processes never touch it.
+ *   dep_comm_unique_id : rank 0 obtains the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other ranks
+ *                        through whatever side channel the host has (the Python layer broadcasts it with torch.distributed);
+ *   dep_comm_init      : collective over all ranks (ncclCommInitRank), binds the communicator to HIP device `device`;
+ *   dep_comm_allreduce : in-place SUM of n fp32 values, enqueued on `stream` (nothing synchronises);
+ *   dep_comm_allreduce_ranges : several ranges as one grouped RCCL operation (one launch);
+ *   dep_comm_destroy   : releases the communicator. */
+typedef struct dep_comm dep_comm;
+int dep_comm_unique_id(void* id_out, size_t bytes);                    /* bytes >= 128 */
+int dep_comm_init(dep_comm** comm, int world, int rank, const void* unique_id, size_t id_bytes, int device);
+int dep_comm_world(const dep_comm* comm);
+int dep_comm_rank(const dep_comm* comm);
+int dep_comm_allreduce(dep_comm* comm, float* buf, long n, void* stream);
+int dep_comm_allreduce_ranges(dep_comm* comm, float* const* bufs, const long* counts, int nranges, void* stream);
+int dep_comm_destroy(dep_comm* comm);
+
+/* Gradient exchange overlapped with the backward pass ("overlapped with layer-0 backward").  range_ptr[l] /
+ * range_count[l] name the contiguous span of the caller's flat gradient buffer that is FINAL once layer l's weight
+ * gradients are written (the layer's own four tensors per direction plus whatever neighbours of the bucket were already
+ * final, e.g. the head's gradients next to the top layer); count 0 skips a layer.  dep_rnn_backward_overlapped is
+ * dep_rnn_backward plus: as soon as layer l's dW are enqueued on `stream`, `comm_stream` is made to wait for them (event)
+ * and the SUM all-reduce of range l is enqueued there -- it runs while the layers below are still in their sweeps.  The
+ * caller makes its compute stream wait for `comm_stream` before the optimizer reads the gradients.
+ * Co-scheduling: collectives only ever overlap BACKWARD sweeps, which run one workgroup per CU and leave VGPR / LDS room
+ * for RCCL's workgroups; the forward sweeps (which may fill a CU) never have a collective beside them because the
+ * optimizer step that precedes the next forward waits for the communication stream. */
+typedef struct {
+    dep_comm* comm;
+    void* comm_stream;           /* hipStream_t, different from the compute stream */
+    float* range_ptr[8];         /* indexed by layer */
+    long range_count[8];
+} dep_grad_sync;
+int dep_rnn_backward_overlapped(const dep_rnn_desc* d, const float* x, const float* const* weights,
+                                const float* dy, const float* dpooled, const float* dh_n,
+                                float* const* dweights, float* dx,
+                                void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                void* stream, const dep_grad_sync* gs);
 
 /* ------------------------------------------------------------------ dense --------- */
 /* C[M,N] = opA(A)[M,K] * opB(B)[K,N] + bias[N] + beta*C      (fp32 MFMA, exact f32 products)

@@ -67,6 +67,44 @@ def test_torch_baseline_matches_reference_fixture():
         assert np.abs(out - g['out_eval']).max() < 1e-6
 
 
+def test_torch_fusion_baseline_matches_reference_fixture():
+    """The CPU yardstick of the fusion workload (bench.py --workload fusion): the reference's fusion_net state_dict loaded
+    into oracle.torch_cpu_baseline.FusionClf reproduces the reference's features, output, MyLoss and weight gradient."""
+    g = load_golden('fuse_clf')
+    Ft, Ht, Fa, Ha = g['xt'].shape[2], g['sd']['fc_out.1.weight'].shape[0], g['xa'].shape[2], g['sd']['fc_audio.1.weight'].shape[0]
+    m = TB.FusionClf(Ft, Ht, Fa, Ha, p=0.0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()}, strict=True)
+    m.eval()
+    tf, af = m.pretrained_feature(torch.from_numpy(g['xa']), torch.from_numpy(g['xt']))
+    assert np.abs(tf.numpy() - g['text_feature']).max() < 1e-5
+    assert np.abs(af.numpy() - g['audio_feature']).max() < 1e-5
+    with torch.no_grad():
+        assert np.abs(m(torch.cat((tf, af), 1)).numpy() - g['out']).max() < 1e-6
+    loss = TB.my_loss(m, tf, af, torch.from_numpy(g['y']).long())
+    loss.backward()
+    assert abs(loss.item() - g['losses'][0]) < 1e-5
+    assert np.abs(m.fc_final[0].weight.grad.numpy() - g['gW']).max() < 1e-5 * max(1.0, np.abs(g['gW']).max())
+
+
+def test_bench_launches_n_ranks_itself():
+    """`bench.py --gpus N` started as ONE plain process must become N ranks: the launch path is
+    exercised on CPU with gloo; the process group's size is checked against --gpus."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launch-check', '--backend', 'gloo'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and lines, r.stdout[-1500:] + r.stderr[-1500:]
+    res = json.loads(lines[-1])
+    assert res == {'launch_check': True, 'world': 2, 'sum': 2.0, 'backend': 'gloo'}
+    # a group whose size differs from --gpus is refused, not silently benchmarked as N=1
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launch-check', '--backend', 'gloo'],
+                       env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'process group has 1 ranks' in (r.stdout + r.stderr)
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -118,3 +156,43 @@ def test_data_parallel_sum_of_shards_equals_full_batch_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert err < 1e-12
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from icassp2022_depression_amd import parallel as par
+    par.init_from_env('gloo')
+    n_live = 1000
+    g = torch.from_numpy(np.random.default_rng(100 + rank).standard_normal(n_live))       # fp64 "gradient bucket" of this rank
+    whole = g.clone(); dist.all_reduce(whole)
+    # the audio classifier's plan shape: top layer + head in-call, layer 0 and the LayerNorm pair afterwards
+    spans = par.layer_buckets([(400, 500), (0, 400), (900, 100)], n_live)
+    pieces = g.clone()
+    for s, c in spans:
+        dist.all_reduce(pieces[s:s + c])
+    if rank == 0:
+        q.put(float((whole - pieces).abs().max()))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_per_layer_buckets_equal_single_bucket_gloo():
+    """Reducing the flat gradient buffer range by range (the overlapped schedule) gives what one all-reduce of the whole
+    bucket gives; and a plan that leaves a gap or overlaps is rejected before anything is sent."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 500
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    diff = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert diff < 1e-12
+    with pytest.raises(ValueError):
+        parallel.layer_buckets([(0, 400), (500, 500)], 1000)
+    with pytest.raises(ValueError):
+        parallel.layer_buckets([(0, 400), (300, 700)], 1000)

@@ -411,3 +411,47 @@ def test_bad_arguments_fail_loudly():
         L.gemm(1, 1, 4, 4, 4, torch.zeros(16, device=DEV), 4, torch.zeros(16, device=DEV), 4, torch.zeros(16, device=DEV), 4)
     with pytest.raises(L.DepError):
         L.Rnn(L.CELL_GRU, 4, 4, 4, 4, 2, 2, False, 0.0, L.POOL_NONE, DEV)     # bidirectional GRU is not in the path
+
+
+def test_backward_refuses_a_reserve_from_the_other_precision_mode():
+    """The packed W_hh images in the reserve are precision-mode specific (include/dep_rnn.h): flipping the mode between a
+    forward and its backward must fail loudly (DEP_ERR_ARG), not produce silently wrong gradients."""
+    rng = np.random.default_rng(21)
+    B, T, F, H = 8, 5, 16, 128
+    P, names, prefix = make_rnn_params(rng, 'gru', F, H, 2, 1)
+    Wd = [dev(P[n]) for n in names]; Gd = [torch.zeros_like(w) for w in Wd]
+    x = dev(rng.standard_normal((B, T, F)))
+    rnn = L.Rnn(L.CELL_GRU, B, T, F, H, 2, 1, True, 0.0, L.POOL_NONE, DEV, impl=3)
+    dy = dev(rng.standard_normal((B, T, H)))
+    try:
+        L.set_gemm_mode(1)
+        rnn.forward(x, Wd)
+        L.set_gemm_mode(0)
+        with pytest.raises(L.DepError, match='mode'):
+            rnn.backward(x, Wd, Gd, dy=dy)
+        L.set_gemm_mode(1)
+        rnn.backward(x, Wd, Gd, dy=dy)          # same mode again: accepted
+        rnn.check()
+    finally:
+        L.set_gemm_mode(1, 1 << 28)
+
+
+def test_sweep_status_is_sticky_over_a_step():
+    """A give-up in any sweep of a step must still be visible after the whole step: the status word is only
+    cleared by dep_rnn_forward; a raised word makes the later sweeps leave at entry and dep_rnn_status report it."""
+    rng = np.random.default_rng(22)
+    B, T, F, H = 8, 5, 16, 128
+    P, names, prefix = make_rnn_params(rng, 'gru', F, H, 2, 1)
+    Wd = [dev(P[n]) for n in names]; Gd = [torch.zeros_like(w) for w in Wd]
+    x = dev(rng.standard_normal((B, T, F)))
+    rnn = L.Rnn(L.CELL_GRU, B, T, F, H, 2, 1, True, 0.0, L.POOL_NONE, DEV, impl=3)
+    dy = dev(rng.standard_normal((B, T, H)))
+    rnn.forward(x, Wd); rnn.check()
+    off = L.load().dep_rnn_workspace_xbuf_offset(__import__('ctypes').byref(rnn.desc)) // 4
+    rnn.workspace[off:off + 1].view(torch.int32).fill_(3)       # as if a forward sweep had given up
+    rnn.backward(x, Wd, Gd, dy=dy)                              # must not clear it
+    with pytest.raises(L.DepError, match='gave up'):
+        rnn.check()
+    rnn.forward(x, Wd)                                          # the next step starts clean
+    rnn.backward(x, Wd, Gd, dy=dy)
+    rnn.check()

@@ -1,0 +1,55 @@
+"""Race / stress row of SURVEY section 5 for the in-launch cross-CU hand-off of the cluster sweeps: full grid, poisoned
+exchange buffers, bit-identical reruns, under the same-XCD fast path, the write-through path (DEP_CLUSTER_NOFAST=1), odd
+chunking (DEP_NUM_CUS in {48, 200}) and with a GEMM loop on a second stream (uneven load).  See tests/stress_handoff.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = [
+    # cell, iters, extra env, extra args
+    ('gru', 20, {}, []),
+    ('gru', 10, {'DEP_CLUSTER_NOFAST': '1'}, []),
+    ('gru', 4, {'DEP_NUM_CUS': '48'}, []),
+    ('gru', 6, {'DEP_NUM_CUS': '200'}, []),
+    ('gru', 12, {}, ['--load', '--load-phase', 'bwd']),            # what an overlapped all-reduce does: load beside the backward
+    ('gru', 8, {'DEP_CLUSTER_NOFAST': '1'}, ['--load', '--load-phase', 'bwd']),
+    ('gru', 8, {'DEP_CLUSTER16': '0'}, ['--load']),                # co-scheduling-tolerant forward (one workgroup per CU) + load on both halves
+    ('gru', 8, {}, ['--load', '--H', '128']),
+    ('gru', 8, {'DEP_GEMM_MODE': 'f32'}, []),                    # exact-fp32 sweeps (different member kernels)
+    ('gru', 8, {}, ['--H', '128']),                               # 32-unit-member forward kernel
+    ('lstm', 12, {}, []),
+    ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, ['--load']),
+    ('lstm', 4, {'DEP_NUM_CUS': '200'}, []),
+]
+
+
+@pytest.mark.parametrize('cell,iters,env,extra', CASES)
+def test_handoff_stress(cell, iters, env, extra):
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'stress_handoff.py'), '--cell', cell, '--iters', str(iters)] + extra,
+                       env=e, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert res['mismatches'] == 0 and res['status_bad'] == 0 and res['nan_iters'] == 0, res
+    assert r.returncode == 0
+
+
+def test_exclusive_forward_fails_loudly_never_silently_under_foreign_load():
+    """The 16-unit-member GRU forward needs the GPU to itself (tests/stress_handoff.py docstring).  With a foreign GEMM
+    loop beside it, an iteration either reproduces the reference bits or raises the status word -- a wrong result with a
+    clean status would be the silent failure the header promises never to produce."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'stress_handoff.py'), '--cell', 'gru', '--iters', '4', '--load',
+                        '--load-m', '1024'], capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert res['status_bad'] >= res['mismatches'] and res['status_bad'] >= res['nan_iters'], res
