@@ -152,6 +152,35 @@ def evaluate(model, fold, train_mae):
     return total_loss
 
 
+def _single_modality_eval(model, col, crit):
+    idx = list(test_dep_idxs) + list(test_non_idxs)
+    X_test = np.array([fuse_features[i][col] for i in idx])
+    Y_test = np.array([fuse_targets[i] for i in idx])
+    model.eval()
+    x = torch.from_numpy(np.ascontiguousarray(X_test)).type(torch.FloatTensor)
+    y = torch.from_numpy(np.ascontiguousarray(Y_test)).type(torch.FloatTensor)
+    optimizer.zero_grad()
+    output = model(x)
+    loss = crit(output, y.view(-1, 1))
+    loss.item()
+    pred = output.data.flatten().cpu().numpy()
+    mae, rmse = _mae_rmse(Y_test, pred)
+    print('MAE: {:.4f}\t RMSE: {:.4f}\n'.format(mae, rmse))
+    print('=' * 89)
+
+
+def evaluate_audio(model):
+    """Reference lines 458-490: the AUDIO regressor alone (`model(x)` on the audio half of every test pair, one full
+    batch) scored with the module-global `criterion` (a two-argument loss at that point of the reference's workflow);
+    prints MAE / RMSE, returns nothing."""
+    _single_modality_eval(model, 0, criterion)
+
+
+def evaluate_text(model):
+    """Reference lines 492-524: the TEXT regressor alone, scored with a local SmoothL1Loss."""
+    _single_modality_eval(model, 1, nn.SmoothL1Loss())
+
+
 def transplant(model, text_state_dict, audio_state_dict):
     """Reference lines 562-583 (no `ln` here; every parameter keeps requires_grad=True, yet only
     fc_final.0.weight is reached by the loss)."""

@@ -433,7 +433,9 @@ class MyLoss:
         L.gemm(0, 1, B, Cc, Ht, text_feature, Ht, W, D, zt, Cc)
         L.gemm(0, 1, B, Cc, Ha, audio_feature, Ha, W[:, Ht:], D, za, Cc)
         if self.variant == 'clf':
-            t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target).to(device=dev, dtype=torch.int32).view(-1)
+            t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target)
+            nn._check_labels(t, Cc)
+            t = t.to(device=dev, dtype=torch.int32).view(-1)
             kind = L.LOSS_CE_LOGITS; norm_local = B
         else:
             t = torch.as_tensor(np.asarray(target, dtype=np.float32) if not torch.is_tensor(target) else target)

@@ -222,6 +222,15 @@ class Loss:
         return self.item()
 
 
+def _check_labels(t, num_classes):
+    """torch's CrossEntropyLoss raises on a class index outside [0, C); the loss kernel indexes with the label, so the
+    range is validated here, on the host copy the training loops hand over (device-resident labels are the caller's)."""
+    if not t.is_cuda and t.numel() > 0:
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= num_classes:
+            raise IndexError(f'Target {lo if lo < 0 else hi} is out of bounds for {num_classes} classes')
+
+
 class _HeadLoss:
     """Loss on a model output; the output nonlinearity, the loss and dLoss/dz are one HIP kernel."""
     kind = None
@@ -234,6 +243,7 @@ class _HeadLoss:
         dev = z.device
         if self.target_dtype == 'int':
             t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target)
+            _check_labels(t, Cc)
             t = t.to(device=dev, dtype=torch.int32).contiguous().view(-1)
         else:
             t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target)
@@ -380,8 +390,13 @@ def xavier_uniform(shape, gen):
 
 
 def make_generator(seed=None):
+    """Initialisation RNG of one model.  seed=None draws a sub-seed from torch's GLOBAL generator, which advances it: like
+    the reference (whose nn.Module constructors consume the global RNG) every model built in a process -- e.g. the three
+    folds of main() -- starts from different weights, and torch.manual_seed() makes the whole sequence reproducible."""
     g = torch.Generator()
-    g.manual_seed(int(torch.initial_seed() if seed is None else seed) & 0x7fffffffffffffff)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    g.manual_seed(int(seed) & 0x7fffffffffffffff)
     return g
 
 

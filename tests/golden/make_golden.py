@@ -257,6 +257,148 @@ def fusion(mod, variant, seed, name):
     save(name, **arrs)
 
 
+def text_clf_train_eval(mod):
+    """train()/evaluate() of Classification/text_bilstm_whole.py:154-235 on synthetic features, dropout 0."""
+    torch.manual_seed(13)
+    rng = np.random.default_rng(13)
+    N, T, F, H = 19, 3, 14, 16
+    cfg = dict(mod.config); cfg.update(embedding_size=F, hidden_dims=H, dropout=0.0, batch_size=4, learning_rate=1e-3)
+    mod.config = cfg
+    feats = rng.standard_normal((N, T, F)).astype(np.float64)
+    targs = rng.integers(0, 2, N).astype(np.int64); targs[:2] = [0, 1]; targs[13:15] = [0, 1]
+    model = mod.TextBiLSTM(cfg)
+    sd0 = sd_np(model)
+    mod.model = model
+    mod.text_features = feats; mod.text_targets = targs
+    mod.optimizer = torch.optim.AdamW(mod.get_param_group(model), lr=cfg['learning_rate'])
+    mod.criterion = torch.nn.CrossEntropyLoss()
+    mod.max_f1 = mod.max_acc = mod.max_rec = mod.max_prec = 2.0      # thresholds unmet -> no save()
+    mod.train_acc = -1
+    train_idxs = list(range(0, 13)); test_idxs = list(range(13, 19))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mod.train(1, train_idxs); acc1 = int(mod.train_acc)
+        mod.train(2, train_idxs); acc2 = int(mod.train_acc)
+        tl = mod.evaluate(model, test_idxs, 1, train_idxs)
+    with torch.no_grad():
+        model.eval()
+        probs = model(torch.from_numpy(feats[test_idxs]).float()).numpy()
+    cm = mod.standard_confusion_matrix(torch.from_numpy(targs[test_idxs]), probs.argmax(1))
+    save('text_clf_train_eval', feats=feats, targs=targs, sd=sd0, train_idxs=np.array(train_idxs),
+         test_idxs=np.array(test_idxs), train_acc=np.array([acc1, acc2]), eval_loss=np.float64(tl), probs=probs, conf=cm,
+         after=sd_np(model), lr=np.float64(cfg['learning_rate']), shape=np.array([N, T, F, H]), batch_size=np.int64(4),
+         printed=np.array(buf.getvalue()))
+
+
+def text_reg_train_eval(mod):
+    """train()/evaluate() of Regression/text_bilstm_perm.py:131-210."""
+    torch.manual_seed(14)
+    rng = np.random.default_rng(14)
+    N, T, F, H = 15, 3, 10, 16
+    cfg = dict(mod.config); cfg.update(embedding_size=F, hidden_dims=H, dropout=0.0, batch_size=4, learning_rate=1e-3)
+    mod.config = cfg
+    feats = rng.standard_normal((N, T, F)).astype(np.float64)
+    targs = rng.uniform(30, 70, N).astype(np.float64)
+    model = mod.TextBiLSTM(cfg)
+    sd0 = sd_np(model)
+    mod.model = model; mod.text_features = feats; mod.text_targets = targs
+    mod.optimizer = torch.optim.Adam(model.parameters(), lr=cfg['learning_rate'])
+    mod.criterion = torch.nn.SmoothL1Loss()
+    mod.train_dep_idxs = [0, 1, 2, 3]; mod.train_non_idxs = [4, 5, 6, 7, 8, 9]
+    mod.test_dep_idxs = [10, 11]; mod.test_non_idxs = [12, 13, 14]
+    mod.min_mae = -1.0; mod.min_rmse = -1.0
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mae1 = mod.train(1)
+        mae2 = mod.train(2)
+        tl = mod.evaluate(0, model, mae2)
+    save('text_reg_train_eval', feats=feats, targs=targs, sd=sd0, train_mae=np.array([mae1, mae2]),
+         eval_loss=np.float64(tl), after=sd_np(model), lr=np.float64(cfg['learning_rate']),
+         shape=np.array([N, T, F, H]), batch_size=np.int64(4), printed=np.array(buf.getvalue()))
+
+
+def fuse_reg_train_eval(mod, a_reg, t_reg):
+    """Regression/fuse_net.py: train()/evaluate() (lines 373-456) and the single-modality checks evaluate_audio /
+    evaluate_text (lines 458-524) run on reference audio / text regressors."""
+    torch.manual_seed(23)
+    rng = np.random.default_rng(23)
+    N, T, Fa, Ft, Ha, Ht = 11, 3, 12, 20, 16, 16
+    cfg = dict(mod.config)
+    cfg.update(audio_embed_size=Fa, text_embed_size=Ft, audio_hidden_dims=Ha, text_hidden_dims=Ht,
+               dropout=0.0, batch_size=4, learning_rate=1e-3, cuda=False)
+    mod.config = cfg
+    model = mod.fusion_net(cfg['text_embed_size'], cfg['text_hidden_dims'], cfg['rnn_layers'], cfg['dropout'],
+                           cfg['num_classes'], cfg['audio_hidden_dims'], cfg['audio_embed_size'])
+    sd0 = sd_np(model)
+    xa = rng.standard_normal((N, T, Fa)).astype(np.float32)
+    xt = rng.standard_normal((N, T, Ft)).astype(np.float32)
+    y = rng.uniform(30, 70, N).astype(np.float32)
+    mod.fuse_features = [[xa[i], xt[i]] for i in range(N)]; mod.fuse_targets = y
+    mod.model = model
+    mod.optimizer = torch.optim.Adam(model.parameters(), lr=cfg['learning_rate'])
+    mod.criterion = mod.MyLoss()
+    mod.train_dep_idxs = [0, 1, 2]; mod.train_non_idxs = [3, 4, 5, 6]
+    mod.test_dep_idxs = [7, 8]; mod.test_non_idxs = [9, 10]
+    mod.min_mae = -1.0; mod.min_rmse = -1.0
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mae1 = mod.train(model, 1)
+        mae2 = mod.train(model, 2)
+        tl = mod.evaluate(model, 0, mae2)
+    W_after = model.fc_final[0].weight.detach().numpy().copy()
+    # single-modality evaluators on reference regressors of matching shapes
+    ca = dict(a_reg.config); ca.update(embedding_size=Fa, hidden_dims=Ha, dropout=0.0)
+    ct = dict(t_reg.config); ct.update(embedding_size=Ft, hidden_dims=Ht, dropout=0.0)
+    am = a_reg.AudioBiLSTM(ca); tm = t_reg.TextBiLSTM(ct)
+    mod.criterion = torch.nn.L1Loss()              # evaluate_audio uses the module-global criterion (2-argument form)
+    ba, bt = io.StringIO(), io.StringIO()
+    with contextlib.redirect_stdout(ba):
+        mod.evaluate_audio(am)
+    with contextlib.redirect_stdout(bt):
+        mod.evaluate_text(tm)
+    save('fuse_reg_train_eval', xa=xa, xt=xt, y=y, sd=sd0, train_mae=np.array([mae1, mae2]), eval_loss=np.float64(tl),
+         W_after=W_after, lr=np.float64(cfg['learning_rate']), dims=np.array([N, T, Fa, Ft, Ha, Ht]),
+         printed=np.array(buf.getvalue()), sd_audio=sd_np(am), sd_text=sd_np(tm),
+         printed_audio=np.array(ba.getvalue()), printed_text=np.array(bt.getvalue()))
+
+
+def fuse_augment():
+    """The fusion script's permutation pairing (Classification/fuse_net_whole.py:531-564) lives in its __main__ block: the
+    statements of the fold loop between the index-file load and the checkpoint load are extracted by AST and run on a
+    synthetic feature list; the fixture keeps the inputs and what the loop produced."""
+    src = open(os.path.join(REF, 'Classification/fuse_net_whole.py')).read()
+    tree = ast.parse(src)
+    main_if = [n for n in tree.body if isinstance(n, ast.If) and isinstance(n.test, ast.Compare)
+               and getattr(n.test.left, 'id', '') == '__name__'][0]
+    fold_loop = [n for n in main_if.body if isinstance(n, ast.For)][0]
+    body = fold_loop.body
+    assert isinstance(body[0], ast.Assign) and body[0].targets[0].id == 'train_idxs_tmp'      # the np.load we replace
+    stmts = body[1:6]
+    assert [type(n).__name__ for n in stmts] == ['Assign', 'Assign', 'Assign', 'For', 'For'], [type(n).__name__ for n in stmts]
+    rng = np.random.default_rng(31)
+    N, Fa, Ft = 9, 4, 5
+    feats = [[rng.standard_normal((3, Fa)).astype(np.float32), rng.standard_normal((3, Ft)).astype(np.float32)] for _ in range(N)]
+    targets = np.array([1, 0, 1, 0, 0, 1, 0, 1, 0])
+    dep = np.where(targets == 1)[0]; non = np.where(targets == 0)[0]
+    train_tmp = np.array([0, 1, 3, 5, 6, 8])
+    ns = {'np': np, 'itertools': __import__('itertools'), 'fuse_features': [list(f) for f in feats], 'fuse_targets': targets.copy(),
+          'fuse_dep_idxs': dep, 'fuse_non_idxs': non, 'train_idxs_tmp': train_tmp}
+    exec(compile(ast.Module(stmts, []), 'fuse_net_whole.py:531-564', 'exec'), ns)
+    added = ns['fuse_features'][N:]
+    save('fuse_augment', xa=np.stack([f[0] for f in feats]), xt=np.stack([f[1] for f in feats]), targets=targets,
+         train_idxs_tmp=train_tmp, test_idxs_tmp=np.array(ns['test_idxs_tmp']), train_idxs=np.array(ns['train_idxs']),
+         test_idxs=np.array(ns['test_idxs']), targets_after=np.asarray(ns['fuse_targets']),
+         added_audio=np.stack([np.stack(a[0]) for a in added]), added_text=np.stack([np.stack(a[1]) for a in added]))
+
+
+def round2(a_reg, t_clf, t_reg, f_reg):
+    single_model(t_clf, 'TextBiLSTM', {}, (8, 50, 64, 128), 'clf', 10, 'adamw', 'ce', light=True, name='text_clf_h128')
+    text_clf_train_eval(t_clf)
+    text_reg_train_eval(t_reg)
+    fuse_reg_train_eval(f_reg, a_reg, t_reg)
+    fuse_augment()
+
+
 def main():
     torch.set_num_threads(4)
     a_clf = load_ref('Classification/audio_gru_whole.py', 'ref_audio_clf')
@@ -265,6 +407,9 @@ def main():
     t_reg = load_ref('Regression/text_bilstm_perm.py', 'ref_text_reg')
     f_clf = load_ref('Classification/fuse_net_whole.py', 'ref_fuse_clf')
     f_reg = load_ref('Regression/fuse_net.py', 'ref_fuse_reg')
+
+    if '--round2-only' in sys.argv:          # the fixtures added in round 2 (the round-1 files are left untouched)
+        return round2(a_reg, t_clf, t_reg, f_reg)
 
     tiny = (4, 6, 5, 8)        # H not a multiple of 16 -> exercises the generic kernels
     mid = (6, 20, 24, 16)      # H % 16 == 0 -> exercises the MFMA sweep kernels
@@ -282,6 +427,9 @@ def main():
     audio_reg_train_eval(a_reg)
     fusion(f_clf, 'clf', 21, 'fuse_clf')
     fusion(f_reg, 'reg', 22, 'fuse_reg')
+    # fresh module objects: the train/evaluate fixtures above replaced module globals (config, model, ...)
+    round2(load_ref('Regression/audio_bilstm_perm.py', 'ref_audio_reg2'), load_ref('Classification/text_bilstm_whole.py', 'ref_text_clf2'),
+           load_ref('Regression/text_bilstm_perm.py', 'ref_text_reg2'), load_ref('Regression/fuse_net.py', 'ref_fuse_reg2'))
 
 
 if __name__ == '__main__':
