@@ -78,6 +78,8 @@ struct Layout {
     bool cluster;                    // cluster-parallel sweeps (rnn_cluster*.hip)
     bool cluster16;                  // forward with 16-unit members, two workgroups per CU (rnn_cluster16.hip)
     bool cluster16_bwd;              // same for the backward (slower than 32-unit members: A/B only, DEP_CLUSTER16_BWD=1)
+    bool fused2;                     // 2-layer GRU, H = 256: both layers in one launch (rnn_fused2.hip), split-precision mode only
+    size_t wih_img;                  // workspace: packed W_ih of layer 1 for the fused forward
 };
 
 bool make_layout(const dep_rnn_desc* d, Layout& lo) {
@@ -137,7 +139,10 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     { const char* e = getenv("DEP_CLUSTER16_BWD"); lo.cluster16_bwd = lo.cluster16 && e && e[0] == '1'; }
     lo.xbuf = w; lo.xbuf_bytes = !lo.cluster ? 0 : (d->cell == DEP_CELL_GRU ? dep_cluster_xbuf_bytes(d->cell, d->H, d->B, d->dirs)
                                                                 : dep_cluster_lstm_xbuf_bytes(d->H, d->B, d->dirs));
+    lo.fused2 = lo.cluster && dep_fused2_ok(d->cell, d->H, d->L, d->dirs);
+    if (lo.fused2) { const size_t fb = dep_fused2_xbuf_bytes(d->B); if (fb > lo.xbuf_bytes) lo.xbuf_bytes = fb; }
     w += al(lo.xbuf_bytes / sizeof(float) + 64);
+    lo.wih_img = w; if (lo.fused2) w += al(G * H * H);
     lo.ws_floats = w;
     return true;
 }
@@ -243,6 +248,36 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     if (lo.cluster) { rc = dep_cluster_reset_status(W + lo.xbuf, s); if (rc) return rc; }
     // the recurrent-weight images packed below are precision-mode specific: remember which mode this reserve holds
     record_reserve_mode(reserve, sweep_split_mode() ? 1 : 0);
+    if (lo.fused2 && sweep_split_mode()) {
+        // both layers in one launch: layer 1 runs one step behind layer 0 and takes its input straight from the exchanged
+        // h0_t (no layer-1 input-projection GEMM, no GI round trip through HBM for it)
+        const float* const* w0 = weights; const float* const* w1 = weights + 4;
+        for (int k = 0; k < 4; ++k) DEP_CHECK_ARG(w0[k] && w1[k]);
+        rc = dep_pack_cluster_fwd_split(w0[1], R + lo.wp[0][0], H, s); if (rc) return rc;
+        rc = dep_pack_cluster_fwd_split(w1[1], R + lo.wp[1][0], H, s); if (rc) return rc;
+        rc = dep_pack_cluster_fwd_split(w1[0], W + lo.wih_img, H, s); if (rc) return rc;
+        if (d->training) {
+            rc = dep_pack_cluster_bwd_split(w0[1], R + lo.wpT[0][0], H, s); if (rc) return rc;
+            rc = dep_pack_cluster_bwd_split(w1[1], R + lo.wpT[1][0], H, s); if (rc) return rc;
+        }
+        float* gi = W + lo.gi;
+        rc = dep_gemm_internal(0, 1, BTr, G * H, d->F, x, d->F, w0[0], d->F, gi, G * H, w0[2], 0.f, 0, 0, nullptr, 0, s);
+        if (rc) return rc;
+        dep_fused2_args f{};
+        f.B = B; f.T = T; f.training = d->training;
+        f.wp0 = R + lo.wp[0][0]; f.wp1 = R + lo.wp[1][0]; f.wpi = W + lo.wih_img;
+        f.b_hh0 = w0[3]; f.b_ih1 = w1[2]; f.b_hh1 = w1[3];
+        f.ostride = (lo.BT * H + 63) / 64 * 64;
+        f.gi = gi; f.y0 = R + lo.y[0]; f.y0d = lo.drop ? R + lo.ydrop[0] : nullptr; f.y1 = R + lo.y[1];
+        f.drop_p = lo.drop ? d->dropout_p : 0.f; f.seed = d->seed; f.site = DEP_SITE_RNN0;
+        f.pooled = pooled; f.pool_scale = d->pool == DEP_POOL_MEAN ? 1.0f / (float)T : 1.0f;
+        f.hn0 = h_n; f.hn1 = h_n ? h_n + (size_t)B * H : nullptr;
+        for (int l = 0; l < 2; ++l) for (int k = 0; k < 4; ++k) f.sv[l][k] = d->training ? R + lo.sv[l][k] : nullptr;
+        f.stream = s;
+        rc = dep_launch_fused2_fwd(f, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
+        if (y) { rc = dep_axpby(R + lo.y[1], y, (long)lo.BT * H, 1.f, 0.f, s); if (rc) return rc; }
+        return DEP_OK;
+    }
     for (int l = 0; l < L; ++l) {
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
         const int Kl = l == 0 ? d->F : D * H;

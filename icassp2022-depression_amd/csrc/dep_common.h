@@ -160,6 +160,22 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
 // Utterances one co-resident cluster launch may cover: `members` workgroups per 16-utterance tile, `per_cu` of them resident
 // per CU (rnn_cluster.hip; CU count from the device, DEP_NUM_CUS overrides), at most `max_wgs` workgroups (flag words).
 int dep_cluster_chunk(int members, int per_cu, int max_wgs);
+// rnn_fused2.hip: both layers of a 2-layer GRU (H = 256) in one cluster launch, layer 1 one step behind layer 0
+struct dep_fused2_args {
+    int B, T, training;
+    const float* wp0; const float* wp1; const float* wpi;   // packed W_hh l0, W_hh l1, W_ih l1 (dep_pack_cluster_fwd_split images)
+    const float* b_hh0; const float* b_ih1; const float* b_hh1;
+    const float* gi;                                          // layer-0 input projection incl. b_ih (B*T, 3H)
+    float* y0; float* y0d; float* y1;
+    size_t ostride;                                           // floats between consecutive per-layer arrays of the reserve
+    float drop_p; uint64_t seed; uint32_t site;
+    float* pooled; float pool_scale; float* hn0; float* hn1;
+    float* sv[2][4];
+    hipStream_t stream;
+};
+bool dep_fused2_ok(int cell, int H, int L, int dirs);
+size_t dep_fused2_xbuf_bytes(int B);
+int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_bytes);
 // comm.hip: all-reduce of [buf, buf+n) on comm_stream after everything enqueued so far on `compute`
 int dep_comm_enqueue_after(dep_comm* c, float* buf, long n, hipStream_t compute, hipStream_t comm_stream);
 // clears the sticky status word of a cluster exchange buffer (once per dep_rnn_forward; the sweeps themselves never clear it)

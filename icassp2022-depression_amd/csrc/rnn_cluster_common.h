@@ -45,8 +45,9 @@ __device__ __forceinline__ void bar_lds() {
 
 // v_exp_f32 / v_rcp_f32 gate nonlinearities: absolute error ~2e-7, far inside the 1e-4 parity budget and several times
 // shorter than the ocml expf / tanhf sequences that sat on the per-step critical path
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// (__builtin_amdgcn_rcpf is the bare v_rcp_f32, 1 ulp; __frcp_rn expands to the ten-instruction IEEE division sequence)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // 3-term bf16 split of one fp32 value for the split-precision sweeps: bf16(x) << 16 | bf16(x - bf16(x))
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -1,0 +1,358 @@
+// Two-layer GRU forward as ONE cluster-parallel launch: layer 1 runs one step behind layer 0 (wavefront over the layers),
+// so a forward pass costs T + 1 dependent hand-offs instead of 2 T, and layer 1's input projection never exists in HBM.
+//
+// Per 16-utterance tile a cluster of NC = 8 workgroups (one per CU, all co-resident); member c owns hidden units
+// [32c, 32c + 32) of BOTH layers.  Twelve waves, three groups of four (wave = (16-unit column tile jl, K half kh) as in
+// gru_fwd_cluster_r1), each group keeping one 96 x 256 weight slice register-resident as (hi, lo) bf16 planes (96 VGPRs):
+//   group 0 : W_hh of layer 0     x h0_{s-1}              -> layer-0 step s
+//   group 1 : W_hh of layer 1     x h1_{s-2}              -> layer-1 step s-1
+//   group 2 : W_ih of layer 1     x dropout(h0_{s-1})     -> layer-1 step s-1's input projection; these waves have no gate
+//             math, so they also own every HBM stream of the member (prefetch of layer 0's input projection, write-out of
+//             h, dropout(h) and the saved gates of both layers) -- the waves on the critical path never touch HBM.
+// Fused step s (0..T): [36 MFMAs per wave] -> barrier -> [gate math of both layers on groups 0 / 1] -> payload stores
+// (h0_s, dropout(h0_s), h1_{s-1} as bf16 (hi << 16 | lo) words), drain, barrier, ONE flag per member -> poll the cluster's
+// 8 flags -> gather the three 16 x 256 blocks into LDS planes -> barrier.  Exchange protocol, same-XCD fast path, parity
+// double-buffered payload, bounded spins and sticky status: rnn_cluster_common.h.  Products use the 3-term bf16 split
+// (w_hi h_lo + w_lo h_hi + w_hi h_hi, fp32 accumulate), everything elementwise is fp32.
+// The matrix pipe bounds a step from below: 3 x 36 v_mfma_f32_16x16x32_bf16 per SIMD = 1728 cycles.
+#include "rnn_cluster_common.h"
+
+namespace {
+using namespace depc;
+
+constexpr int FH = 256, FNC = 8, FKS2 = 4, FTHREADS = 768;
+constexpr int FLDHB = FH + 8;                 // bf16 elements per row of a split plane (528-byte rows: conflict-free b128 reads)
+constexpr int FPLANE = BT * FLDHB;            // bf16 elements per plane
+constexpr int F_RED = 12 * 3 * 256;           // floats: [wave][gate][lane][4]
+constexpr int OROW = 36;                      // floats per utterance row of gbuf / obuf (32 + 4: an unpadded row puts all 16 rows on one bank)
+constexpr int OARR = BT * OROW;               // one [16 utterances][32 units] array
+constexpr int F_GBUF = 3 * OARR;              // [gate][16 utterances][32 units]
+constexpr int F_OBUF = 12 * OARR;             // per layer 6 slots: h, r, z, n, hn, dropout(h) (layer 0 only)
+constexpr int F_REGION = BT * FH;             // words of one payload block (one tile, one tensor)
+constexpr int F_BIAS = 3 * 3 * 32;            // b_hh l0, b_hh l1, b_ih l1 slices of the member: [vector][gate][32 units]
+constexpr int F_TRACE = 2 * 4 * 8 * 2;        // debug stamps (DEP_TRACE=1): [role 0 / 2][4 steps][8 slots] 64-bit
+constexpr size_t F_LDS_BYTES = (size_t)(3 * FPLANE + F_RED + F_GBUF + F_OBUF + F_BIAS + 4 + F_TRACE + 16) * sizeof(float);
+
+struct FF {
+    int B, T, nbtp, b0;
+    const u32x4* wp0; const u32x4* wp1; const u32x4* wpi;        // W_hh l0, W_hh l1, W_ih l1 images (pack_cluster_fwd_split format)
+    const float* b_hh0; const float* b_ih1; const float* b_hh1;
+    const float* gi; int ldgi;                                    // layer-0 input projection incl. b_ih (B*T, 3H)
+    float* y0; float* y1;                                         // (B,T,H) outputs; the other per-layer arrays follow each at
+    unsigned ostride; int training;                               // +k*ostride floats: [y0, dropout(y0) (DROP only), r, z, n, hn] / [y1, r, z, n, hn]
+    float drop_p, drop_scale; uint64_t seed; uint32_t site;
+    float* pooled; float pool_scale; float* hn0; float* hn1;
+    unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes; int nofast;
+    long long* trace;
+};
+
+#define FSTAMP(slot) do { if (trl && s >= 100 && s < 104) trl[(s - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+
+__device__ __forceinline__ float2 add2(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+
+// Register budget: 12 waves -> 3 per SIMD -> 168 VGPRs, 96 of them the weight slice.  Every per-thread index (utterance,
+// unit pair, LDS / payload offsets) is therefore RE-DERIVED inside the loop from a laundered copy of threadIdx.x (the
+// compiler would otherwise hoist ~40 loop-invariant address registers of all three roles out of the loop and spill -- and a
+// scratch reload in the streaming waves waits on vmcnt, i.e. on their outstanding HBM stores: 10k cycles per step measured).
+template <bool DROP>
+__global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = p.T;
+    const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
+    if (p.b0 + bt * BT >= p.B) return;
+    if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up (sticky status)
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: role tests become scalar branches
+    const int grp = w >> 2, gw = w & 3, jl = gw >> 1, kh = gw & 1;
+    const int shalf = gw >> 1;                        // group 2: which array / gate of a pair this wave streams
+    const int jt = c * 2 + jl;
+    unsigned short* hs0 = reinterpret_cast<unsigned short*>(smem);      // h0 planes: hi at +0, lo at +FPLANE
+    unsigned short* hs0d = hs0 + 2 * FPLANE;                              // dropout(h0)
+    unsigned short* hs1 = hs0 + 4 * FPLANE;                               // h1
+    float* red = smem + 3 * FPLANE;
+    float* gbuf = red + F_RED;
+    float* obuf = gbuf + F_GBUF;
+    float* bias_l = obuf + F_OBUF;                    // biases live in LDS, not in registers (the weight slice needs those)
+    float* zpair = bias_l + F_BIAS;                   // two zeros (branch-free gate math), then the debug stamps
+    for (int i = tid; i < 3 * FPLANE; i += FTHREADS) smem[i] = 0.f;
+    if (tid < 4) zpair[tid] = 0.f;
+    if (tid < F_BIAS) {
+        const int v = tid / 96, g = (tid / 32) % 3, u = tid & 31;
+        const float* src = v == 0 ? p.b_hh0 : (v == 1 ? p.b_hh1 : p.b_ih1);
+        bias_l[tid] = src[g * FH + c * 32 + u];
+    }
+    // the group's weight slice, register-resident for the whole sweep
+    u32x4 wq[3][FKS2][2];
+    {
+        const u32x4* wimg = grp == 0 ? p.wp0 : (grp == 1 ? p.wp1 : p.wpi);
+        const int lane = tid & 63;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ks = 0; ks < FKS2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    wq[g][ks][pl] = wimg[(size_t)((((jt * 3 + g) * 2 + kh) * FKS2 + ks) * 2 + pl) * 64 + lane];
+    }
+    const unsigned short* bsrc = grp == 0 ? hs0 : (grp == 1 ? hs1 : (DROP ? hs0d : hs0));
+    // per-role persistent state shares two vector registers (the roles are wave-uniform, the compiler cannot know):
+    //   groups 0 / 1: st0 = (h_prev.x, h_prev.y, pool.x, pool.y), st1 = (mask.x, mask.y, -, -)
+    //   group 2     : st0, st1 = the prefetched input-projection pieces
+    f32x4 st0 = zero4(), st1 = zero4();
+
+    const unsigned pstride = (unsigned)p.nbtp * 3 * F_REGION;           // payload words (fits 32 bits: <= 2 x 32 x 3 x 4096)
+    const unsigned tile_base = (unsigned)bt * 3 * F_REGION;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
+    unsigned* myflag = p.flags + bt * FNC + c;
+    unsigned* tflags = p.flags + bt * FNC;
+    const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * FNC, FNC, c, p.status);
+    if (sx < 0) return;
+    const bool fast = sx == 1;
+    const int b0t = p.b0 + bt * BT;                   // first utterance of the tile
+
+    // ---- streaming role of group 2: thread -> (utterance su, 16-byte piece sqd of the member's 32 units)
+    auto issue_gi = [&](int tv, int t) {
+        const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
+        const bool on = b0t + su < p.B && t < T;
+        const float* src = p.gi + ((size_t)(b0t + su) * T + t) * p.ldgi + c * 32 + sqd * 4;
+        st0 = on ? ld4(src + shalf * FH) : zero4();
+        if (shalf == 0) st1 = on ? ld4(src + 2 * FH) : zero4();
+    };
+    auto write_gbuf = [&](int tv) {
+        const int rem = tv & 127, ro = (rem >> 3) * OROW + (rem & 7) * 4;
+        *reinterpret_cast<f32x4*>(gbuf + shalf * OARR + ro) = st0;
+        if (shalf == 0) *reinterpret_cast<f32x4*>(gbuf + 2 * OARR + ro) = st1;
+    };
+    auto flush = [&](int tv, int s) {                 // results of fused step s: LDS -> HBM (16-byte stores)
+        const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
+        if (b0t + su >= p.B) return;
+        const unsigned so = ((unsigned)(b0t + su) * T) * FH + c * 32 + sqd * 4;       // < 2^28: one array is B*T*H floats
+        // obuf slot k of layer l -> array index in the reserve's order (see FF): layer 0 with dropout h,hd,r,z,n,hn
+        constexpr int dslot0[6] = {0, DROP ? 2 : 1, DROP ? 3 : 2, DROP ? 4 : 3, DROP ? 5 : 4, 1};
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+            const int a = pr * 2 + shalf;             // obuf array (wave-uniform): 0..5 layer 0, 6..10 layer 1
+            const bool l0 = a < 6;
+            const int k = l0 ? a : a - 6;
+            const bool on = (l0 ? (s < T) : (s >= 1)) && a < 11 && (k == 0 || (k == 5 ? DROP : p.training != 0));
+            const int t = l0 ? s : s - 1;
+            float* base = l0 ? p.y0 : p.y1;
+            const unsigned slot = l0 ? dslot0[k] : k;
+            if (on) *reinterpret_cast<f32x4*>(base + (size_t)slot * p.ostride + (so + (unsigned)t * FH)) = ld4(obuf + a * OARR + su * OROW + sqd * 4);
+        }
+    };
+    // inter-layer dropout: the mask of step s+1 is drawn while step s waits for the other members
+    auto draw = [&](int tv, int t) {
+        const int l = tv & 63, j = l & 15, ul = jl * 16 + (l >> 4) * 4 + 2 * kh;
+        const size_t o = ((size_t)(b0t + j) * T + t) * FH + c * 32 + ul;
+        const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+        return f2(kh ? m[2] : m[0], kh ? m[3] : m[1]);
+    };
+    if (grp == 2) { issue_gi(tid, 0); write_gbuf(tid); issue_gi(tid, 1); }
+    if (grp < 2) { st1[0] = 1.f; st1[1] = 1.f; }
+    __syncthreads();
+
+    long long* trl = nullptr;                         // workgroup 0, thread 0 (group 0) and thread 512 (group 2)
+    if (p.trace && blockIdx.x == 0 && (tid == 0 || tid == 512)) trl = reinterpret_cast<long long*>(zpair + 4) + (tid ? 32 : 0);
+    for (int s = 0; s <= T; ++s) {
+        FSTAMP(0);
+        int tv = tid;
+        asm volatile("" : "+v"(tv));                  // launder: everything derived from tv is recomputed per step, not hoisted
+        const int lane = tv & 63, j = lane & 15, q = lane >> 4;
+        const int ul = jl * 16 + q * 4 + 2 * kh;      // this lane's pair of units (ul, ul+1) inside the member's 32
+        const bool act = grp == 0 ? (s < T) : (s >= 1);
+        f32x4 acc[3] = {zero4(), zero4(), zero4()};
+        if (act) {
+            // the accumulators of the K-half-0 wave start from the group's bias (b_hh l0 / b_hh l1 / b_ih l1): the bias add is free
+            if (kh == 0) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = ld4(bias_l + grp * 96 + g * 32 + jl * 16 + q * 4);
+            }
+            const int ho = j * FLDHB + kh * 128 + q * 8;
+            bf16x8 hh[2], hl[2];                          // two k-steps in flight (registers are the scarce resource here)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                hh[ks] = *reinterpret_cast<const bf16x8*>(bsrc + ho + ks * 32);
+                hl[ks] = *reinterpret_cast<const bf16x8*>(bsrc + FPLANE + ho + ks * 32);
+            }
+#pragma unroll
+            for (int ks = 0; ks < FKS2; ++ks) {
+                const bf16x8 ch = hh[ks & 1], cl = hl[ks & 1];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[g][ks][0]), wl = __builtin_bit_cast(bf16x8, wq[g][ks][1]);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cl, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ch, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ch, acc[g], 0, 0, 0);
+                }
+                if (ks + 2 < FKS2) {
+                    hh[ks & 1] = *reinterpret_cast<const bf16x8*>(bsrc + ho + (ks + 2) * 32);
+                    hl[ks & 1] = *reinterpret_cast<const bf16x8*>(bsrc + FPLANE + ho + (ks + 2) * 32);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + ((w * 3 + g) * 64 + lane) * 4) = acc[g];
+            // the dropout mask of this step is drawn here, before the partial-sum barrier (the other groups arrive later anyway)
+            if (DROP && grp == 0) { const float2 mn = draw(tv, s); st1[0] = mn.x; st1[1] = mn.y; }
+        }
+        FSTAMP(1);
+        bar_lds();                                        // #1: partial sums (and the prefetched input projection) are in LDS
+        FSTAMP(2);
+        const unsigned pbase = (unsigned)(s & 1) * pstride + tile_base;
+        if (grp < 2 && act) {
+            // branch-free over the two roles: the input-projection term is gi = A + B with
+            //   layer 0: A = prefetched projection (gbuf), B = a zero pair ; layer 1: A, B = group 2's two K halves (b_ih inside)
+            const int e2 = lane * 4 + 2 * kh;             // this lane's pair inside a [64][4] fragment block
+            // both K halves of the lane's pair come back from LDS (the own half too: selecting acc[g][2 kh + i] in registers
+            // compiles to a dynamic-index select tree of ~150 instructions)
+            const float* po = red + (w * 3) * 256 + e2;
+            const float* pp = red + ((w ^ 1) * 3) * 256 + e2;
+            const float* pa = grp == 0 ? gbuf + j * OROW + ul : red + ((8 + jl * 2) * 3) * 256 + e2;
+            const float* pb = grp == 0 ? zpair : red + ((9 + jl * 2) * 3) * 256 + e2;
+            const int sa = grp == 0 ? OARR : 256, sb = grp == 0 ? 0 : 256;
+            float2 ov[3], pv[3], va[3], vb[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { ov[g] = ld2(po + g * 256); pv[g] = ld2(pp + g * 256); va[g] = ld2(pa + g * sa); vb[g] = ld2(pb + g * sb); }
+            float2 tot[3], gi[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { tot[g] = add2(ov[g], pv[g]); gi[g] = add2(va[g], vb[g]); }
+            float2 r, z, hn, n, h;
+            r.x = fast_sigmoid(gi[0].x + tot[0].x); r.y = fast_sigmoid(gi[0].y + tot[0].y);
+            z.x = fast_sigmoid(gi[1].x + tot[1].x); z.y = fast_sigmoid(gi[1].y + tot[1].y);
+            hn = tot[2];
+            n.x = fast_tanh(gi[2].x + r.x * hn.x); n.y = fast_tanh(gi[2].y + r.y * hn.y);
+            h.x = (1.0f - z.x) * n.x + z.x * st0[0]; h.y = (1.0f - z.y) * n.y + z.y * st0[1];
+            st0[0] = h.x; st0[1] = h.y; st0[2] += h.x; st0[3] += h.y;       // (the running sum is only read by layer 1)
+            const float2 hd = f2(h.x * st1[0], h.y * st1[1]);
+            if (s < T) {                                  // publish first: it is on the other members' critical path
+                gu64* dst = (gu64*)(p.payload + (pbase + (unsigned)(grp == 0 ? 0 : 2) * F_REGION + j * FH + c * 32 + ul));
+                const u64 bits = (u64)split_word(h.x) | ((u64)split_word(h.y) << 32);
+                if (fast) __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (DROP && grp == 0) {
+                    const u64 dbits = (u64)split_word(hd.x) | ((u64)split_word(hd.y) << 32);
+                    if (fast) __hip_atomic_store(dst + F_REGION / 2, dbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store(dst + F_REGION / 2, dbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            float* ob = obuf + grp * (6 * OARR) + j * OROW + ul;            // results for the streaming waves
+            st2(ob, h); st2(ob + OARR, r); st2(ob + 2 * OARR, z); st2(ob + 3 * OARR, n); st2(ob + 4 * OARR, hn);
+            if (DROP && grp == 0) st2(ob + 5 * OARR, hd);
+        }
+        if (s == T) break;
+        FSTAMP(3);
+        if (grp < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // payload stores acknowledged
+        FSTAMP(4);
+        bar_lds();                                        // #2: every publishing wave drained; deposits visible to group 2
+        if (tid == 0) { if (fast) st_local(myflag, (unsigned)s + 1u); else st_agent(myflag, (unsigned)s + 1u); }
+        if (grp == 2) {
+            write_gbuf(tv);                               // layer-0 input projection of step s+1 (loads issued a step ago)
+            flush(tv, s);
+            issue_gi(tv, s + 2);
+        } else {
+            FSTAMP(5);
+            if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6)) return;
+            FSTAMP(6);
+            // gather: h0_s (next layer-0 step), dropout(h0_s) (layer-1 input), h1_{s-1} (next layer-1 step)
+            const bool need0 = (s + 1 < T) || !DROP, need1 = DROP, need2 = s >= 1;
+            u32x4 v[3][2];
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg) {
+                const bool need = rg == 0 ? need0 : (rg == 1 ? need1 : need2);
+                if (need) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        v[rg][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pbase + (unsigned)rg * F_REGION + (unsigned)(tv + 512 * k) * 4) * 4, 0, 16 /* sc1 */);
+                }
+            }
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg) {
+                const bool need = rg == 0 ? need0 : (rg == 1 ? need1 : need2);
+                if (need) {
+                    unsigned short* hi = rg == 0 ? hs0 : (rg == 1 ? hs0d : hs1);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int i4 = (tv + 512 * k) * 4;
+                        const int o = (i4 >> 8) * FLDHB + (i4 & (FH - 1));
+                        const u32x4 x = v[rg][k];
+                        uint2 hi2, lo2;
+                        hi2.x = (x.x >> 16) | (x.y & 0xffff0000u); hi2.y = (x.z >> 16) | (x.w & 0xffff0000u);
+                        lo2.x = (x.x & 0xffffu) | (x.y << 16);      lo2.y = (x.z & 0xffffu) | (x.w << 16);
+                        *reinterpret_cast<uint2*>(hi + o) = hi2; *reinterpret_cast<uint2*>(hi + FPLANE + o) = lo2;
+                    }
+                }
+            }
+        }
+        FSTAMP(7);
+        bar_lds();                                        // #3: planes of step s+1 complete, obuf / gbuf handed over
+    }
+    bar_lds();                                            // the last layer-1 step's results are in obuf
+    if (trl) { long long* o = p.trace + (tid ? 32 : 0); for (int i = 0; i < 32; ++i) o[i] = trl[i]; }
+    if (grp == 2) flush(tid, T);
+    {
+        const int lane = tid & 63, j = lane & 15, ul = jl * 16 + (lane >> 4) * 4 + 2 * kh;
+        const int b = b0t + j, col = c * 32 + ul;
+        if (b < p.B) {
+            if (grp == 0 && p.hn0) st2(p.hn0 + (size_t)b * FH + col, f2(st0[0], st0[1]));
+            if (grp == 1) {
+                if (p.pooled) st2(p.pooled + (size_t)b * FH + col, f2(st0[2] * p.pool_scale, st0[3] * p.pool_scale));
+                if (p.hn1) st2(p.hn1 + (size_t)b * FH + col, f2(st0[0], st0[1]));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool dep_fused2_ok(int cell, int H, int L, int dirs) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("DEP_FUSED2"); off = (e && e[0] == '0') ? 1 : 0; }
+    return !off && cell == DEP_CELL_GRU && H == FH && L == 2 && dirs == 1;
+}
+
+size_t dep_fused2_xbuf_bytes(int B) {
+    const int CH = dep_cluster_chunk(FNC, 1, 256);
+    const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
+    return PAYLOAD_OFF + (size_t)2 * nbtp * 3 * F_REGION * sizeof(float) + 4096;
+}
+
+int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_bytes) {
+    const int CH = dep_cluster_chunk(FNC, 1, 256);
+    const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
+    FF p{};
+    p.B = a.B; p.T = a.T;
+    p.wp0 = (const u32x4*)a.wp0; p.wp1 = (const u32x4*)a.wp1; p.wpi = (const u32x4*)a.wpi;
+    p.b_hh0 = a.b_hh0; p.b_ih1 = a.b_ih1; p.b_hh1 = a.b_hh1;
+    p.gi = a.gi; p.ldgi = 3 * FH;
+    const bool drop = a.drop_p > 0.f;
+    p.y0 = a.y0; p.y1 = a.y1; p.ostride = (unsigned)a.ostride; p.training = a.training;
+    p.drop_p = a.drop_p; p.drop_scale = drop ? 1.0f / (1.0f - a.drop_p) : 1.0f; p.seed = a.seed; p.site = a.site;
+    p.pooled = a.pooled; p.pool_scale = a.pool_scale; p.hn0 = a.hn0; p.hn1 = a.hn1;
+    // the kernel addresses every per-layer output array as y_l + k * ostride: check the caller's layout really is that
+    DEP_CHECK_ARG(!drop || a.y0d == a.y0 + a.ostride);
+    if (a.training) for (int k = 0; k < 4; ++k)
+        DEP_CHECK_ARG(a.sv[0][k] == a.y0 + (size_t)(k + (drop ? 2 : 1)) * a.ostride && a.sv[1][k] == a.y1 + (size_t)(k + 1) * a.ostride);
+    const size_t pay = (size_t)2 * nbtp_max * 3 * F_REGION * sizeof(float);
+    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * FNC <= 256);
+    DEP_CHECK_ARG(!drop || a.y0d);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
+    p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+        attr = true;
+    }
+    DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
+    for (int b0 = 0; b0 < a.B; b0 += CH) {
+        const int cb = a.B - b0 < CH ? a.B - b0 : CH;
+        p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
+        // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
+        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        if (drop) hipLaunchKernelGGL(gru2_fwd_fused<true>, dim3(FNC * p.nbtp), dim3(FTHREADS), F_LDS_BYTES, a.stream, p);
+        else hipLaunchKernelGGL(gru2_fwd_fused<false>, dim3(FNC * p.nbtp), dim3(FTHREADS), F_LDS_BYTES, a.stream, p);
+        DEP_CHECK_LAUNCH();
+    }
+    return DEP_OK;
+}

@@ -10,12 +10,13 @@ NaN or a different bit pattern: every iteration must reproduce the first one bit
 clean.  --load runs a GEMM loop on a second stream while the sweeps run (uneven load: the GEMM's workgroups take CU
 slots, delay cluster members and keep the L2 / fabric busy).  Prints one JSON line.
 
-Finding this driver produced (round 2): the 16-unit-member GRU forward (rnn_cluster16.hip, two 5-wave workgroups per CU)
-fills the register file of some SIMDs completely, so a foreign workgroup that arrives while the launch is still being
+Finding this driver produced (round 2): the GRU forward kernels that fill a CU's register file -- the fused two-layer launch
+(rnn_fused2.hip, twelve 168-VGPR waves per CU) and the 16-unit-member kernel (rnn_cluster16.hip, two 5-wave workgroups per
+CU) -- leave no room for anybody else, so a foreign workgroup that arrives while the launch is still being
 dispatched cannot be placed, blocks the dispatcher, and the not-yet-resident cluster members never arrive: the sweep
 gives up LOUDLY (status 5 -> DepError), never silently.  That kernel therefore needs the GPU to itself (the product runs
-the forward on one stream with nothing beside it; DEP_CLUSTER16=0 selects the one-workgroup-per-CU forward that tolerates
-co-scheduled kernels).  Every other sweep kernel (one workgroup per CU, LDS / VGPR headroom left) is exercised under
+the forward on one stream with nothing beside it; DEP_FUSED2=0 DEP_CLUSTER16=0 selects the 4-wave one-workgroup-per-CU
+forward that tolerates co-scheduled kernels).  Every other sweep kernel (one workgroup per CU, LDS / VGPR headroom left) is exercised under
 load here, which is what an overlapped gradient all-reduce needs: collectives only ever overlap the BACKWARD sweeps.
 """
 import argparse

@@ -21,7 +21,9 @@ CASES = [
     ('gru', 6, {'DEP_NUM_CUS': '200'}, []),
     ('gru', 12, {}, ['--load', '--load-phase', 'bwd']),            # what an overlapped all-reduce does: load beside the backward
     ('gru', 8, {'DEP_CLUSTER_NOFAST': '1'}, ['--load', '--load-phase', 'bwd']),
-    ('gru', 8, {'DEP_CLUSTER16': '0'}, ['--load']),                # co-scheduling-tolerant forward (one workgroup per CU) + load on both halves
+    ('gru', 8, {'DEP_CLUSTER16': '0', 'DEP_FUSED2': '0'}, ['--load']),   # co-scheduling-tolerant forward (one 4-wave workgroup per CU) + load on both halves
+    ('gru', 10, {'DEP_FUSED2': '0'}, []),                         # per-layer forward kernels (16-unit members) instead of the fused 2-layer launch
+    ('gru', 6, {'DEP_FUSED2': '0', 'DEP_CLUSTER_NOFAST': '1'}, []),
     ('gru', 8, {}, ['--load', '--H', '128']),
     ('gru', 8, {'DEP_GEMM_MODE': 'f32'}, []),                    # exact-fp32 sweeps (different member kernels)
     ('gru', 8, {}, ['--H', '128']),                               # 32-unit-member forward kernel

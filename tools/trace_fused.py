@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""DEP_TRACE=1 python tools/trace_fused.py : phase timings (shader cycles) of workgroup 0 of the fused 2-layer GRU forward
+(rnn_fused2.hip): thread 0 (group 0, on the critical path) and thread 512 (group 2, input projection + HBM streams)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from icassp2022_depression_amd import _lib as L  # noqa: E402
+
+B, T, F, H = 512, 300, 256, 256
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+x = torch.randn(B, T, F, device=dev)
+k = H ** -0.5
+W = []
+for l in range(2):
+    W += [(torch.rand(3 * H, F if l == 0 else H, device=dev) * 2 - 1) * k, (torch.rand(3 * H, H, device=dev) * 2 - 1) * k,
+          (torch.rand(3 * H, device=dev) * 2 - 1) * k, (torch.rand(3 * H, device=dev) * 2 - 1) * k]
+p = float(os.environ.get('DROP', '0.5'))
+rnn = L.Rnn(L.CELL_GRU, B, T, F, H, 2, 1, True, p, L.POOL_MEAN, dev)
+pooled = torch.empty(B, H, device=dev)
+for _ in range(3):
+    rnn.forward(x, W, pooled=pooled, seed=3)
+torch.cuda.synchronize()
+rnn.check()
+off = L.load().dep_rnn_workspace_xbuf_offset(C.byref(rnn.desc))
+tr = rnn.workspace[(off + 6144) // 4:(off + 6144) // 4 + 128].view(torch.int64).cpu().numpy().reshape(2, 4, 8)
+n0 = ['frags+MFMA+red', 'barrier#1', 'gates+publish+deposit', 'drain vmcnt', 'barrier#2+flag', 'mask draw', 'poll', 'gather->LDS']
+for s in range(4):
+    a = tr[0, s]
+    d = [int(a[i + 1] - a[i]) for i in range(7)]
+    nxt = int(tr[0, s + 1, 0] - a[7]) if s < 3 else 0
+    print(f'g0 step {100 + s}: total {int(a[7] - a[0])} + barrier#3 {nxt} | ' + ' | '.join(f'{n}: {v}' for n, v in zip(n0, d)))
+for s in range(4):
+    a = tr[1, s]
+    print(f'g2 step {100 + s}: MFMA+red {int(a[1] - a[0])} | barrier#1 {int(a[2] - a[1])} | idle->#2 {int(a[4] - a[2])} | stream (gbuf, flush, issue) {int(a[7] - a[4])}'
+          + (f' | barrier#3 {int(tr[1, s + 1, 0] - a[7])}' if s < 3 else ''))
