@@ -1,20 +1,22 @@
-// Two-layer GRU forward as ONE cluster-parallel launch: layer 1 runs one step behind layer 0 (wavefront over the layers),
+// Two-layer GRU forward as ONE cluster-parallel launch: layer 1 runs two steps behind layer 0 (wavefront over the layers),
 // so a forward pass costs T + 1 dependent hand-offs instead of 2 T, and layer 1's input projection never exists in HBM.
 //
 // Per 16-utterance tile a cluster of NC = 8 workgroups (one per CU, all co-resident); member c owns hidden units
 // [32c, 32c + 32) of BOTH layers.  Twelve waves, three groups of four (wave = (16-unit column tile jl, K half kh) as in
 // gru_fwd_cluster_r1), each group keeping one 96 x 256 weight slice register-resident as (hi, lo) bf16 planes (96 VGPRs):
 //   group 0 : W_hh of layer 0     x h0_{s-1}              -> layer-0 step s
-//   group 1 : W_hh of layer 1     x h1_{s-2}              -> layer-1 step s-1
-//   group 2 : W_ih of layer 1     x dropout(h0_{s-1})     -> layer-1 step s-1's input projection; these waves have no gate
-//             math, so they also own every HBM stream of the member (prefetch of layer 0's input projection, write-out of
-//             h, dropout(h) and the saved gates of both layers) -- the waves on the critical path never touch HBM.
-// Fused step s (0..T): [36 MFMAs per wave] -> barrier -> [gate math of both layers on groups 0 / 1] -> payload stores
-// (h0_s, dropout(h0_s), h1_{s-1} as bf16 (hi << 16 | lo) words), drain, barrier, ONE flag per member -> poll the cluster's
-// 8 flags -> gather the three 16 x 256 blocks into LDS planes -> barrier.  Exchange protocol, same-XCD fast path, parity
+//   group 1 : W_hh of layer 1     x h1_{s-3}              -> layer-1 step s-2
+//   group 2 : W_ih of layer 1     x dropout(h0_{s-1})     -> input projection of layer-1 step s-1 (consumed one fused step
+//             later).  These waves have no gate math: their MFMAs run while groups 0 / 1 do theirs (the matrix pipe is idle
+//             then), and they own every HBM stream of the member (prefetch of layer 0's input projection, write-out of h,
+//             dropout(h) and the saved gates of both layers) -- the waves on the critical path never touch HBM.
+// Fused step s (0..T+1): [groups 0/1: 36 MFMAs per wave | group 2: write-out of step s-1] -> barrier -> [gate math of both
+// layers | group 2: its MFMAs] -> payload stores (h0_s, dropout(h0_s), h1_{s-2} as bf16 (hi << 16 | lo) words), drain,
+// barrier, ONE flag per member -> [poll the cluster's 8 flags, gather the three 16 x 256 blocks into LDS planes | group 2:
+// partial sums to LDS, input-projection prefetch] -> barrier.  Exchange protocol, same-XCD fast path, parity
 // double-buffered payload, bounded spins and sticky status: rnn_cluster_common.h.  Products use the 3-term bf16 split
 // (w_hi h_lo + w_lo h_hi + w_hi h_hi, fp32 accumulate), everything elementwise is fp32.
-// The matrix pipe bounds a step from below: 3 x 36 v_mfma_f32_16x16x32_bf16 per SIMD = 1728 cycles.
+// Matrix-pipe time per step and SIMD: 2 x 36 v_mfma_f32_16x16x32_bf16 on the critical path (1152 cycles) + 36 beside the gate math.
 #include "rnn_cluster_common.h"
 
 namespace {
@@ -46,7 +48,7 @@ struct FF {
     long long* trace;
 };
 
-#define FSTAMP(slot) do { if (trl && s >= 100 && s < 104) trl[(s - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define FSTAMP(slot) do { if (TRACE && trl && s >= 100 && s < 104) trl[(s - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ float2 add2(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
@@ -54,7 +56,7 @@ __device__ __forceinline__ float2 add2(float2 a, float2 b) { return make_float2(
 // unit pair, LDS / payload offsets) is therefore RE-DERIVED inside the loop from a laundered copy of threadIdx.x (the
 // compiler would otherwise hoist ~40 loop-invariant address registers of all three roles out of the loop and spill -- and a
 // scratch reload in the streaming waves waits on vmcnt, i.e. on their outstanding HBM stores: 10k cycles per step measured).
-template <bool DROP>
+template <bool DROP, bool TRACE>
 __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T;
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             const int a = pr * 2 + shalf;             // obuf array (wave-uniform): 0..5 layer 0, 6..10 layer 1
             const bool l0 = a < 6;
             const int k = l0 ? a : a - 6;
-            const bool on = (l0 ? (s < T) : (s >= 1)) && a < 11 && (k == 0 || (k == 5 ? DROP : p.training != 0));
-            const int t = l0 ? s : s - 1;
+            const bool on = (l0 ? (s < T) : (s >= 2)) && a < 11 && (k == 0 || (k == 5 ? DROP : p.training != 0));
+            const int t = l0 ? s : s - 2;
             float* base = l0 ? p.y0 : p.y1;
             const unsigned slot = l0 ? dslot0[k] : k;
             if (on) *reinterpret_cast<f32x4*>(base + (size_t)slot * p.ostride + (so + (unsigned)t * FH)) = ld4(obuf + a * OARR + su * OROW + sqd * 4);
@@ -150,19 +152,27 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     };
     if (grp == 2) { issue_gi(tid, 0); write_gbuf(tid); issue_gi(tid, 1); }
     if (grp < 2) { st1[0] = 1.f; st1[1] = 1.f; }
+    if (DROP && grp == 0) { const float2 m0 = draw(tid, 0); st1[0] = m0.x; st1[1] = m0.y; }
     __syncthreads();
 
     long long* trl = nullptr;                         // workgroup 0, thread 0 (group 0) and thread 512 (group 2)
-    if (p.trace && blockIdx.x == 0 && (tid == 0 || tid == 512)) trl = reinterpret_cast<long long*>(zpair + 4) + (tid ? 32 : 0);
-    for (int s = 0; s <= T; ++s) {
+    if (TRACE && p.trace && blockIdx.x == 0 && (tid == 0 || tid == 512)) trl = reinterpret_cast<long long*>(zpair + 4) + (tid ? 32 : 0);
+    // Group 2 runs ONE BARRIER out of phase with groups 0 / 1 (it passes one extra barrier here and one fewer at the end): its
+    // slot X (the MFMAs) then coincides with their slot Y (gate math, matrix pipe idle), its slot Y (partial sums to LDS,
+    // input-projection prefetch) with their slot Z (poll + gather), its slot Z (write-out of the step) with their next slot X.
+    // One loop body, one MFMA code site for all three roles -- two sites cost 16 VGPRs of spills.
+    if (grp == 2) bar_lds();
+    for (int s = 0; s <= T + 1; ++s) {
+        if (grp == 2 && s == T + 1) break;
         FSTAMP(0);
         int tv = tid;
         asm volatile("" : "+v"(tv));                  // launder: everything derived from tv is recomputed per step, not hoisted
         const int lane = tv & 63, j = lane & 15, q = lane >> 4;
         const int ul = jl * 16 + q * 4 + 2 * kh;      // this lane's pair of units (ul, ul+1) inside the member's 32
-        const bool act = grp == 0 ? (s < T) : (s >= 1);
+        // group 0: layer-0 step s ; group 1: layer-1 step s-2 ; group 2: input projection of layer-1 step s-1 (phase 2)
+        const bool act = grp == 0 ? (s < T) : (grp == 1 ? (s >= 2) : (s >= 1 && s <= T));
         f32x4 acc[3] = {zero4(), zero4(), zero4()};
-        if (act) {
+        auto matvec = [&]() {
             // the accumulators of the K-half-0 wave start from the group's bias (b_hh l0 / b_hh l1 / b_ih l1): the bias add is free
             if (kh == 0) {
 #pragma unroll
@@ -190,14 +200,26 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                     hl[ks & 1] = *reinterpret_cast<const bf16x8*>(bsrc + FPLANE + ho + (ks + 2) * 32);
                 }
             }
+        };
+        auto put_red = [&]() {
 #pragma unroll
             for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + ((w * 3 + g) * 64 + lane) * 4) = acc[g];
-            // the dropout mask of this step is drawn here, before the partial-sum barrier (the other groups arrive later anyway)
-            if (DROP && grp == 0) { const float2 mn = draw(tv, s); st1[0] = mn.x; st1[1] = mn.y; }
+        };
+        // ---- slot X
+        if (act) matvec();
+        if (grp < 2 && act) {
+            put_red();
         }
         FSTAMP(1);
-        bar_lds();                                        // #1: partial sums (and the prefetched input projection) are in LDS
+        bar_lds();                                        // groups 0/1: #1 of step s (partial sums in LDS) | group 2: #2 of step s
         FSTAMP(2);
+        if (grp == 2) {                                   // ---- slot Y of group 2 (the others are polling / gathering); placed before the gate block so that
+                                                          // the accumulators' live range does not span it
+            if (act) put_red();                           // group 1 reads these partial sums in the next step's gate phase
+            write_gbuf(tv);                               // layer-0 input projection of step s+1 (loads issued a step ago)
+            issue_gi(tv, s + 2);
+            flush(tv, s);                                 // write-out of step s (deposited before the barrier just passed)
+        }
         const unsigned pbase = (unsigned)(s & 1) * pstride + tile_base;
         if (grp < 2 && act) {
             // branch-free over the two roles: the input-projection term is gi = A + B with
@@ -224,7 +246,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             h.x = (1.0f - z.x) * n.x + z.x * st0[0]; h.y = (1.0f - z.y) * n.y + z.y * st0[1];
             st0[0] = h.x; st0[1] = h.y; st0[2] += h.x; st0[3] += h.y;       // (the running sum is only read by layer 1)
             const float2 hd = f2(h.x * st1[0], h.y * st1[1]);
-            if (s < T) {                                  // publish first: it is on the other members' critical path
+            if (s <= T) {                                 // publish first: it is on the other members' critical path
                 gu64* dst = (gu64*)(p.payload + (pbase + (unsigned)(grp == 0 ? 0 : 2) * F_REGION + j * FH + c * 32 + ul));
                 const u64 bits = (u64)split_word(h.x) | ((u64)split_word(h.y) << 32);
                 if (fast) __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -238,38 +260,52 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             float* ob = obuf + grp * (6 * OARR) + j * OROW + ul;            // results for the streaming waves
             st2(ob, h); st2(ob + OARR, r); st2(ob + 2 * OARR, z); st2(ob + 3 * OARR, n); st2(ob + 4 * OARR, hn);
             if (DROP && grp == 0) st2(ob + 5 * OARR, hd);
+            // next step's dropout mask: Philox work in the shadow of the payload stores' acknowledgement (the drain below)
+            if (DROP && grp == 0 && s + 1 < T) { const float2 mn = draw(tv, s + 1); st1[0] = mn.x; st1[1] = mn.y; }
         }
-        if (s == T) break;
+        if (grp < 2 && s == T + 1) break;
         FSTAMP(3);
         if (grp < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // payload stores acknowledged
         FSTAMP(4);
-        bar_lds();                                        // #2: every publishing wave drained; deposits visible to group 2
+        bar_lds();                                        // groups 0/1: #2 (every publishing wave drained) | group 2: #3
         if (tid == 0) { if (fast) st_local(myflag, (unsigned)s + 1u); else st_agent(myflag, (unsigned)s + 1u); }
         if (grp == 2) {
-            write_gbuf(tv);                               // layer-0 input projection of step s+1 (loads issued a step ago)
-            flush(tv, s);
-            issue_gi(tv, s + 2);
+            // slot Z of group 2.  dropout(h0_s) is only read by this group (next slot X), so it gathers that block itself:
+            // passing barrier #3 means groups 0 / 1 of this workgroup saw all eight flags, no poll needed.
+            if (DROP && s < T) {
+                u32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pbase + (unsigned)F_REGION + (unsigned)((tv & 255) + 256 * k) * 4) * 4, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i4 = ((tv & 255) + 256 * k) * 4;
+                    const int o = (i4 >> 8) * FLDHB + (i4 & (FH - 1));
+                    uint2 hi2, lo2;
+                    hi2.x = (v[k].x >> 16) | (v[k].y & 0xffff0000u); hi2.y = (v[k].z >> 16) | (v[k].w & 0xffff0000u);
+                    lo2.x = (v[k].x & 0xffffu) | (v[k].y << 16);      lo2.y = (v[k].z & 0xffffu) | (v[k].w << 16);
+                    *reinterpret_cast<uint2*>(hs0d + o) = hi2; *reinterpret_cast<uint2*>(hs0d + FPLANE + o) = lo2;
+                }
+            }
         } else {
             FSTAMP(5);
             if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6)) return;
             FSTAMP(6);
-            // gather: h0_s (next layer-0 step), dropout(h0_s) (layer-1 input), h1_{s-1} (next layer-1 step)
-            const bool need0 = (s + 1 < T) || !DROP, need1 = DROP, need2 = s >= 1;
-            u32x4 v[3][2];
+            // gather: h0_s (next layer-0 step; also layer 1's input when there is no dropout) and h1_{s-2} (next layer-1 step)
+            const bool need0 = (s + 1 < T) || (!DROP && s < T), need2 = s >= 2;
+            u32x4 v[2][2];
 #pragma unroll
-            for (int rg = 0; rg < 3; ++rg) {
-                const bool need = rg == 0 ? need0 : (rg == 1 ? need1 : need2);
-                if (need) {
+            for (int rg = 0; rg < 2; ++rg) {
+                if (rg == 0 ? need0 : need2) {
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
-                        v[rg][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pbase + (unsigned)rg * F_REGION + (unsigned)(tv + 512 * k) * 4) * 4, 0, 16 /* sc1 */);
+                        v[rg][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pbase + (unsigned)(rg * 2) * F_REGION + (unsigned)(tv + 512 * k) * 4) * 4, 0, 16 /* sc1 */);
                 }
             }
 #pragma unroll
-            for (int rg = 0; rg < 3; ++rg) {
-                const bool need = rg == 0 ? need0 : (rg == 1 ? need1 : need2);
-                if (need) {
-                    unsigned short* hi = rg == 0 ? hs0 : (rg == 1 ? hs0d : hs1);
+            for (int rg = 0; rg < 2; ++rg) {
+                if (rg == 0 ? need0 : need2) {
+                    unsigned short* hi = rg == 0 ? hs0 : hs1;
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int i4 = (tv + 512 * k) * 4;
@@ -284,11 +320,11 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             }
         }
         FSTAMP(7);
-        bar_lds();                                        // #3: planes of step s+1 complete, obuf / gbuf handed over
+        bar_lds();                                        // groups 0/1: #3 (planes of step s+1 complete) | group 2: #1 of step s+1
     }
     bar_lds();                                            // the last layer-1 step's results are in obuf
-    if (trl) { long long* o = p.trace + (tid ? 32 : 0); for (int i = 0; i < 32; ++i) o[i] = trl[i]; }
-    if (grp == 2) flush(tid, T);
+    if (TRACE && trl) { long long* o = p.trace + (tid ? 32 : 0); for (int i = 0; i < 32; ++i) o[i] = trl[i]; }
+    if (grp == 2) flush(tid, T + 1);
     {
         const int lane = tid & 63, j = lane & 15, ul = jl * 16 + (lane >> 4) * 4 + 2 * kh;
         const int b = b0t + j, col = c * 32 + ul;
@@ -340,8 +376,10 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
         attr = true;
     }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
@@ -350,8 +388,14 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
-        if (drop) hipLaunchKernelGGL(gru2_fwd_fused<true>, dim3(FNC * p.nbtp), dim3(FTHREADS), F_LDS_BYTES, a.stream, p);
-        else hipLaunchKernelGGL(gru2_fwd_fused<false>, dim3(FNC * p.nbtp), dim3(FTHREADS), F_LDS_BYTES, a.stream, p);
+        const dim3 grid(FNC * p.nbtp), blk(FTHREADS);
+        if (p.trace) {                                    // DEP_TRACE=1: the stamped variant (tools/trace_fused.py)
+            if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+            else hipLaunchKernelGGL((gru2_fwd_fused<false, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+        } else {
+            if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, false>), grid, blk, F_LDS_BYTES, a.stream, p);
+            else hipLaunchKernelGGL((gru2_fwd_fused<false, false>), grid, blk, F_LDS_BYTES, a.stream, p);
+        }
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
