@@ -289,7 +289,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             }
         } else {
             FSTAMP(5);
-            if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6)) return;
+            if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6)) return;      // every wave polls (one poller + a verdict barrier measured no faster)
             FSTAMP(6);
             // gather: h0_s (next layer-0 step; also layer 1's input when there is no dropout) and h1_{s-2} (next layer-1 step)
             const bool need0 = (s + 1 < T) || (!DROP && s < T), need2 = s >= 2;
