@@ -81,6 +81,11 @@ _SIGS = {
     'dep_reduce_loss': (C.c_int, [_P, C.c_int, C.c_float, _P, C.c_int, _P]),
     'dep_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int, C.c_int, _P]),
+    'dep_frame_window': (C.c_int, [_P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'dep_power_spectrum': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'dep_log_floor': (C.c_int, [_P, _P, C.c_long, C.c_float, _P]),
+    'dep_row_softmax': (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    'dep_vlad_normalize': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     'dep_profile_enable': (C.c_int, [C.c_int]),
     'dep_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     'dep_fill': (C.c_int, [_P, C.c_long, C.c_float, _P]),

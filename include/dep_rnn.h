@@ -264,6 +264,23 @@ int dep_reduce_loss(const float* loss_rows, int B, float norm, float* loss_out, 
 int dep_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int decoupled, int step, void* stream);
 
+/* ------------------------------------------------------------------ feature front-end */
+/* wav2vlad of Classification/audio_features_whole.py:57-72: log-mel spectrogram (librosa.feature.melspectrogram defaults:
+ * n_fft 2048, hop 512, periodic Hann, centred frames with reflect padding, power 2, 80 Slaney mel filters) followed by
+ * loupe_keras.NetVLAD(feature_size 80, cluster_size 16, output_dim 256).  The five contractions run on dep_gemm_f32
+ * (windowed frames x [cos | -sin] DFT basis, power x mel filters, frames x cluster weights, assignment^T x frames,
+ * VLAD x hidden weights); these entry points are the passes between them.
+ *   dep_frame_window   : out (n_frames, n_fft) = reflect-padded y framed at `hop`, times the Hann window
+ *   dep_power_spectrum : reim (rows, ld) = [re(0..bins) | im(0..bins)] -> power (rows, bins) = re^2 + im^2
+ *   dep_log_floor      : y = log(max(floor, x))                       (np.log(np.maximum(1e-6, melspec)))
+ *   dep_row_softmax    : softmax over the last axis, C <= 64          (NetVLAD soft assignment)
+ *   dep_vlad_normalize : vkf (K,F) = assignment^T x frames, a_sum (K), w2 (F,K) -> out (F*K) = l2norm_all(l2norm_f(vkf^T - a_sum*w2)) */
+int dep_frame_window(const float* y, long n, int n_fft, int hop, int n_frames, float* out, void* stream);
+int dep_power_spectrum(const float* reim, int rows, int bins, int ld, float* power, void* stream);
+int dep_log_floor(const float* x, float* y, long n, float floor_value, void* stream);
+int dep_row_softmax(const float* z, float* p, int rows, int C, void* stream);
+int dep_vlad_normalize(const float* vkf, const float* a_sum, const float* w2, float* out, int F, int K, void* stream);
+
 /* ------------------------------------------------------------------ profiling ------ */
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
  * roofline figure).  Categories: 0 GRU fwd sweep, 1 GRU bwd sweep, 2 LSTM fwd sweep, 3 LSTM bwd sweep,
