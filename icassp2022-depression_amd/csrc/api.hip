@@ -72,6 +72,7 @@ struct Layout {
     size_t reserve_floats;
     // workspace (float offsets)
     size_t gi, dghn, dx[2], dbpart, biastmp, gemm, xbuf;
+    size_t gi2, dghn2, dbpart2;      // second set of gate-gradient buffers: the fused backward keeps both layers' dgi / dghn
     size_t gemm_bytes, xbuf_bytes, ws_floats;
     int nwg;
     bool drop;
@@ -140,9 +141,18 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     lo.xbuf = w; lo.xbuf_bytes = !lo.cluster ? 0 : (d->cell == DEP_CELL_GRU ? dep_cluster_xbuf_bytes(d->cell, d->H, d->B, d->dirs)
                                                                 : dep_cluster_lstm_xbuf_bytes(d->H, d->B, d->dirs));
     lo.fused2 = lo.cluster && dep_fused2_ok(d->cell, d->H, d->L, d->dirs);
-    if (lo.fused2) { const size_t fb = dep_fused2_xbuf_bytes(d->B); if (fb > lo.xbuf_bytes) lo.xbuf_bytes = fb; }
+    if (lo.fused2) {
+        size_t fb = dep_fused2_xbuf_bytes(d->B); if (fb > lo.xbuf_bytes) lo.xbuf_bytes = fb;
+        if (d->training) { fb = dep_fused2_bwd_xbuf_bytes(d->B); if (fb > lo.xbuf_bytes) lo.xbuf_bytes = fb; }
+    }
     w += al(lo.xbuf_bytes / sizeof(float) + 64);
     lo.wih_img = w; if (lo.fused2) w += al(G * H * H);
+    lo.gi2 = lo.dghn2 = lo.dbpart2 = 0;
+    if (lo.fused2 && d->training) {
+        lo.gi2 = w; w += al(lo.BT * G * H);
+        lo.dghn2 = w; w += al(lo.BT * H);
+        lo.dbpart2 = w; w += al((size_t)lo.nwg * 4 * H);
+    }
     lo.ws_floats = w;
     return true;
 }
@@ -373,6 +383,50 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     const int BTr = (int)lo.BT;
     void* gws = W + lo.gemm; const size_t gwsb = lo.gemm_bytes;
     int rc;
+    static int fused_bwd_off = -1;
+    if (fused_bwd_off < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fused_bwd_off = (e && e[0] == '0') ? 1 : 0; }
+    if (lo.fused2 && !fused_bwd_off && sweep_split_mode()) {
+        // both layers in one launch: layer 0 one step behind layer 1; layer 1's dX (the gradient into layer 0) stays on chip
+        const float* const* w0 = weights; const float* const* w1 = weights + 4;
+        float* const* g0 = dweights; float* const* g1 = dweights + 4;
+        for (int k = 0; k < 4; ++k) DEP_CHECK_ARG(w0[k] && w1[k] && g0[k] && g1[k]);
+        rc = dep_pack_cluster_bwd_split(w1[0], W + lo.wih_img, H, s); if (rc) return rc;
+        dep_fused2_bwd_args f{};
+        f.B = B; f.T = T;
+        f.wh1 = R + lo.wpT[1][0]; f.wi1 = W + lo.wih_img; f.wh0 = R + lo.wpT[0][0];
+        f.y1 = R + lo.y[1]; f.y0 = R + lo.y[0]; f.sv1 = R + lo.sv[1][0]; f.sv0 = R + lo.sv[0][0];
+        f.svstride = (lo.BT * H + 63) / 64 * 64;
+        f.dy = dy; f.dpooled = dpooled; f.pool_scale = d->pool == DEP_POOL_MEAN ? 1.0f / (float)T : 1.0f;
+        f.dhn1 = dh_n ? dh_n + (size_t)B * H : nullptr; f.dhn0 = dh_n;
+        f.drop_p = lo.drop ? d->dropout_p : 0.f; f.seed = d->seed; f.site = DEP_SITE_RNN0;
+        f.dgi1 = W + lo.gi; f.dghn1 = W + lo.dghn; f.dgi0 = W + lo.gi2; f.dghn0 = W + lo.dghn2;
+        f.dbpart1 = W + lo.dbpart; f.dbpart0 = W + lo.dbpart2; f.dbpart_rows = lo.nwg; f.stream = s;
+        rc = dep_launch_fused2_bwd(f, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
+        for (int l = 1; l >= 0; --l) {
+            const float* const* wl = l ? w1 : w0; float* const* gl = l ? g1 : g0;
+            const float* dg = l ? f.dgi1 : f.dgi0; const float* dgh = l ? f.dghn1 : f.dghn0;
+            const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[0] : R + lo.y[0]);
+            const int Kl = l == 0 ? d->F : H;
+            dep_sweep_bwd_args a{};
+            a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = 1; a.impl = d->impl; a.dbpart = l ? f.dbpart1 : f.dbpart0; a.stream = s;
+            float* dbi[2] = {gl[2], nullptr}; float* dbh[2] = {gl[3], nullptr};
+            rc = dep_finish_db(a, dbi, dbh); if (rc) return rc;
+            if (l == 0 && dx) {
+                rc = dep_gemm_internal(0, 0, BTr, Kl, G * H, dg, G * H, wl[0], Kl, dx, Kl, nullptr, 0.f, 0, 0, nullptr, 0, s);
+                if (rc) return rc;
+            }
+            rc = dep_gemm_internal(1, 0, G * H, Kl, BTr, dg, G * H, in, Kl, gl[0], Kl, nullptr, 0.f, 0, 0, gws, gwsb, s); if (rc) return rc;
+            const float* yl = R + lo.y[l];
+            rc = dep_gemm_internal(1, 0, 2 * H, H, BTr, dg, G * H, yl, H, gl[1], H, nullptr, 0.f, T, -1, gws, gwsb, s); if (rc) return rc;
+            rc = dep_gemm_internal(1, 0, H, H, BTr, dgh, H, yl, H, gl[1] + (size_t)2 * H * H, H, nullptr, 0.f, T, -1, gws, gwsb, s);
+            if (rc) return rc;
+            if (gs && gs->comm && gs->range_ptr[l] && gs->range_count[l] > 0) {
+                rc = dep_comm_enqueue_after((dep_comm*)gs->comm, gs->range_ptr[l], gs->range_count[l], s, (hipStream_t)gs->comm_stream);
+                if (rc) return rc;
+            }
+        }
+        return DEP_OK;
+    }
     for (int l = L - 1; l >= 0; --l) {
         const bool top = l == L - 1;
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);

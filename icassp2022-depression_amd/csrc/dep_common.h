@@ -176,6 +176,18 @@ struct dep_fused2_args {
 bool dep_fused2_ok(int cell, int H, int L, int dirs);
 size_t dep_fused2_xbuf_bytes(int B);
 int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_bytes);
+// rnn_fused2_bwd.hip: BPTT of both layers in one cluster launch, layer 0 one step behind layer 1
+struct dep_fused2_bwd_args {
+    int B, T;
+    const float* wh1; const float* wi1; const float* wh0;     // dep_pack_cluster_bwd_split images of W_hh l1, W_ih l1, W_hh l0
+    const float* y1; const float* y0; const float* sv1; const float* sv0; size_t svstride;
+    const float* dy; const float* dpooled; float pool_scale; const float* dhn1; const float* dhn0;
+    float drop_p; uint64_t seed; uint32_t site;
+    float* dgi1; float* dghn1; float* dgi0; float* dghn0; float* dbpart1; float* dbpart0; int dbpart_rows;
+    hipStream_t stream;
+};
+size_t dep_fused2_bwd_xbuf_bytes(int B);
+int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_bytes);
 // comm.hip: all-reduce of [buf, buf+n) on comm_stream after everything enqueued so far on `compute`
 int dep_comm_enqueue_after(dep_comm* c, float* buf, long n, hipStream_t compute, hipStream_t comm_stream);
 // clears the sticky status word of a cluster exchange buffer (once per dep_rnn_forward; the sweeps themselves never clear it)
