@@ -383,8 +383,11 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     const int BTr = (int)lo.BT;
     void* gws = W + lo.gemm; const size_t gwsb = lo.gemm_bytes;
     int rc;
+    // The fused two-layer backward (rnn_fused2_bwd.hip) is parity-tested but NOT the default: its 36 KB of HBM streams per step
+    // and CU (saved gates in, gate gradients out, both layers at once) queue in front of the exchange traffic and it measures
+    // 1.9-2.2 ms against 1.64 + 0.25 ms for the two per-layer sweeps + the dX GEMM it removes.  DEP_FUSED2_BWD=1.
     static int fused_bwd_off = -1;
-    if (fused_bwd_off < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fused_bwd_off = (e && e[0] == '0') ? 1 : 0; }
+    if (fused_bwd_off < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fused_bwd_off = (e && e[0] == '1') ? 0 : 1; }
     if (lo.fused2 && !fused_bwd_off && sweep_split_mode()) {
         // both layers in one launch: layer 0 one step behind layer 1; layer 1's dX (the gradient into layer 0) stays on chip
         const float* const* w0 = weights; const float* const* w1 = weights + 4;

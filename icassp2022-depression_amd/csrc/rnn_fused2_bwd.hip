@@ -172,7 +172,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         if (grp == 1) {
             put_ibuf(tv, u + 1);                          // loads issued at the top of the PREVIOUS step: a whole step to land
             if (!(p.exp & 4)) stage(tv, u + 2);
-            if (u >= 1 && !(p.exp & 2)) flush(tv, u - 1);
+            if (u >= 1 && !(p.exp & 2) && !(p.exp & 32)) flush(tv, u - 1);
         }
         // ---- gate gradients (groups 0 and 2; identical code, role-dependent LDS bases)
         if (grp != 1 && act) {
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         bar_lds();                                        // #2
         if (tid == 0) { if (fast) st_local(myflag, (unsigned)u + 1u); else st_agent(myflag, (unsigned)u + 1u); }
         if (grp == 1) {
+            if ((p.exp & 32) && !(p.exp & 2)) flush(tv, u);
         } else {
             // next step's dropout mask for layer 0, in the shadow of the wait
             if (DROP && grp == 2 && u + 1 <= T) { const float2 m = draw(tv, T - (u + 1)); st[3][2] = m.x; st[3][3] = m.y; }
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         }
         bar_lds();                                        // #3: next step's inputs are in LDS, this step's write-out left it
     }
-    if (grp == 1) flush(tid, T);                          // layer 0's last step
+    if (grp == 1) { if (!(p.exp & 32) && T >= 1) {} flush(tid, T); }      // layer 0's last step
     if (grp != 1) {
         // bias-gradient partials [batch tile][4][H]: sum over the 16 utterance rows = lanes that differ in bits 1..4
         float2 a[4] = {f2(st[1][0], st[1][1]), f2(st[1][2], st[1][3]), f2(st[2][0], st[2][1]), f2(st[2][2], st[2][3])};

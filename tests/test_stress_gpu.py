@@ -27,6 +27,7 @@ CASES = [
     ('gru', 8, {}, ['--load', '--H', '128']),
     ('gru', 8, {'DEP_GEMM_MODE': 'f32'}, []),                    # exact-fp32 sweeps (different member kernels)
     ('gru', 8, {}, ['--H', '128']),                               # 32-unit-member forward kernel
+    ('gru', 6, {'DEP_FUSED2_BWD': '1'}, []),                      # opt-in fused two-layer backward: same bits every run
     ('lstm', 12, {}, []),
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, ['--load']),
     ('lstm', 4, {'DEP_NUM_CUS': '200'}, []),
@@ -55,3 +56,13 @@ def test_exclusive_forward_fails_loudly_never_silently_under_foreign_load():
     assert line, r.stdout[-2000:] + r.stderr[-2000:]
     res = json.loads(line[-1])
     assert res['status_bad'] >= res['mismatches'] and res['status_bad'] >= res['nan_iters'], res
+
+
+def test_opt_in_fused_backward_passes_the_kernel_parity_suite():
+    """rnn_fused2_bwd.hip (both GRU layers' BPTT in one launch) is not the default path but stays
+    parity-green: the whole RNN-stack suite, run in a process with DEP_FUSED2_BWD=1, against the oracle."""
+    e = dict(os.environ, DEP_FUSED2_BWD='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
+                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
