@@ -38,7 +38,6 @@ struct FB {
     float* dgi1; float* dghn1; float* dgi0; float* dghn0;           // (B*T, 3H) / (B*T, H)
     float* dbpart1; float* dbpart0;                                 // [batch tile][4][H] bias-gradient partials
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes; int nofast;
-    int exp;                                                        // timing experiments (DEP_FB_EXP bit mask), 0 in production
 };
 
 // Registers: 3 waves per SIMD -> 168 VGPRs, 96 of them weights.  Per-thread indices are re-derived every step from a laundered
@@ -168,11 +167,13 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         // ---- group 1's HBM streams go HERE, while nothing latency-critical uses the CU's memory pipeline (the others are in
         // their gate math, then everybody in the MFMAs): the next step's inputs first, then the previous step's write-out (from
         // the other obuf parity).  36 KB per step and CU is ~3400 cycles of the CU's ~10.7 B/clk share of HBM: issued beside
-        // the payload stores / flag polls / gather loads instead, these streams queued in front of them and cost 0.8 ms.
+        // the payload stores / flag polls / gather loads instead, these streams queue in front of them.  (Measured: without the
+        // streams this launch takes 1.07 ms, with the loads alone 1.47, the stores alone 1.31, both 1.9-2.1 -- wherever they are
+        // issued -- against 1.64 + 0.25 ms for the two per-layer sweeps plus the dX GEMM this launch removes: not adopted, opt-in.)
         if (grp == 1) {
             put_ibuf(tv, u + 1);                          // loads issued at the top of the PREVIOUS step: a whole step to land
-            if (!(p.exp & 4)) stage(tv, u + 2);
-            if (u >= 1 && !(p.exp & 2) && !(p.exp & 32)) flush(tv, u - 1);
+            stage(tv, u + 2);
+            if (u >= 1) flush(tv, u - 1);
         }
         // ---- gate gradients (groups 0 and 2; identical code, role-dependent LDS bases)
         if (grp != 1 && act) {
@@ -256,16 +257,13 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         }
         bar_lds();                                        // #2
         if (tid == 0) { if (fast) st_local(myflag, (unsigned)u + 1u); else st_agent(myflag, (unsigned)u + 1u); }
-        if (grp == 1) {
-            if ((p.exp & 32) && !(p.exp & 2)) flush(tv, u);
-        } else {
+        if (grp != 1) {
             // next step's dropout mask for layer 0, in the shadow of the wait
             if (DROP && grp == 2 && u + 1 <= T) { const float2 m = draw(tv, T - (u + 1)); st[3][2] = m.x; st[3][3] = m.y; }
-            if (!(p.exp & 16) && !wait_flags(tflags, BNC, (unsigned)u + 1u, p.status, 7)) return;
+            if (!wait_flags(tflags, BNC, (unsigned)u + 1u, p.status, 7)) return;
             // reduce-scatter: this thread's two columns of every member's partial, summed in member order
             const float* src = p.payload + pbase + ((unsigned)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
-            if (p.exp & 8) {
-            } else if (grp == 0) {                        // dh1_{t-1}
+            if (grp == 0) {                               // dh1_{t-1}
                 if (u + 1 <= T - 1) {
                     float2 part[8];
 #pragma unroll
@@ -296,7 +294,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         }
         bar_lds();                                        // #3: next step's inputs are in LDS, this step's write-out left it
     }
-    if (grp == 1) { if (!(p.exp & 32) && T >= 1) {} flush(tid, T); }      // layer 0's last step
+    if (grp == 1) flush(tid, T);                          // layer 0's last step
     if (grp != 1) {
         // bias-gradient partials [batch tile][4][H]: sum over the 16 utterance rows = lanes that differ in bits 1..4
         float2 a[4] = {f2(st[1][0], st[1][1]), f2(st[1][2], st[1][3]), f2(st[2][0], st[2][1]), f2(st[2][2], st[2][3])};
@@ -337,7 +335,6 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * BNC <= 256 && pay < (1ull << 32));
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
-    { static int e = -1; if (e < 0) { const char* v = getenv("DEP_FB_EXP"); e = v ? atoi(v) : 0; } p.exp = e; }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B_LDS_BYTES);
