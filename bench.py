@@ -232,6 +232,10 @@ def main():
                      {'gru_fwd_sweep': 34 * H, 'gru_bwd_sweep': 38 * H, 'lstm_fwd_sweep': 84 * H, 'lstm_bwd_sweep': 88 * H})[dom]
     compulsory_per_ut = 4 * H * dirs
     design_bytes = float(design_per_ut) * B * T * layers_per_launch
+    if dom == 'gru_fwd_sweep' and layers_per_launch > 1.5:
+        # the fused two-layer forward: layer 0's input projection in (12H), both layers' h (8H) and saved gates (32H) out, the
+        # dropped copy of layer 0's h (4H); layer 1's projection never exists in HBM
+        design_bytes = float(56 * H) * B * T
     compulsory_bytes = float(compulsory_per_ut) * B * T * layers_per_launch
     split = L.get_gemm_mode() == 1                           # the cluster sweeps follow the GEMM precision mode
     mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
