@@ -32,6 +32,7 @@ struct P2 {
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
     int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
     long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
+    int trall_off;           // debug: LDS offset (32-bit words) of the per-step stamp array
 };
 
 struct StepIn { float2 r, z, n, hn, hp, dy; };
@@ -44,8 +45,23 @@ struct StepIn { float2 r, z, n, hn, hp, dy; };
 // rows are exactly three 32-wide k-steps (r, z, n), 4 tiles x 3 k-steps x 3 products = 36 v_mfma_f32_16x16x32_bf16
 // (576 cycles) replace 96 v_mfma_f32_16x16x4_f32 (3072 cycles, close to half of the step).  The thread that produces a
 // gate gradient splits it once and writes the (hi, lo) bf16 planes the MFMA B fragments are read from.
-template <int NTW, bool SPLIT>      // output tiles per wave = H/64
-__global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
+//
+// KB > 0: BURST STREAMS.  A CU returns vector loads in issue order ACROSS its waves (tools/micro/inorder.hip: a load that hits
+// in L2 comes back after 200 cycles on a quiet CU, after 600-4000 when another wave of the CU has HBM loads or stores in
+// flight), so every HBM stream request of a step sits in front of that step's flag polls and gather loads, whichever wave
+// issues it: the sweep pays HBM time and exchange latency one after the other.  With KB > 0 four service waves (threads
+// CT .. CT+255) own every stream and move KB steps at a time: on a tile's `dirty' step (every KB-th, the tiles of an XCD
+// staggered) they request the inputs of KB steps (registers for KB-1 steps, then the LDS ring `ibuf') and write out the
+// gate gradients of the last KB steps (LDS ring `obuf'); the other KB-1 steps of the tile run with nothing but the
+// exchange in the CU's memory pipeline.  The compute waves read their inputs from ibuf and leave dr, dz, dn, dn*r in obuf.
+constexpr int SVC_THREADS = 256;
+constexpr int SROW = 36;                             // LDS row stride (floats) of ibuf / obuf: 16-byte aligned rows, conflict-free columns
+constexpr int SARR = 16 * SROW;
+constexpr int TRACE_F = 2048, IBUF_F = 2304;         // float offsets into the workgroup's LDS (planes: [0, 2048))
+constexpr size_t burst_lds_bytes(int KB) { return (size_t)(IBUF_F + KB * 6 * SARR + (KB + 1) * 4 * SARR) * sizeof(float); }
+
+template <int NTW, bool SPLIT, int KB>      // output tiles per wave = H/64
+__global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1(P2 p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 96, KCB = KS / 16, LDG = KS + LPAD;
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane (208-byte rows)
@@ -63,27 +79,34 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     unsigned short* dg_hi = reinterpret_cast<unsigned short*>(smem);
     unsigned short* dg_lo = dg_hi + BT * LDGB;
 
+    constexpr bool BURST = KB > 0;
+    constexpr int KBX = BURST ? KB : 1;
+    const bool svc = BURST && tid >= CT;              // wave-uniform
+    float* ibuf = smem + IBUF_F;                      // [KB][6][16][SROW]: r, z, n, hn, h_{t-1}, dy of step k in slot k % KB
+    float* obuf = ibuf + KBX * 6 * SARR;              // [KB+1][4][16][SROW]: dr, dz, dn, dn*r of step k in slot k % (KB+1)
     f32x4 wr[SPLIT ? 1 : NTW][SPLIT ? 1 : KCB];
     u32x4 wq[SPLIT ? NTW : 1][SPLIT ? 3 : 1][2];       // [tile][k-step = gate][hi, lo]
-    if constexpr (SPLIT) {
-        const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp);
+    if (!svc) {
+        if constexpr (SPLIT) {
+            const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp);
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks)
+                for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    wq[i][ks][pl] = wpq[(size_t)(((c * NTT + w * NTW + i) * 3 + ks) * 2 + pl) * 64 + lane];
-    } else {
+                    for (int pl = 0; pl < 2; ++pl)
+                        wq[i][ks][pl] = wpq[(size_t)(((c * NTT + w * NTW + i) * 3 + ks) * 2 + pl) * 64 + lane];
+        } else {
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int k = 0; k < KCB; ++k)
-                wr[i][k] = p.wp[(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
+                for (int k = 0; k < KCB; ++k)
+                    wr[i][k] = p.wp[(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
+        }
     }
-    float2 dhrec = (p.dh_n && valid) ? ld2(p.dh_n + (size_t)b * H + col) : f2(0.f, 0.f);
+    float2 dhrec = (p.dh_n && valid && !svc) ? ld2(p.dh_n + (size_t)b * H + col) : f2(0.f, 0.f);
     float2 dpl = f2(0.f, 0.f);
-    if (p.dpooled && valid) { dpl = ld2(p.dpooled + (size_t)b * H + col); dpl.x *= p.pool_scale; dpl.y *= p.pool_scale; }
+    if (p.dpooled && valid && !svc) { dpl = ld2(p.dpooled + (size_t)b * H + col); dpl.x *= p.pool_scale; dpl.y *= p.pool_scale; }
     float2 dbr = f2(0.f, 0.f), dbz = dbr, dbn = dbr, dbh = dbr;
     const size_t pstride = (size_t)p.nbtp * NC * BT * H;                   // floats per parity buffer
     const size_t tile_base = (size_t)bt * NC * BT * H;                     // this tile's [NC][NTT][64][4] block
@@ -106,7 +129,98 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         }
     };
     StepIn cur, nxt;
-    load_step(T - 1, cur);
+    if constexpr (!BURST) load_step(T - 1, cur);
+    // ---- service waves.  Step counter k = T-1-t.  Service thread st: piece idx = st + 256 i (i < 3) of a step's 768 input
+    // pieces -> array idx / 128, utterance row (idx % 128) / 8, 16-byte piece idx % 8; likewise 512 write-out pieces (i < 2).
+    const int st = tid - CT, sarr0 = (st >> 7) & 1, sr = (st >> 3) & 15, sp = st & 7;
+    const int sb = p.b0 + bt * BT + sr;
+    const bool svalid = sb < p.B;
+    const int scol = 32 * c + sp * 4;
+    const int phi = (bt >> 3) % KBX;                  // the tiles of an XCD (bt = xcd mod 8) take their dirty steps in turn
+    f32x4 sreg[KBX][3];
+    // wave-uniform array choice (waves 4, 5: arrays 0, 2, 4 = r, n, h_{t-1}; waves 6, 7: 1, 3, 5 = z, hn, dy), made scalar so
+    // that the base pointers are selected in SGPRs (a per-lane choice makes hipcc index the kernel arguments in memory and
+    // wait for that pointer load -- vmcnt(0) -- in front of every data load)
+    const bool sodd = __builtin_amdgcn_readfirstlane(sarr0) != 0;
+    const float* sbase0 = sodd ? p.sv1 : p.sv0;
+    const float* sbase1 = sodd ? p.sv3 : p.sv2;
+    const float* sbase2 = sodd ? p.dy : p.y;
+    const int sld2 = sodd ? p.lddy : p.ldy;
+    auto svc_load1 = [&](int k, int i) -> f32x4 {     // input array a = sarr0 + 2 i of step k
+        const int t = T - 1 - k;
+        if (!svalid || t < 0) return zero4();
+        const size_t row = (size_t)sb * T + t;
+        if (i == 0) return ld4(sbase0 + row * H + scol);
+        if (i == 1) return ld4(sbase1 + row * H + scol);
+        if (sodd) return sbase2 ? ld4(sbase2 + row * sld2 + scol) : zero4();
+        return t > 0 ? ld4(sbase2 + (row - 1) * sld2 + scol) : zero4();
+    };
+    auto svc_issue = [&](int k0, int n) {             // inputs of steps k0 .. k0+n-1 -> registers
+#pragma unroll
+        for (int d = 0; d < KBX; ++d)
+            if (d < n) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sreg[d][i] = svc_load1(k0 + d, i);
+            }
+    };
+    auto svc_put = [&](int k0, int n) {               // registers -> ibuf slots of steps k0 .. k0+n-1
+#pragma unroll
+        for (int d = 0; d < KBX; ++d)
+            if (d < n) {
+                float* dst = ibuf + ((k0 + d) % KBX) * 6 * SARR + sr * SROW + sp * 4;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(dst + (sarr0 + 2 * i) * SARR) = sreg[d][i];
+            }
+    };
+    auto svc_flush = [&](int k0, int k1) {            // gate gradients of steps k0 .. k1-1: obuf -> dgi (dr, dz, dn), dghn (dn * r)
+        if (!svalid) return;
+        for (int k = k0 < 0 ? 0 : k0; k < k1; ++k) {
+            const size_t row = (size_t)sb * T + (T - 1 - k);
+            const float* o = obuf + (k % (KBX + 1)) * 4 * SARR + sr * SROW + sp * 4;
+            // arrays sarr0 (dr / dz) and 2 + sarr0 (dn / dn*r)
+            *reinterpret_cast<f32x4*>(p.dgi + row * p.lddg + (sodd ? H : 0) + scol) = ld4(o + (sodd ? SARR : 0));
+            float* g1 = sodd ? p.dghn + row * H + scol : p.dgi + row * p.lddg + 2 * H + scol;
+            *reinterpret_cast<f32x4*>(g1) = ld4(o + (sodd ? 3 * SARR : 2 * SARR));
+        }
+    };
+    if constexpr (BURST) {
+        if (svc) {
+            // the service waves' whole life: same barrier sequence as the compute waves' loop below (two per step, one in the last)
+            svc_issue(0, KBX); svc_put(0, KBX);       // steps 0 .. KB-1 straight into the ring
+            svc_issue(KBX, phi);                      // steps KB .. KB+phi-1: written at step phi-1, before the first dirty step (k = phi)
+            __syncthreads();
+            for (int k = 0; k < T; ++k) {
+                const int jj = (k + KBX - phi) % KBX;                  // jj == 0: this tile's dirty step
+                const int last = k - jj;                               // the dirty step this burst started with (< 0: the prologue)
+                const bool trs = p.trace && blockIdx.x == 0 && st == 0 && k >= 100 && k < 104;
+                if (trs) p.trace[32 + (k - 100) * 4 + 0] = (long long)__builtin_readcyclecounter();
+                if (jj == 0) {
+                    // everything the next KB steps need from HBM, and everything the last KB produced.  (The service waves run
+                    // ahead of the compute waves -- nothing holds them after barrier #2 -- so the burst starts during the
+                    // previous step's poll; holding it back until the compute waves reach the dirty step's gate phase
+                    // measured the same launch time: the burst occupies the CU's memory pipeline for ~1.3 steps either way.)
+                    svc_issue(k + KBX, KBX);
+                    if (trs) p.trace[32 + (k - 100) * 4 + 1] = (long long)__builtin_readcyclecounter();
+                    svc_flush(k - KBX, k);
+                }
+                if (trs) p.trace[32 + (k - 100) * 4 + 2] = (long long)__builtin_readcyclecounter();
+                bar_lds();                           // #1
+                if (trs) p.trace[32 + (k - 100) * 4 + 3] = (long long)__builtin_readcyclecounter();
+                if (jj == KBX - 1) {
+                    // last step of the burst: the ring slots of steps last .. k are consumed; the registers (requested at step
+                    // `last', KB-1 steps ago) become steps last+KB .. k+KB
+                    if (last >= 0) svc_put(last + KBX, KBX);
+                    else svc_put(KBX, phi);
+                }
+                if (k == T - 1) break;
+                bar_lds();                           // #2 (the compute waves' drain barrier)
+            }
+            const int jl2 = (T - 1 + KBX - phi) % KBX;
+            svc_flush(T - 1 - jl2, T);                // the gate gradients since the last dirty step
+            return;
+        }
+        __syncthreads();
+    }
     // inter-layer dropout on the incoming dy: the Philox draw of step t-1 is made while step t waits for the other members
     // (it depends on nothing but the position), so it never sits on the step's critical path
     const bool masked = p.dy && p.drop_p > 0.f && valid;
@@ -118,12 +232,20 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
     float2 mk = masked ? draw(T - 1) : f2(1.f, 1.f);
     // debug stamps (DEP_TRACE=1, tools/trace_bwd.py): buffered in otherwise unused LDS, copied out after the sweep
     long long* trb = (p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
-    long long* trlb = reinterpret_cast<long long*>(smem + 8192);
+    long long* trlb = reinterpret_cast<long long*>(smem + (BURST ? TRACE_F : 8192));
 #define BSTAMP(slot) do { if (trb && t <= 199 && t > 195) trlb[(199 - t) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
+    if (trb) trlb[7] = (long long)__builtin_readcyclecounter();
+    unsigned* trall = reinterpret_cast<unsigned*>(smem) + p.trall_off;      // DEP_TRACE: low 32 bits of the tick counter at the top of every step
     for (int t = T - 1; t >= 0; --t) {
         const size_t row = (size_t)b * T + t;
         BSTAMP(0);
+        if (trb && T - 1 - t < 360) trall[T - 1 - t] = (unsigned)__builtin_readcyclecounter();
+        if constexpr (BURST) {
+            const float* ib = ibuf + ((T - 1 - t) % KBX) * 6 * SARR + j * SROW + ul;
+            cur.r = ld2(ib); cur.z = ld2(ib + SARR); cur.n = ld2(ib + 2 * SARR); cur.hn = ld2(ib + 3 * SARR);
+            cur.hp = ld2(ib + 4 * SARR); cur.dy = ld2(ib + 5 * SARR);
+        }
         const float2 dyv = f2(cur.dy.x * mk.x, cur.dy.y * mk.y);
         const float2 r = cur.r, z = cur.z, n = cur.n, hn = cur.hn, hp = cur.hp;
         const float2 d = f2(dhrec.x + dpl.x + dyv.x, dhrec.y + dpl.y + dyv.y);
@@ -143,7 +265,10 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         } else {
             st2(dgs + j * LDG + ul, dr); st2(dgs + j * LDG + 32 + ul, dz); st2(dgs + j * LDG + 64 + ul, dnr);
         }
-        if (valid) {
+        if constexpr (BURST) {
+            float* ob = obuf + ((T - 1 - t) % (KBX + 1)) * 4 * SARR + j * SROW + ul;
+            st2(ob, dr); st2(ob + SARR, dz); st2(ob + 2 * SARR, dn); st2(ob + 3 * SARR, dnr);
+        } else if (valid) {
             float* g = p.dgi + row * p.lddg;
             st2(g + col, dr); st2(g + H + col, dz); st2(g + 2 * H + col, dn);
             st2(p.dghn + row * H + col, dnr);
@@ -152,7 +277,7 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
         bar_lds();                                   // LDS only: the dgi/dghn stores above stay in flight
         BSTAMP(1);
         if (t == 0) break;
-        load_step(t - 1, nxt);                       // independent of the recurrence: in flight under the MFMAs
+        if constexpr (!BURST) load_step(t - 1, nxt); // independent of the recurrence: in flight under the MFMAs
         f32x4 acc[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; ++i) acc[i] = zero4();
@@ -223,10 +348,15 @@ __global__ __launch_bounds__(CT) void gru_bwd_cluster_r1(P2 p) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) { s.x += part[m].x; s.y += part[m].y; }
         dhrec = f2(dzt.x + s.x, dzt.y + s.y);
-        cur = nxt;
+        if constexpr (!BURST) cur = nxt;
         BSTAMP(6);
     }
-    if (trb) for (int i = 0; i < 32; ++i) trb[i] = trlb[i];
+    if (trb) {
+        trlb[15] = (long long)__builtin_readcyclecounter();
+        for (int i = 0; i < 32; ++i) trb[i] = trlb[i];
+        unsigned* o = reinterpret_cast<unsigned*>(trb + 64);
+        for (int i = 0; i < T && i < 360; ++i) o[i] = trall[i];
+    }
     // bias-gradient partials dbpart[bt][4][H]: sum over the 16 utterance rows = lanes that differ in bits 1..4
     float2 a[4] = {dbr, dbz, dbn, dbh};
 #pragma unroll
@@ -561,13 +691,18 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
     p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
-    const size_t lds = EXCLUSIVE_LDS;
+    static int kb_env = -1;                           // DEP_BWD_BURST=0: the round-1 kernel (every wave streams for itself, every step); 4 (default) or 6: burst length
+    if (kb_env < 0) { const char* v = getenv("DEP_BWD_BURST"); kb_env = v ? atoi(v) : 4; if (kb_env != 0 && kb_env != 4 && kb_env != 6) kb_env = 4; }
+    const int kb = kb_env;
+    const size_t lds = (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
+    p.trall_off = (int)((lds - 2048) / 4);
     static bool attr_b = false;
     if (!attr_b) {
-        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define DEP_BWD_ATTR(N, S, V) (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<N, S, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((V ? burst_lds_bytes(V) > EXCLUSIVE_LDS ? burst_lds_bytes(V) : EXCLUSIVE_LDS : EXCLUSIVE_LDS) + 2048))
+        DEP_BWD_ATTR(2, false, 0); DEP_BWD_ATTR(4, false, 0); DEP_BWD_ATTR(2, true, 0); DEP_BWD_ATTR(4, true, 0);
+        DEP_BWD_ATTR(2, false, 4); DEP_BWD_ATTR(4, false, 4); DEP_BWD_ATTR(2, true, 4); DEP_BWD_ATTR(4, true, 4);
+        DEP_BWD_ATTR(2, false, 6); DEP_BWD_ATTR(4, false, 6); DEP_BWD_ATTR(2, true, 6); DEP_BWD_ATTR(4, true, 6);
+#undef DEP_BWD_ATTR
         attr_b = true;
     }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
@@ -576,10 +711,14 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
         dim3 grid(NC * p.nbtp);
-        if (a.H == 128) { if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<2, true>), grid, dim3(CT), lds, a.stream, p);
-                          else hipLaunchKernelGGL((gru_bwd_cluster_r1<2, false>), grid, dim3(CT), lds, a.stream, p); }
-        else            { if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true>), grid, dim3(CT), lds, a.stream, p);
-                          else hipLaunchKernelGGL((gru_bwd_cluster_r1<4, false>), grid, dim3(CT), lds, a.stream, p); }
+        const dim3 block(kb ? CT + SVC_THREADS : CT);
+#define DEP_BWD_LAUNCH(N, S)                                                                                              \
+        do { if (kb == 4) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 4>), grid, block, lds, a.stream, p);               \
+             else if (kb == 6) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 6>), grid, block, lds, a.stream, p);          \
+             else hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 0>), grid, block, lds, a.stream, p); } while (0)
+        if (a.H == 128) { if (a.split) DEP_BWD_LAUNCH(2, true); else DEP_BWD_LAUNCH(2, false); }
+        else            { if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false); }
+#undef DEP_BWD_LAUNCH
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;

@@ -10,9 +10,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int B = 512, T = 300, H = 256;
 
 template <bool TMAJOR, int DEPTH>
-__global__ __launch_bounds__(128) void walk(const float* __restrict__ in, float* __restrict__ out, float* sink) {
+__global__ __launch_bounds__(256) void walk(const float* __restrict__ in, float* __restrict__ out, float* sink) {
     const int bt = blockIdx.x % 32, c = blockIdx.x / 32;
-    const int row = bt * 16 + (threadIdx.x >> 3), col = c * 32 + (threadIdx.x & 7) * 4;
+    const int row = (bt * 16 + (threadIdx.x >> 3)) % B, col = c * 32 + (threadIdx.x & 7) * 4;
     const size_t arr = (size_t)B * T * H;
     f32x4 acc = {0, 0, 0, 0};
     f32x4 ring[DEPTH][6];
@@ -56,6 +56,22 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
         printf("%-28s %.3f ms  %.2f TB/s  (%.2f GB per launch)\n", name, ms, gb / ms, gb);
     };
+    // per-CU streaming rate when only 64 workgroups (one CU each) are active: what a burst can draw
+    {
+        auto run64 = [&](const char* name, auto kern, int threads) {
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(64), dim3(threads), 0, 0, in, out, sink);
+            hipEventRecord(e0, 0);
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(64), dim3(threads), 0, 0, in, out, sink);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+            const double g = gb / 4 * (threads / 128.0);
+            printf("%-28s %.3f ms  %.1f GB/s per CU (64 CUs active, %d threads each)\n", name, ms, g / 64 / ms * 1e3, threads);
+        };
+        run64("64 WGs, depth 1", walk<false, 1>, 128);
+        run64("64 WGs, depth 4", walk<false, 4>, 128);
+        run64("64 WGs, depth 4, 256 thr", walk<false, 4>, 256);
+        run64("64 WGs, depth 8, 256 thr", walk<false, 8>, 256);
+    }
     run("batch-major, depth 1", walk<false, 1>);
     run("batch-major, depth 2", walk<false, 2>);
     run("batch-major, depth 4", walk<false, 4>);
