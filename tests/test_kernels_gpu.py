@@ -212,6 +212,9 @@ RNN_CASES = [
     ('gru', 3, 2, 8, 128, 3),           # two steps: a single exchange
     ('lstm', 2, 1, 8, 128, 3),
     ('gru', 2, 1, 5, 16, 2), ('lstm', 1, 1, 3, 8, 1),
+    ('gru', 400, 7, 16, 256, 3),        # burst-stream backward: every dirty-step phase (tiles 0..24), T not a multiple of the burst
+    ('gru', 300, 13, 8, 128, 3),        # same, H = 128 members, ragged last tile
+    ('gru', 200, 5, 8, 256, 3),         # T = burst + 1: the prologue's partial burst and the final flush
 ]
 
 

@@ -28,6 +28,9 @@ CASES = [
     ('gru', 8, {'DEP_GEMM_MODE': 'f32'}, []),                    # exact-fp32 sweeps (different member kernels)
     ('gru', 8, {}, ['--H', '128']),                               # 32-unit-member forward kernel
     ('gru', 6, {'DEP_FUSED2_BWD': '1'}, []),                      # opt-in fused two-layer backward: same bits every run
+    ('gru', 8, {'DEP_BWD_BURST': '0'}, []),                       # round-1 backward schedule (no service waves)
+    ('gru', 8, {'DEP_BWD_BURST': '6'}, ['--load', '--load-phase', 'bwd']),   # longer bursts, with a co-scheduled kernel
+    ('gru', 6, {'DEP_BWD_BURST': '4', 'DEP_NUM_CUS': '200'}, ['--H', '128']),
     ('lstm', 12, {}, []),
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, ['--load']),
     ('lstm', 4, {'DEP_NUM_CUS': '200'}, []),
@@ -62,6 +65,17 @@ def test_opt_in_fused_backward_passes_the_kernel_parity_suite():
     """rnn_fused2_bwd.hip (both GRU layers' BPTT in one launch) is not the default path but stays
     parity-green: the whole RNN-stack suite, run in a process with DEP_FUSED2_BWD=1, against the oracle."""
     e = dict(os.environ, DEP_FUSED2_BWD='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
+                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+
+
+@pytest.mark.parametrize('burst', ['0', '6'])
+def test_backward_burst_variants_pass_the_kernel_parity_suite(burst):
+    """gru_bwd_cluster_r1<.., KB>: KB = 4 is the default; the round-1 schedule (0) and the longer bursts (6)
+    stay parity-green -- the GRU part of the RNN-stack suite in a process with DEP_BWD_BURST set, against the oracle."""
+    e = dict(os.environ, DEP_BWD_BURST=burst)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
