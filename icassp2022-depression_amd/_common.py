@@ -23,11 +23,62 @@ def save(model, filename):
         print('Saved as %s' % save_filename)
 
 
-def load_checkpoint_state_dict(path):
-    obj = torch.load(path, map_location='cpu', weights_only=False)
+class StateDictModule(torch.nn.Module):
+    """A stock torch.nn.Module whose only content is a state_dict: nested plain modules carrying the tensors under the
+    same dotted names, in the same order.  What `export_reference_checkpoint` pickles: the reference's consumers of a
+    checkpoint (fuse_net_whole.py:566-588, the *ModelChecking.py scripts) do `torch.load(path).state_dict()`, which works on
+    this object wherever this package is importable.  It has no forward()."""
+
+    def __init__(self, state_dict=None, source_class=None):
+        super().__init__()
+        self.source_class = source_class
+        for name, value in (state_dict or {}).items():
+            mod, parts = self, name.split('.')
+            for part in parts[:-1]:
+                if part not in mod._modules:
+                    mod.add_module(part, torch.nn.Module())
+                mod = mod._modules[part]
+            mod.register_parameter(parts[-1], torch.nn.Parameter(value.detach().cpu().clone(), requires_grad=False))
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('StateDictModule only carries weights (source: %s); rebuild the model with '
+                                  'icassp2022_depression_amd and load_state_dict()' % self.source_class)
+
+
+def export_reference_checkpoint(model, filename):
+    """Write `<filename>.pt` the way the reference's `save()` does -- ONE pickled torch module (the dict payload of
+    `save()` cannot be read by code that expects `torch.load(p).state_dict()`)."""
+    save_filename = '{}.pt'.format(filename)
+    os.makedirs(os.path.dirname(save_filename) or '.', exist_ok=True)
+    shell = StateDictModule(model.state_dict(), type(model).__name__)
+    if parallel.rank() == 0:
+        torch.save(shell, save_filename)
+    return save_filename
+
+
+def load_checkpoint_state_dict(path, allow_pickle=None):
+    """state_dict of a checkpoint written by `save()` (a dict of tensors: loaded with weights_only=True, nothing is
+    executed), by `export_reference_checkpoint`, or by the reference itself (a pickled nn.Module).  Unpickling a module
+    runs code from the file and needs the pickled classes importable under their original path (`__main__.AudioBiLSTM`
+    for the reference's scripts); it is only attempted when `allow_pickle` is true (default: env DEP_ALLOW_PICKLE, on unless
+    set to 0 -- the reference's own loaders do the same)."""
+    try:
+        obj = torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as safe_err:                      # not a plain tensor container
+        if allow_pickle is None:
+            allow_pickle = os.environ.get('DEP_ALLOW_PICKLE', '1') != '0'
+        if not allow_pickle:
+            raise RuntimeError('%s is not a tensor-only checkpoint (%s); pass allow_pickle=True / DEP_ALLOW_PICKLE=1 to '
+                               'unpickle it as a module' % (path, type(safe_err).__name__)) from safe_err
+        try:
+            obj = torch.load(path, map_location='cpu', weights_only=False)
+        except AttributeError as e:
+            raise RuntimeError('%s pickles a module whose class cannot be found (%s): import or define the class under '
+                               'the module path it was saved from (the reference saves `__main__.AudioBiLSTM` / '
+                               '`__main__.TextBiLSTM`) before loading' % (path, e)) from e
     if isinstance(obj, dict) and 'state_dict' in obj:
         return obj['state_dict']
-    if hasattr(obj, 'state_dict'):          # a reference-made pickle of a whole torch module
+    if hasattr(obj, 'state_dict'):          # a pickle of a whole torch module
         return obj.state_dict()
     return obj
 

@@ -196,3 +196,38 @@ def test_per_layer_buckets_equal_single_bucket_gloo():
         parallel.layer_buckets([(0, 400), (500, 500)], 1000)
     with pytest.raises(ValueError):
         parallel.layer_buckets([(0, 400), (300, 700)], 1000)
+
+
+def test_checkpoint_loader_is_safe_first_and_the_exporter_writes_a_module(tmp_path, monkeypatch):
+    """ADVICE r1 (checkpoint format): dict checkpoints load with weights_only=True; `export_reference_checkpoint` writes what
+    the reference's consumers read (`torch.load(p).state_dict()`); a module pickle is refused when pickles are disallowed."""
+    import collections
+    import torch
+    from icassp2022_depression_amd import _common
+
+    sd = collections.OrderedDict([('ln.weight', torch.arange(4.)), ('gru.weight_ih_l0', torch.ones(6, 4)),
+                                  ('fc_audio.1.weight', torch.zeros(3, 2)), ('fc_audio.1.bias', torch.full((3,), 2.))])
+
+    class Fake:
+        variant = 'clf'
+
+        def state_dict(self):
+            return sd
+
+    stem = str(tmp_path / 'ckpt')
+    _common.save(Fake(), stem)
+    got = _common.load_checkpoint_state_dict(stem + '.pt', allow_pickle=False)       # tensor-only: no unpickling needed
+    assert list(got) == list(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+
+    path = _common.export_reference_checkpoint(Fake(), str(tmp_path / 'ref_style'))
+    mod = torch.load(path, weights_only=False)                                       # what the reference's consumers do
+    msd = mod.state_dict()
+    assert list(msd) == list(sd) and all(torch.equal(msd[k], sd[k]) for k in sd)
+    with pytest.raises(RuntimeError, match='allow_pickle'):
+        _common.load_checkpoint_state_dict(path, allow_pickle=False)
+    monkeypatch.setenv('DEP_ALLOW_PICKLE', '0')
+    with pytest.raises(RuntimeError):
+        _common.load_checkpoint_state_dict(path)
+    monkeypatch.delenv('DEP_ALLOW_PICKLE')
+    again = _common.load_checkpoint_state_dict(path)
+    assert list(again) == list(sd)
