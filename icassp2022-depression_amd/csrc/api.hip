@@ -109,6 +109,8 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     }
     lo.reserve_floats = off;
     // workspace
+    // rows of bias-gradient partials: one per 16-utterance tile for the tile-MFMA and the cluster sweeps, one per utterance for
+    // the generic sweep.  (Sized for the larger; dep_finish_db sums the rows the sweep that ran has written: dbpart_rows.)
     lo.nwg = dep_sweep_num_wg(d->B, d->H, d->impl);
     size_t w = 0;
     lo.gi = w; w += al(lo.BT * D * G * H);                 // GI (fwd) / dGI (bwd)
@@ -140,6 +142,7 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     { const char* e = getenv("DEP_CLUSTER16_BWD"); lo.cluster16_bwd = lo.cluster16 && e && e[0] == '1'; }
     lo.xbuf = w; lo.xbuf_bytes = !lo.cluster ? 0 : (d->cell == DEP_CELL_GRU ? dep_cluster_xbuf_bytes(d->cell, d->H, d->B, d->dirs)
                                                                 : dep_cluster_lstm_xbuf_bytes(d->H, d->B, d->dirs));
+    if (lo.cluster) lo.nwg = dep_cdiv(d->B, 16);      // the cluster sweeps write one row per tile whatever the tile-MFMA sweep could do at this H
     lo.fused2 = lo.cluster && dep_fused2_ok(d->cell, d->H, d->L, d->dirs);
     if (lo.fused2) {
         size_t fb = dep_fused2_xbuf_bytes(d->B); if (fb > lo.xbuf_bytes) lo.xbuf_bytes = fb;
@@ -411,7 +414,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
             const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[0] : R + lo.y[0]);
             const int Kl = l == 0 ? d->F : H;
             dep_sweep_bwd_args a{};
-            a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = 1; a.impl = d->impl; a.dbpart = l ? f.dbpart1 : f.dbpart0; a.stream = s;
+            a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = 1; a.impl = d->impl; a.dbpart = l ? f.dbpart1 : f.dbpart0; a.dbpart_rows = lo.nwg; a.stream = s;
             float* dbi[2] = {gl[2], nullptr}; float* dbh[2] = {gl[3], nullptr};
             rc = dep_finish_db(a, dbi, dbh); if (rc) return rc;
             if (l == 0 && dx) {

@@ -64,7 +64,7 @@ int dep_cluster_chunk(int members, int per_cu, int max_wgs) {
 
 bool dep_cluster_ok(int cell, int H, int B, int dirs) {
     (void)B; (void)dirs;                              // any batch: the launchers chunk it
-    return cell == DEP_CELL_GRU && (H == 128 || H == 256);     // KCH = H/32 in {4,8}; NTW = H/64 in {2,4}
+    return cell == DEP_CELL_GRU && (H == 64 || H == 128 || H == 256 || H == 512);     // KCH = H/32 in {2,4,8,16}; NTW = H/64 in {1,2,4,8}
 }
 
 // header + the largest (backward) exchange of one launch chunk

@@ -341,12 +341,12 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
         // gather this thread's two columns from the NC partials, sum in member order
         float2 s = f2(0.f, 0.f);
         const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
-        float2 part[8];
+        constexpr int NCM = 2 * NTW;                  // members of a cluster = H / 32
+        float2 part[NCM];
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
-            part[m] = (m < NC) ? ld2_agent(src + (size_t)m * NTT * 256) : f2(0.f, 0.f);
+        for (int m = 0; m < NCM; ++m) part[m] = ld2_agent(src + (size_t)m * NTT * 256);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) { s.x += part[m].x; s.y += part[m].y; }
+        for (int m = 0; m < NCM; ++m) { s.x += part[m].x; s.y += part[m].y; }
         dhrec = f2(dzt.x + s.x, dzt.y + s.y);
         if constexpr (!BURST) cur = nxt;
         BSTAMP(6);
@@ -649,10 +649,10 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
     const size_t lds = EXCLUSIVE_LDS;
     static bool attr_f = false;
     if (!attr_f) {
-        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define DEP_FWD_ATTR(K) (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                        (void)hipFuncSetAttribute((const void*)gru_fwd_cluster_r1<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        DEP_FWD_ATTR(2); DEP_FWD_ATTR(4); DEP_FWD_ATTR(8); DEP_FWD_ATTR(16);
+#undef DEP_FWD_ATTR
         attr_f = true;
     }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
@@ -661,10 +661,16 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
         dim3 grid(NC * p.nbtp);
-        if (a.H == 128) { if (a.split) hipLaunchKernelGGL((gru_fwd_cluster_r1<4, true>), grid, dim3(CT), lds, a.stream, p);
-                          else hipLaunchKernelGGL((gru_fwd_cluster_r1<4, false>), grid, dim3(CT), lds, a.stream, p); }
-        else            { if (a.split) hipLaunchKernelGGL((gru_fwd_cluster_r1<8, true>), grid, dim3(CT), lds, a.stream, p);
-                          else hipLaunchKernelGGL((gru_fwd_cluster_r1<8, false>), grid, dim3(CT), lds, a.stream, p); }
+#define DEP_FWD_LAUNCH(K)                                                                                                 \
+        do { if (a.split) hipLaunchKernelGGL((gru_fwd_cluster_r1<K, true>), grid, dim3(CT), lds, a.stream, p);            \
+             else hipLaunchKernelGGL((gru_fwd_cluster_r1<K, false>), grid, dim3(CT), lds, a.stream, p); } while (0)
+        switch (a.H) {                                // KCH = H / 32
+            case 64: DEP_FWD_LAUNCH(2); break;
+            case 128: DEP_FWD_LAUNCH(4); break;
+            case 256: DEP_FWD_LAUNCH(8); break;
+            default: DEP_FWD_LAUNCH(16); break;       // 512
+        }
+#undef DEP_FWD_LAUNCH
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
@@ -693,15 +699,17 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
     static int kb_env = -1;                           // DEP_BWD_BURST=0: the round-1 kernel (every wave streams for itself, every step); 4 (default) or 6: burst length
     if (kb_env < 0) { const char* v = getenv("DEP_BWD_BURST"); kb_env = v ? atoi(v) : 4; if (kb_env != 0 && kb_env != 4 && kb_env != 6) kb_env = 4; }
-    const int kb = kb_env;
+    const int kb = a.H >= 512 ? 0 : kb_env;           // H = 512: 192 weight registers per compute wave leave no room for a second wave per SIMD
     const size_t lds = (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
     p.trall_off = (int)((lds - 2048) / 4);
     static bool attr_b = false;
     if (!attr_b) {
 #define DEP_BWD_ATTR(N, S, V) (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<N, S, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((V ? burst_lds_bytes(V) > EXCLUSIVE_LDS ? burst_lds_bytes(V) : EXCLUSIVE_LDS : EXCLUSIVE_LDS) + 2048))
+        DEP_BWD_ATTR(1, false, 0); DEP_BWD_ATTR(1, true, 0); DEP_BWD_ATTR(1, false, 4); DEP_BWD_ATTR(1, true, 4); DEP_BWD_ATTR(1, false, 6); DEP_BWD_ATTR(1, true, 6);
         DEP_BWD_ATTR(2, false, 0); DEP_BWD_ATTR(4, false, 0); DEP_BWD_ATTR(2, true, 0); DEP_BWD_ATTR(4, true, 0);
         DEP_BWD_ATTR(2, false, 4); DEP_BWD_ATTR(4, false, 4); DEP_BWD_ATTR(2, true, 4); DEP_BWD_ATTR(4, true, 4);
         DEP_BWD_ATTR(2, false, 6); DEP_BWD_ATTR(4, false, 6); DEP_BWD_ATTR(2, true, 6); DEP_BWD_ATTR(4, true, 6);
+        DEP_BWD_ATTR(8, false, 0); DEP_BWD_ATTR(8, true, 0);
 #undef DEP_BWD_ATTR
         attr_b = true;
     }
@@ -716,8 +724,15 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         do { if (kb == 4) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 4>), grid, block, lds, a.stream, p);               \
              else if (kb == 6) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 6>), grid, block, lds, a.stream, p);          \
              else hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 0>), grid, block, lds, a.stream, p); } while (0)
-        if (a.H == 128) { if (a.split) DEP_BWD_LAUNCH(2, true); else DEP_BWD_LAUNCH(2, false); }
-        else            { if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false); }
+        switch (a.H) {                                // NTW = H / 64
+            case 64: if (a.split) DEP_BWD_LAUNCH(1, true); else DEP_BWD_LAUNCH(1, false); break;
+            case 128: if (a.split) DEP_BWD_LAUNCH(2, true); else DEP_BWD_LAUNCH(2, false); break;
+            case 256: if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false); break;
+            default:                                  // 512: round-1 schedule only (kb == 0)
+                if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<8, true, 0>), grid, block, lds, a.stream, p);
+                else hipLaunchKernelGGL((gru_bwd_cluster_r1<8, false, 0>), grid, block, lds, a.stream, p);
+                break;
+        }
 #undef DEP_BWD_LAUNCH
         DEP_CHECK_LAUNCH();
     }

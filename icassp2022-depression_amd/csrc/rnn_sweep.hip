@@ -721,7 +721,8 @@ int dep_launch_sweep_bwd(const dep_sweep_bwd_args& a) {
 
 int dep_finish_db(const dep_sweep_bwd_args& a, float* const* db_ih, float* const* db_hh) {
     const int G = a.cell == DEP_CELL_GRU ? 3 : 4;
-    const int nwg = dep_sweep_num_wg(a.B, a.H, a.impl);
+    DEP_CHECK_ARG(a.dirs >= 1 && a.dbpart_rows >= a.dirs && a.dbpart_rows % a.dirs == 0);
+    const int nwg = a.dbpart_rows / a.dirs;           // rows per direction the sweep that ran has written
     for (int d = 0; d < a.dirs; ++d) {
         hipLaunchKernelGGL(finish_db_kernel, dim3(dep_cdiv(4 * a.H, 128)), dim3(128), 0, a.stream,
                            a.dbpart + (size_t)d * nwg * 4 * a.H, nwg, a.H, G, a.cell, db_ih[d], db_hh[d]);

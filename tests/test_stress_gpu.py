@@ -31,6 +31,9 @@ CASES = [
     ('gru', 8, {'DEP_BWD_BURST': '0'}, []),                       # round-1 backward schedule (no service waves)
     ('gru', 8, {'DEP_BWD_BURST': '6'}, ['--load', '--load-phase', 'bwd']),   # longer bursts, with a co-scheduled kernel
     ('gru', 6, {'DEP_BWD_BURST': '4', 'DEP_NUM_CUS': '200'}, ['--H', '128']),
+    ('gru', 6, {}, ['--H', '64']),                                # two members per tile
+    ('gru', 4, {}, ['--H', '512', '--T', '100']),                 # sixteen members per tile, two chunks of 256 utterances
+    ('gru', 4, {}, ['--H', '512', '--T', '60', '--load', '--load-phase', 'bwd']),
     ('lstm', 12, {}, []),
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, ['--load']),
     ('lstm', 4, {'DEP_NUM_CUS': '200'}, []),

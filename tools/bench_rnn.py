@@ -32,7 +32,7 @@ def main():
                   (torch.rand(G * H, device=dev) * 2 - 1) * k, (torch.rand(G * H, device=dev) * 2 - 1) * k]
     Gd = [torch.empty_like(w) for w in W]
     rnn = L.Rnn(L.CELL_GRU if cell == 'gru' else L.CELL_LSTM, B, T, F, H, 2, dirs, True, 0.5,
-                L.POOL_MEAN if cell == 'gru' else L.POOL_NONE, dev)
+                L.POOL_MEAN if cell == 'gru' else L.POOL_NONE, dev, impl=int(os.environ.get('DEP_IMPL', 0)))
     pooled = torch.empty(B, H, device=dev) if cell == 'gru' else None
     hn = torch.empty(2 * dirs, B, H, device=dev)
     dpool = torch.randn(B, H, device=dev) if cell == 'gru' else None
