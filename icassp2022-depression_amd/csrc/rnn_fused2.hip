@@ -217,7 +217,8 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                                                           // the accumulators' live range does not span it
             if (act) put_red();                           // group 1 reads these partial sums in the next step's gate phase
             write_gbuf(tv);                               // layer-0 input projection of step s+1
-            flush(tv, s);                                 // write-out of step s: posted stores, harmless beside the others' polls
+            flush(tv, s);                                 // write-out of step s: posted stores, harmless beside the others' polls (moved behind
+                                                          // this group's gather in slot Z they make it late for barrier #1: +0.23 ms per forward)
         }
         const unsigned pbase = (unsigned)(s & 1) * pstride + tile_base;
         if (grp < 2 && act) {
@@ -275,8 +276,9 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             // ahead): groups 0 / 1 are in their MFMAs now and nothing latency-critical uses the CU's memory pipeline -- beside
             // the others' flag polls and gathers these 28 KB per step queued in front of them.
             // prefetch of the input projection two steps ahead: HBM LOADS are issued here, while groups 0 / 1 are in their MFMAs --
-            // issued beside their flag polls / gathers (slot Y) they queued in front of them: +0.10 ms per forward (A/B measured)
-            issue_gi(tv, s + 2);
+            // issued beside their flag polls / gathers (slot Y) they queued in front of them: +0.10 ms per forward (A/B measured).
+            // The gather goes FIRST: a CU returns loads in issue order, the gather's L2 hits would otherwise wait
+            // for the prefetch's HBM round trip and this group would be late for barrier #1.
             if (DROP && s < T) {
                 u32x4 v[4];
 #pragma unroll
@@ -292,6 +294,9 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                     *reinterpret_cast<uint2*>(hs0d + o) = hi2; *reinterpret_cast<uint2*>(hs0d + FPLANE + o) = lo2;
                 }
             }
+            // (loads return to a wave in order: issued in front of the gather, the HBM prefetch would hold the gather's data -- and
+            // with it this group's arrival at the next barrier -- back by its whole round trip)
+            issue_gi(tv, s + 2);                          // (in front of the gather: 1.49 instead of 1.44 ms per 2-layer forward incl. the projection GEMM)
         } else {
             FSTAMP(5);
             if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6)) return;      // every wave polls (one poller + a verdict barrier measured no faster)
