@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 rnn.check()
 off = L.load().dep_rnn_workspace_xbuf_offset(C.byref(rnn.desc))
 tr = rnn.workspace[(off + 6144) // 4:(off + 6144) // 4 + 128].view(torch.int64).cpu().numpy().reshape(2, 4, 8)
-n0 = ['frags+MFMA+red', 'barrier#1', 'gates+publish+deposit', 'drain vmcnt', 'barrier#2+flag', 'mask draw', 'poll', 'gather->LDS']
+n0 = ['frags+MFMA+red', 'barrier#1', 'gates+publish+deposit+mask draw', 'drain vmcnt', 'barrier#2+flag', 'poll', 'gather->LDS']
 for s in range(4):
     a = tr[0, s]
     d = [int(a[i + 1] - a[i]) for i in range(7)]
@@ -36,5 +36,5 @@ for s in range(4):
     print(f'g0 step {100 + s}: total {int(a[7] - a[0])} + barrier#3 {nxt} | ' + ' | '.join(f'{n}: {v}' for n, v in zip(n0, d)))
 for s in range(4):
     a = tr[1, s]
-    print(f'g2 step {100 + s}: MFMA+red {int(a[1] - a[0])} | barrier#1 {int(a[2] - a[1])} | idle->#2 {int(a[4] - a[2])} | stream (gbuf, flush, issue) {int(a[7] - a[4])}'
+    print(f'g2 step {100 + s}: MFMA+red {int(a[1] - a[0])} | barrier#1 {int(a[2] - a[1])} | slot Y (red, gbuf, flush)->#2 {int(a[4] - a[2])} | slot Z (gather, prefetch issue) {int(a[7] - a[4])}'
           + (f' | barrier#3 {int(tr[1, s + 1, 0] - a[7])}' if s < 3 else ''))
