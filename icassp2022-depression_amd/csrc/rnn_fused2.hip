@@ -158,8 +158,9 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     long long* trl = nullptr;                         // workgroup 0, thread 0 (group 0) and thread 512 (group 2)
     if (TRACE && p.trace && blockIdx.x == 0 && (tid == 0 || tid == 512)) trl = reinterpret_cast<long long*>(zpair + 4) + (tid ? 32 : 0);
     // Group 2 runs ONE BARRIER out of phase with groups 0 / 1 (it passes one extra barrier here and one fewer at the end): its
-    // slot X (the MFMAs) then coincides with their slot Y (gate math, matrix pipe idle), its slot Y (partial sums to LDS,
-    // input-projection prefetch) with their slot Z (poll + gather), its slot Z (write-out of the step) with their next slot X.
+    // slot X (the MFMAs) then coincides with their slot Y (gate math, matrix pipe idle), its slot Y (partial sums to LDS, staged
+    // projection, its own poll + gather of the dropout block) with their slot Z (poll + gather), its slot Z (write-out of the
+    // step, projection prefetch) with their next slot X.
     // One loop body, one MFMA code site for all three roles -- two sites cost 16 VGPRs of spills.
     if (grp == 2) bar_lds();
     for (int s = 0; s <= T + 1; ++s) {
@@ -213,14 +214,31 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         FSTAMP(1);
         bar_lds();                                        // groups 0/1: #1 of step s (partial sums in LDS) | group 2: #2 of step s
         FSTAMP(2);
+        const unsigned pbase = (unsigned)(s & 1) * pstride + tile_base;
         if (grp == 2) {                                   // ---- slot Y of group 2 (the others are polling / gathering); placed before the gate block so that
                                                           // the accumulators' live range does not span it
             if (act) put_red();                           // group 1 reads these partial sums in the next step's gate phase
             write_gbuf(tv);                               // layer-0 input projection of step s+1
-            flush(tv, s);                                 // write-out of step s: posted stores, harmless beside the others' polls (moved behind
-                                                          // this group's gather in slot Z they make it late for barrier #1: +0.23 ms per forward)
+            // dropout(h0_s) is only read by this group (its next slot X), so it gathers that block itself -- here, beside the
+            // others' poll + gather and behind its own flag poll (the write-out stores come later, in slot Z: a wave's poll
+            // loop would sit out its own stores).
+            if (DROP && s < T) {
+                if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6)) return;
+                u32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pbase + (unsigned)F_REGION + (unsigned)((tv & 255) + 256 * k) * 4) * 4, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i4 = ((tv & 255) + 256 * k) * 4;
+                    const int o = (i4 >> 8) * FLDHB + (i4 & (FH - 1));
+                    uint2 hi2, lo2;
+                    hi2.x = (v[k].x >> 16) | (v[k].y & 0xffff0000u); hi2.y = (v[k].z >> 16) | (v[k].w & 0xffff0000u);
+                    lo2.x = (v[k].x & 0xffffu) | (v[k].y << 16);      lo2.y = (v[k].z & 0xffffu) | (v[k].w << 16);
+                    *reinterpret_cast<uint2*>(hs0d + o) = hi2; *reinterpret_cast<uint2*>(hs0d + FPLANE + o) = lo2;
+                }
+            }
         }
-        const unsigned pbase = (unsigned)(s & 1) * pstride + tile_base;
         if (grp < 2 && act) {
             // branch-free over the two roles: the input-projection term is gi = A + B with
             //   layer 0: A = prefetched projection (gbuf), B = a zero pair ; layer 1: A, B = group 2's two K halves (b_ih inside)
@@ -270,33 +288,16 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         bar_lds();                                        // groups 0/1: #2 (every publishing wave drained) | group 2: #3
         if (tid == 0) { if (fast) st_local(myflag, (unsigned)s + 1u); else st_agent(myflag, (unsigned)s + 1u); }
         if (grp == 2) {
-            // slot Z of group 2.  dropout(h0_s) is only read by this group (next slot X), so it gathers that block itself:
-            // passing barrier #3 means groups 0 / 1 of this workgroup saw all eight flags, no poll needed.
-            // The member's HBM streams are issued here too (write-out of step s, prefetch of the input projection two steps
-            // ahead): groups 0 / 1 are in their MFMAs now and nothing latency-critical uses the CU's memory pipeline -- beside
-            // the others' flag polls and gathers these 28 KB per step queued in front of them.
-            // prefetch of the input projection two steps ahead: HBM LOADS are issued here, while groups 0 / 1 are in their MFMAs --
-            // issued beside their flag polls / gathers (slot Y) they queued in front of them: +0.10 ms per forward (A/B measured).
-            // The gather goes FIRST: a CU returns loads in issue order, the gather's L2 hits would otherwise wait
-            // for the prefetch's HBM round trip and this group would be late for barrier #1.
-            if (DROP && s < T) {
-                u32x4 v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pbase + (unsigned)F_REGION + (unsigned)((tv & 255) + 256 * k) * 4) * 4, 0, 16 /* sc1 */);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i4 = ((tv & 255) + 256 * k) * 4;
-                    const int o = (i4 >> 8) * FLDHB + (i4 & (FH - 1));
-                    uint2 hi2, lo2;
-                    hi2.x = (v[k].x >> 16) | (v[k].y & 0xffff0000u); hi2.y = (v[k].z >> 16) | (v[k].w & 0xffff0000u);
-                    lo2.x = (v[k].x & 0xffffu) | (v[k].y << 16);      lo2.y = (v[k].z & 0xffffu) | (v[k].w << 16);
-                    *reinterpret_cast<uint2*>(hs0d + o) = hi2; *reinterpret_cast<uint2*>(hs0d + FPLANE + o) = lo2;
-                }
-            }
-            // (loads return to a wave in order: issued in front of the gather, the HBM prefetch would hold the gather's data -- and
-            // with it this group's arrival at the next barrier -- back by its whole round trip)
-            issue_gi(tv, s + 2);                          // (in front of the gather: 1.49 instead of 1.44 ms per 2-layer forward incl. the projection GEMM)
+            // slot Z of group 2 (groups 0 / 1 are in their MFMAs: nothing latency-critical uses the CU's memory pipeline now, and
+            // a CU returns loads in issue order across its waves -- DESIGN 4.1c): the member's HBM streams.  Write-out of step s,
+            // then the prefetch of the input projection two steps ahead (issued beside the others' flag polls / gathers
+            // instead, the loads queue in front of them: +0.10 ms per forward).  Schedules measured for this group, 2-layer forward
+            // incl. the projection GEMM: prefetch, gather, (write-out in slot Y) 1.49 ms; gather, prefetch 1.44; gather, write-out,
+            // prefetch all here 1.66; poll + gather + write-out in slot Y 1.58; poll + gather in slot Y, write-out + prefetch
+            // here 1.39 (this one).  The group is close to being the critical resource: ~1400 ticks of MFMAs, ~1800 of
+            // poll + gather, ~2700 to push 31 KB through the CU's memory pipeline, out of a 6800-tick step.
+            flush(tv, s);                                 // write-out of step s (obuf is next written in the others' slot Y of step s+1)
+            issue_gi(tv, s + 2);
         } else {
             FSTAMP(5);
             if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6)) return;      // every wave polls (one poller + a verdict barrier measured no faster)
