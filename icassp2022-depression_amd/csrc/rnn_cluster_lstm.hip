@@ -40,8 +40,17 @@ struct LB {
 // SPLIT: recurrent products on the bf16 matrix cores with the 3-term split, as in the GRU sweeps (rnn_cluster16.hip):
 // 24 v_mfma_f32_16x16x32_bf16 per wave and step instead of 64 v_mfma_f32_16x16x4_f32 (384 vs 2048 cycles); h travels
 // as (bf16 hi << 16 | bf16 lo) words and lives in LDS as two bf16 planes; gates, c and h themselves stay fp32.
-template <int KCH, bool SPLIT>      // k-chunks of 16 per wave = H/32
-__global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
+// KB > 0: burst streams, as in gru_bwd_cluster_r1 (a CU returns vector loads in issue order across its waves, so
+// every HBM request of a step sits in front of that step's flag polls and gather).  Four service waves (threads CT .. CT+255)
+// own every HBM access of the member and move KB steps at a time -- on a cluster's dirty step (every KB-th; the clusters of an
+// XCD take turns) they request the input projection of steps k+KB .. k+2KB-1 (registers for KB-1 steps, then the LDS ring
+// `ibuf') and write out h, dropout(h), the four activated gates and c of the last KB steps (LDS ring `obuf', KB+1 slots).
+constexpr int L_SVC = 256;
+constexpr int LROW = 36, LARR = 16 * LROW;           // LDS row stride / array size (floats) of ibuf / obuf
+constexpr size_t lstm_fwd_lds_floats(int H, int KB) { return (size_t)BT * (H + 8) + 4 * 4 * 64 * 4 + (KB ? KB * 4 * LARR + (KB + 1) * 7 * LARR : 0); }
+
+template <int KCH, bool SPLIT, int KB>      // k-chunks of 16 per wave = H/32
+__global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
     const int LDHB = H + 8;                           // bf16 elements per row of a split plane
@@ -58,12 +67,18 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
     unsigned short* hs_hi = reinterpret_cast<unsigned short*>(smem);
     unsigned short* hs_lo = hs_hi + BT * LDHB;
     float* red = smem + hs_floats;                    // [4 waves][4 gates][64][4]
-    for (int i = tid; i < hs_floats; i += CT) hs[i] = 0.f;
+    constexpr bool BURST = KB > 0;
+    constexpr int KBX = BURST ? KB : 1;
+    float* ibuf = red + 4 * 4 * 64 * 4;               // [KB][4 gates][16][LROW]: input projection of step k in slot k % KB
+    float* obuf = ibuf + KBX * 4 * LARR;              // [KB+1][7][16][LROW]: h, dropout(h), i, f, g, o, c of step k in slot k % (KB+1)
+    const bool svc = BURST && tid >= CT;              // wave-uniform
+    for (int i = tid; i < hs_floats; i += (BURST ? CT + L_SVC : CT)) hs[i] = 0.f;
 
     constexpr int KS2 = KCH / 2;                      // 32-wide k-steps per wave (SPLIT)
     f32x4 wr[SPLIT ? 1 : 4][SPLIT ? 1 : KCH];
     u32x4 wq[SPLIT ? 4 : 1][SPLIT ? KS2 : 1][2];      // [gate][k-step][hi, lo]
-    if constexpr (SPLIT) {
+    if (svc) {
+    } else if constexpr (SPLIT) {
         const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp[dir]);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -92,26 +107,94 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + cl * NC, NC, c, p.status);
     if (sx < 0) return;
     const bool fast = sx == 1;
+    if constexpr (BURST) {
+        if (svc) {
+            // ---- the service waves' whole life.  Thread st: piece idx = st + 256 i of a step's pieces -> array idx / 128 (wave-
+            // uniform: waves 4, 5 even arrays, waves 6, 7 odd ones), utterance row (idx % 128) / 8, 16-byte piece idx % 8.
+            const int st = tid - CT, sr = (st >> 3) & 15, sp = st & 7;
+            const bool sodd = __builtin_amdgcn_readfirstlane((st >> 7) & 1) != 0;
+            const int sb = p.b0 + bt * BT + sr;
+            const bool svalid = sb < p.B;
+            const int scol = 32 * c + sp * 4;
+            const int phi = (bt >> 3) % KBX;          // the clusters of an XCD take their dirty steps in turn
+            f32x4 sreg[KBX][2];
+            auto tstep = [&](int k) { return dir ? T - 1 - k : k; };
+            auto svc_issue = [&](int k0, int n) {     // input projection of steps k0 .. k0+n-1 -> registers (gates sodd, sodd + 2)
+#pragma unroll
+                for (int d = 0; d < KBX; ++d)
+                    if (d < n) {
+                        const int k = k0 + d;
+                        const bool on = svalid && k < T;
+                        const float* src = p.gi + ((size_t)sb * T + tstep(k)) * p.ldgi + dir * 4 * H + (sodd ? H : 0) + scol;
+                        sreg[d][0] = on ? ld4(src) : zero4();
+                        sreg[d][1] = on ? ld4(src + 2 * H) : zero4();
+                    }
+            };
+            auto svc_put = [&](int k0, int n) {
+#pragma unroll
+                for (int d = 0; d < KBX; ++d)
+                    if (d < n) {
+                        float* dst = ibuf + ((k0 + d) % KBX) * 4 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
+                        *reinterpret_cast<f32x4*>(dst) = sreg[d][0];
+                        *reinterpret_cast<f32x4*>(dst + 2 * LARR) = sreg[d][1];
+                    }
+            };
+            // write-out arrays: 0 h, 1 dropout(h), 2..5 the activated gates, 6 c.  Even waves: 0, 2, 4, 6; odd waves: 1, 3, 5.
+            float* const ybase = sodd ? p.ydrop : p.y;
+            auto svc_flush = [&](int k0, int k1) {
+                if (!svalid) return;
+                for (int k = k0 < 0 ? 0 : k0; k < k1; ++k) {
+                    const size_t row = (size_t)sb * T + tstep(k);
+                    const float* o = obuf + (k % (KBX + 1)) * 7 * LARR + sr * LROW + sp * 4;
+                    if (ybase) *reinterpret_cast<f32x4*>(ybase + row * p.ldy + dir * H + scol) = ld4(o + (sodd ? LARR : 0));
+                    if (p.svg) {
+                        float* gs = p.svg + row * ldsg + dir * 4 * H + scol;
+                        *reinterpret_cast<f32x4*>(gs + (sodd ? H : 0)) = ld4(o + (sodd ? 3 : 2) * LARR);
+                        *reinterpret_cast<f32x4*>(gs + (sodd ? 3 * H : 2 * H)) = ld4(o + (sodd ? 5 : 4) * LARR);
+                        if (!sodd) *reinterpret_cast<f32x4*>(p.svc + row * ldsc + dir * H + scol) = ld4(o + 6 * LARR);
+                    }
+                }
+            };
+            svc_issue(0, KBX); svc_put(0, KBX);       // steps 0 .. KB-1 straight into the ring
+            svc_issue(KBX, phi);                      // steps KB .. KB+phi-1: written at step phi-1, before the first dirty step (k = phi)
+            __syncthreads();
+            for (int k = 0; k < T; ++k) {             // same barrier sequence as the compute waves: three per step, one in the last
+                const int jj = (k + KBX - phi) % KBX, last = k - jj;
+                if (jj == 0) { svc_issue(k + KBX, KBX); svc_flush(k - KBX, k); }
+                bar_lds();                           // #1 (partial sums)
+                if (k == T - 1) break;
+                bar_lds();                           // #2 (the compute waves' drain barrier): step k's ring slot is consumed
+                if (jj == KBX - 1) { if (last >= 0) svc_put(last + KBX, KBX); else svc_put(KBX, phi); }
+                bar_lds();                           // #3 (gathered h in LDS)
+            }
+            __syncthreads();                          // the last step's results are in obuf
+            svc_flush(T - 1 - (T - 1 + KBX - phi) % KBX, T);
+            return;
+        }
+        __syncthreads();
+    }
     float2 gin[4];
-    {
+    if constexpr (!BURST) {
         const int t0 = dir ? T - 1 : 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             gin[g] = valid ? ld2(p.gi + ((size_t)b * T + t0) * p.ldgi + dir * 4 * H + g * H + col) : f2(0.f, 0.f);
     }
-    __syncthreads();
+    if constexpr (!BURST) __syncthreads();            // (BURST: the barrier above, shared with the service waves' prologue)
 
     for (int s = 0; s < T; ++s) {
         const int t = dir ? (T - 1 - s) : s;
         const size_t row = (size_t)b * T + t;
         float2 gi[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gi[g] = gin[g];
         const bool more = s + 1 < T;
-        if (valid && more) {
-            const size_t rown = dir ? row - 1 : row + 1;
+        if constexpr (!BURST) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gin[g] = ld2(p.gi + rown * p.ldgi + dir * 4 * H + g * H + col);
+            for (int g = 0; g < 4; ++g) gi[g] = gin[g];
+            if (valid && more) {
+                const size_t rown = dir ? row - 1 : row + 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gin[g] = ld2(p.gi + rown * p.ldgi + dir * 4 * H + g * H + col);
+            }
         }
         f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
         if constexpr (SPLIT) {
@@ -149,6 +232,12 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(red + ((w * 4 + g) * 64 + lane) * 4) = acc[g];
         bar_lds();
+        const int ulc = col - 32 * c;                 // this lane's pair of units inside the member's 32
+        if constexpr (BURST) {
+            const float* ib = ibuf + (s % KBX) * 4 * LARR + j * LROW + ulc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gi[g] = ld2(ib + g * LARR);
+        }
         float2 tot[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -176,7 +265,16 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
             __builtin_amdgcn_s_barrier();
             if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         }
-        if (valid) {
+        if constexpr (BURST) {
+            float* ob = obuf + (s % (KBX + 1)) * 7 * LARR + j * LROW + ulc;
+            st2(ob, h);
+            if (p.ydrop) {
+                const size_t o = row * p.ldy + dir * H + col;
+                const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+                st2(ob + LARR, f2(h.x * (kh ? m[2] : m[0]), h.y * (kh ? m[3] : m[1])));
+            }
+            if (p.svg) { st2(ob + 2 * LARR, ig); st2(ob + 3 * LARR, fg); st2(ob + 4 * LARR, gg); st2(ob + 5 * LARR, og); st2(ob + 6 * LARR, cst); }
+        } else if (valid) {
             const size_t o = row * p.ldy + dir * H + col;
             st2(p.y + o, h);
             if (p.ydrop) {
@@ -211,6 +309,7 @@ __global__ __launch_bounds__(CT) void lstm_fwd_cluster(LF p) {
             bar_lds();
         }
     }
+    if constexpr (BURST) __syncthreads();             // the service waves flush the last steps after this
     if (valid && p.h_n) st2(p.h_n + ((size_t)dir * p.B + b) * H + col, hlast);
 }
 
@@ -470,14 +569,26 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     DepProfScope prof(DEP_PROF_LSTM_FWD, a.stream);
-    const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 4 * 64 * 4) * sizeof(float);
+    static int kb_env = -1;                           // DEP_LSTM_BURST=0: every wave streams for itself, every step (round-1 schedule)
+    if (kb_env < 0) { const char* v = getenv("DEP_LSTM_BURST"); kb_env = (v && atoi(v) == 0) ? 0 : 4; }
+    const int kb = kb_env;
+    const size_t lds = lstm_fwd_lds_floats(a.H, kb) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4) * sizeof(float)));
+        attr = true;
+    }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
-        if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
-        else hipLaunchKernelGGL((lstm_fwd_cluster<4, false>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
+        const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
+        if (kb) { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4>), grid, block, lds, a.stream, p);
+                  else hipLaunchKernelGGL((lstm_fwd_cluster<4, false, 4>), grid, block, lds, a.stream, p); }
+        else    { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 0>), grid, block, lds, a.stream, p);
+                  else hipLaunchKernelGGL((lstm_fwd_cluster<4, false, 0>), grid, block, lds, a.stream, p); }
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
