@@ -316,8 +316,13 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
 // =============================================================================== backward
 struct StepIn { float2 ig, fg, gg, og, ct, cp, dy; };
 
-template <int NTW, bool SPLIT>      // output tiles per wave = H/64
-__global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
+// KB > 0: burst streams (see lstm_fwd_cluster / gru_bwd_cluster_r1): the service waves bring the saved gates, c_t, c_{t-1} and dy of
+// KB steps per burst into the LDS ring `ibuf' and write the four gate gradients of the last KB steps out of `obuf'.
+constexpr int LB_IBUF = 2304;                        // float offset of ibuf (the gate-gradient planes live in [0, 2304))
+constexpr size_t lstm_bwd_lds_floats(int KB) { return KB ? (size_t)LB_IBUF + KB * 7 * LARR + (KB + 1) * 4 * LARR : (size_t)BT * (128 + 8); }
+
+template <int NTW, bool SPLIT, int KB>      // output tiles per wave = H/64
+__global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 128, KCB = KS / 16, LDG = KS + LPAD;
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane
@@ -335,9 +340,15 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
     unsigned short* dg_hi = reinterpret_cast<unsigned short*>(smem);
     unsigned short* dg_lo = dg_hi + BT * LDGB;
 
+    constexpr bool BURST = KB > 0;
+    constexpr int KBX = BURST ? KB : 1;
+    const bool svc = BURST && tid >= CT;              // wave-uniform
+    float* ibuf = smem + LB_IBUF;                     // [KB][7][16][LROW]: i, f, g, o, c_t, c_{t-1}, dy of step k (k = T-1-s) in slot k % KB
+    float* obuf = ibuf + KBX * 7 * LARR;              // [KB+1][4][16][LROW]: di, df, dg, do of step k in slot k % (KB+1)
     f32x4 wr[SPLIT ? 1 : NTW][SPLIT ? 1 : KCB];
     u32x4 wq[SPLIT ? NTW : 1][SPLIT ? 4 : 1][2];      // [tile][k-step = gate][hi, lo]
-    if constexpr (SPLIT) {
+    if (svc) {
+    } else if constexpr (SPLIT) {
         const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp[dir]);
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
             for (int k = 0; k < KCB; ++k)
                 wr[i][k] = p.wp[dir][(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
     }
-    float2 dhrec = (p.dh_n && valid) ? ld2(p.dh_n + ((size_t)dir * p.B + b) * H + col) : f2(0.f, 0.f);
+    float2 dhrec = (p.dh_n && valid && !svc) ? ld2(p.dh_n + ((size_t)dir * p.B + b) * H + col) : f2(0.f, 0.f);
     float2 dcrec = f2(0.f, 0.f);
     float2 db[4] = {f2(0.f, 0.f), f2(0.f, 0.f), f2(0.f, 0.f), f2(0.f, 0.f)};
     const int cl = dir * p.nbtp + bt;
@@ -380,8 +391,72 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
             if (p.dy) st.dy = ld2(p.dy + row * p.lddy + dir * H + col);
         }
     };
+    if constexpr (BURST) {
+        if (svc) {
+            // ---- the service waves' whole life (thread -> piece mapping as in lstm_fwd_cluster; step counter k = T-1-s)
+            const int st = tid - CT, sr = (st >> 3) & 15, sp = st & 7;
+            const bool sodd = __builtin_amdgcn_readfirstlane((st >> 7) & 1) != 0;
+            const int sb = p.b0 + bt * BT + sr;
+            const bool svalid = sb < p.B;
+            const int scol = 32 * c + sp * 4;
+            const int phi = (bt >> 3) % KBX;
+            f32x4 sreg[KBX][4];
+            // input arrays: even waves 0 i, 2 g, 4 c_t, 6 dy ; odd waves 1 f, 3 o, 5 c_{t-1}
+            auto svc_issue = [&](int k0, int n) {
+#pragma unroll
+                for (int d = 0; d < KBX; ++d)
+                    if (d < n) {
+                        const int sstep = T - 1 - (k0 + d);
+                        const bool on = svalid && sstep >= 0;
+                        const int t = dir ? (T - 1 - sstep) : sstep;
+                        const size_t row = (size_t)sb * T + t;
+                        const float* gs = p.svg + row * ldsg + dir * 4 * H + (sodd ? H : 0) + scol;
+                        sreg[d][0] = on ? ld4(gs) : zero4();
+                        sreg[d][1] = on ? ld4(gs + 2 * H) : zero4();
+                        const size_t rowc = sodd ? (dir ? row + 1 : row - 1) : row;       // odd waves: c of the previous time step of this direction
+                        sreg[d][2] = (on && (!sodd || sstep > 0)) ? ld4(p.svc + rowc * ldsc + dir * H + scol) : zero4();
+                        sreg[d][3] = (on && !sodd && p.dy) ? ld4(p.dy + row * p.lddy + dir * H + scol) : zero4();
+                    }
+            };
+            auto svc_put = [&](int k0, int n) {
+#pragma unroll
+                for (int d = 0; d < KBX; ++d)
+                    if (d < n) {
+                        float* dst = ibuf + ((k0 + d) % KBX) * 7 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
+                        *reinterpret_cast<f32x4*>(dst) = sreg[d][0];
+                        *reinterpret_cast<f32x4*>(dst + 2 * LARR) = sreg[d][1];
+                        *reinterpret_cast<f32x4*>(dst + 4 * LARR) = sreg[d][2];
+                        if (!sodd) *reinterpret_cast<f32x4*>(dst + 6 * LARR) = sreg[d][3];
+                    }
+            };
+            auto svc_flush = [&](int k0, int k1) {    // gate gradients of steps k0 .. k1-1: even waves di, dg ; odd waves df, do
+                if (!svalid) return;
+                for (int k = k0 < 0 ? 0 : k0; k < k1; ++k) {
+                    const int sstep = T - 1 - k, t = dir ? (T - 1 - sstep) : sstep;
+                    const float* o = obuf + (k % (KBX + 1)) * 4 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
+                    float* g = p.dgi + ((size_t)sb * T + t) * p.lddg + dir * 4 * H + (sodd ? H : 0) + scol;
+                    *reinterpret_cast<f32x4*>(g) = ld4(o);
+                    *reinterpret_cast<f32x4*>(g + 2 * H) = ld4(o + 2 * LARR);
+                }
+            };
+            svc_issue(0, KBX); svc_put(0, KBX);
+            svc_issue(KBX, phi);
+            __syncthreads();
+            for (int k = 0; k < T; ++k) {             // same barrier sequence as the compute waves: two per step, one in the last
+                const int jj = (k + KBX - phi) % KBX, last = k - jj;
+                if (jj == 0) { svc_issue(k + KBX, KBX); svc_flush(k - KBX, k); }
+                bar_lds();                           // #1
+                if (jj == KBX - 1) { if (last >= 0) svc_put(last + KBX, KBX); else svc_put(KBX, phi); }
+                if (k == T - 1) break;
+                bar_lds();                           // #2 (the compute waves' drain barrier)
+            }
+            svc_flush(T - 1 - (T - 1 + KBX - phi) % KBX, T);
+            return;
+        }
+        __syncthreads();
+    }
     StepIn cur, nxt;
-    load_step(T - 1, cur);
+    if constexpr (!BURST) load_step(T - 1, cur);
     // dropout mask of the incoming dy: drawn one step ahead while waiting for the other members (see rnn_cluster_bwd.hip)
     const bool masked = p.dy && p.drop_p > 0.f && valid;
     auto draw = [&](int s) {
@@ -395,6 +470,11 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
     for (int s = T - 1; s >= 0; --s) {
         const int t = dir ? (T - 1 - s) : s;
         const size_t row = (size_t)b * T + t;
+        if constexpr (BURST) {
+            const float* ib = ibuf + ((T - 1 - s) % KBX) * 7 * LARR + j * LROW + ul;
+            cur.ig = ld2(ib); cur.fg = ld2(ib + LARR); cur.gg = ld2(ib + 2 * LARR); cur.og = ld2(ib + 3 * LARR);
+            cur.ct = ld2(ib + 4 * LARR); cur.cp = ld2(ib + 5 * LARR); cur.dy = ld2(ib + 6 * LARR);
+        }
         const float2 dyv = f2(cur.dy.x * mk.x, cur.dy.y * mk.y);
         const float2 ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og, cp = cur.cp;
         const float2 d = f2(dhrec.x + dyv.x, dhrec.y + dyv.y);
@@ -419,7 +499,10 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
             float* dl = dgs + j * LDG + ul;
             st2(dl, dig); st2(dl + 32, dfg); st2(dl + 64, dgg); st2(dl + 96, dog);
         }
-        if (valid) {
+        if constexpr (BURST) {
+            float* ob = obuf + ((T - 1 - s) % (KBX + 1)) * 4 * LARR + j * LROW + ul;
+            st2(ob, dig); st2(ob + LARR, dfg); st2(ob + 2 * LARR, dgg); st2(ob + 3 * LARR, dog);
+        } else if (valid) {
             float* g = p.dgi + row * p.lddg + dir * 4 * H + col;
             st2(g, dig); st2(g + H, dfg); st2(g + 2 * H, dgg); st2(g + 3 * H, dog);
         }
@@ -427,7 +510,7 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
         db[2].x += dgg.x; db[2].y += dgg.y; db[3].x += dog.x; db[3].y += dog.y;
         bar_lds();                                   // LDS only: the dgi stores above stay in flight
         if (s == 0) break;
-        load_step(s - 1, nxt);
+        if constexpr (!BURST) load_step(s - 1, nxt);
         f32x4 acc[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; ++i) acc[i] = zero4();
@@ -487,7 +570,7 @@ __global__ __launch_bounds__(CT) void lstm_bwd_cluster(LB p) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) { sum.x += part[m].x; sum.y += part[m].y; }
         dhrec = sum;
-        cur = nxt;
+        if constexpr (!BURST) cur = nxt;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -611,14 +694,26 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     DepProfScope prof(DEP_PROF_LSTM_BWD, a.stream);
-    const size_t lds = (size_t)(BT * (128 + 8)) * sizeof(float);
+    static int kb_env = -1;                           // DEP_LSTM_BURST=0: round-1 schedule
+    if (kb_env < 0) { const char* v = getenv("DEP_LSTM_BURST"); kb_env = (v && atoi(v) == 0) ? 0 : 4; }
+    const int kb = kb_env;
+    const size_t lds = lstm_bwd_lds_floats(kb) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
+        attr = true;
+    }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
-        if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
-        else hipLaunchKernelGGL((lstm_bwd_cluster<2, false>), dim3(a.dirs * NC * p.nbtp), dim3(CT), lds, a.stream, p);
+        const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
+        if (kb) { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4>), grid, block, lds, a.stream, p);
+                  else hipLaunchKernelGGL((lstm_bwd_cluster<2, false, 4>), grid, block, lds, a.stream, p); }
+        else    { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 0>), grid, block, lds, a.stream, p);
+                  else hipLaunchKernelGGL((lstm_bwd_cluster<2, false, 0>), grid, block, lds, a.stream, p); }
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;

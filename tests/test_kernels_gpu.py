@@ -215,6 +215,8 @@ RNN_CASES = [
     ('gru', 400, 7, 16, 256, 3),        # burst-stream backward: every dirty-step phase (tiles 0..24), T not a multiple of the burst
     ('gru', 300, 13, 8, 128, 3),        # same, H = 128 members, ragged last tile
     ('gru', 200, 5, 8, 256, 3),         # T = burst + 1: the prologue's partial burst and the final flush
+    ('lstm', 400, 7, 16, 128, 3),       # burst-stream BiLSTM sweeps: every dirty-step phase, T not a multiple of the burst
+    ('lstm', 40, 5, 8, 128, 3),         # T = burst + 1
     ('gru', 20, 9, 24, 64, 3),          # H = 64: two members per tile
     ('gru', 2100, 3, 8, 64, 3),         # H = 64: chunks of 2048 + 52
     ('gru', 40, 6, 32, 512, 3),         # H = 512: sixteen members per tile (round-1 backward schedule: no room for service waves)

@@ -37,6 +37,8 @@ CASES = [
     ('lstm', 12, {}, []),
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, ['--load']),
     ('lstm', 4, {'DEP_NUM_CUS': '200'}, []),
+    ('lstm', 6, {'DEP_LSTM_BURST': '0'}, []),                     # round-1 BiLSTM schedule (no service waves)
+    ('lstm', 6, {}, ['--load', '--load-phase', 'bwd']),           # burst-stream BiLSTM backward with a co-scheduled kernel
 ]
 
 
@@ -80,6 +82,15 @@ def test_backward_burst_variants_pass_the_kernel_parity_suite(burst):
     stay parity-green -- the GRU part of the RNN-stack suite in a process with DEP_BWD_BURST set, against the oracle."""
     e = dict(os.environ, DEP_BWD_BURST=burst)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
+                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+
+
+def test_lstm_round1_schedule_passes_the_kernel_parity_suite():
+    """lstm_fwd_cluster / lstm_bwd_cluster<.., KB = 0> (every wave streams for itself; DEP_LSTM_BURST=0) stay parity-green."""
+    e = dict(os.environ, DEP_LSTM_BURST='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'lstm',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
