@@ -338,7 +338,7 @@ class Rnn:
 
     def backward(self, x, weights, dweights, dy=None, dpooled=None, dh_n=None, dx=None, grad_sync=None):
         """grad_sync: a GradSync (data parallel) -> dep_rnn_backward_overlapped: layer l's range of the flat gradient
-        buffer is all-reduced on the communication stream while the layers below are still in their sweeps."""
+        buffer is all-reduced on the communication stream beside the weight-gradient GEMMs of the layer below."""
         for i, (w, g) in enumerate(zip(weights, dweights)):
             self._warr[i] = w.data_ptr()
             self._garr[i] = g.data_ptr()

@@ -357,6 +357,14 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     return DEP_OK;
 }
 
+// DEP_COMM_OVERLAP=sweep: enqueue a layer's gradient all-reduce as soon as its GEMMs are enqueued (it may then run beside the
+// next layer's backward sweep); default: behind that sweep, beside its GEMMs.
+static bool comm_beside_sweeps() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DEP_COMM_OVERLAP"); v = (e && e[0] == 's') ? 1 : 0; }
+    return v != 0;
+}
+
 static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float* const* weights, const float* dy,
                              const float* dpooled, const float* dh_n, float* const* dweights, float* dx,
                              void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
@@ -433,6 +441,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         }
         return DEP_OK;
     }
+    float* pending_ptr = nullptr; long pending_n = 0;      // data parallel: a finished layer's gradient range waiting for the next sweep to be enqueued
     for (int l = L - 1; l >= 0; --l) {
         const bool top = l == L - 1;
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
@@ -459,6 +468,15 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
         if (rc) return rc;
+        if (pending_ptr) {
+            // the layer above's gradient range: the event recorded here completes with this sweep, the all-reduce then runs
+            // beside this layer's GEMMs.  A cluster sweep needs every one of its workgroups resident (one per CU, most of a CU's
+            // registers and LDS): a collective kernel that holds CUs when the sweep is dispatched delays the members that
+            // cannot be placed -- and with them the whole launch -- until the collective's peers on the other GPUs let it finish.
+            rc = dep_comm_enqueue_after((dep_comm*)gs->comm, pending_ptr, pending_n, s, (hipStream_t)gs->comm_stream);
+            if (rc) return rc;
+            pending_ptr = nullptr;
+        }
         float* dbi[2]; float* dbh[2];
         for (int dd = 0; dd < D; ++dd) {
             float* const* gl = dweights + (size_t)(l * D + dd) * 4;
@@ -498,11 +516,16 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
                 if (rc) return rc;
             }
         }
-        // data parallel: layer l's gradients are complete -- hand their range of the caller's flat gradient buffer to RCCL on
-        // the communication stream; it travels over xGMI while the layers below are still in their backward sweeps
+        // data parallel: layer l's gradients are complete -- their range of the caller's flat gradient buffer goes to RCCL on the
+        // communication stream.  Not right away: the collective is enqueued behind the NEXT layer's sweep (see `pending' above),
+        // so that it travels over xGMI beside that layer's weight-gradient GEMMs and never beside a sweep.  The bottom layer's
+        // range has nothing left to hide behind and goes out at once.
         if (gs && gs->comm && gs->range_ptr[l] && gs->range_count[l] > 0) {
-            rc = dep_comm_enqueue_after((dep_comm*)gs->comm, gs->range_ptr[l], gs->range_count[l], s, (hipStream_t)gs->comm_stream);
-            if (rc) return rc;
+            if (l > 0 && !comm_beside_sweeps()) { pending_ptr = gs->range_ptr[l]; pending_n = gs->range_count[l]; }
+            else {
+                rc = dep_comm_enqueue_after((dep_comm*)gs->comm, gs->range_ptr[l], gs->range_count[l], s, (hipStream_t)gs->comm_stream);
+                if (rc) return rc;
+            }
         }
     }
     return DEP_OK;

@@ -9,8 +9,8 @@ loss is a batch mean, so the path shards naturally:
     exactly, ragged last batches included;
   * the gradient exchange is a SUM all-reduce of the model's flat gradient buffer.  With the native RCCL communicator
     (`init_native_comm`, the C-ABI's dep_comm_* entry points; default on GPUs) it is cut at layer boundaries and
-    overlapped with the backward pass: the top layer's range [layer L-1 | head] is enqueued on a communication stream as
-    soon as its weight gradients exist and travels over xGMI while the layers below are still in their backward sweeps
+    overlapped with the backward pass: the top layer's range [layer L-1 | head] is enqueued on a communication stream behind
+    the next layer's backward sweep and travels over xGMI beside that layer's weight-gradient GEMMs
     (dep_rnn_backward_overlapped); what becomes final later (layer 0, LayerNorm) follows as one grouped operation, and the
     compute stream waits for the communication stream before the optimizer reads the gradients.  Without it (gloo tests,
     DEP_COMM=torch) the whole bucket is reduced in one torch.distributed all-reduce after the backward.

@@ -143,11 +143,14 @@ int dep_comm_destroy(dep_comm* comm);
  * range_count[l] name the contiguous span of the caller's flat gradient buffer that is FINAL once layer l's weight
  * gradients are written (the layer's own four tensors per direction plus whatever neighbours of the bucket were already
  * final, e.g. the head's gradients next to the top layer); count 0 skips a layer.  dep_rnn_backward_overlapped is
- * dep_rnn_backward plus: as soon as layer l's dW are enqueued on `stream`, `comm_stream` is made to wait for them (event)
- * and the SUM all-reduce of range l is enqueued there -- it runs while the layers below are still in their sweeps.  The
- * caller makes its compute stream wait for `comm_stream` before the optimizer reads the gradients.
- * Co-scheduling: collectives only ever overlap BACKWARD sweeps, which run one workgroup per CU and leave VGPR / LDS room
- * for RCCL's workgroups; the forward sweeps (which may fill a CU) never have a collective beside them because the
+ * dep_rnn_backward plus: once layer l's dW are enqueued on `stream` AND the sweep of the layer below has been enqueued behind
+ * them, `comm_stream` is made to wait for that point (event) and the SUM all-reduce of range l is enqueued there -- it runs
+ * beside the weight-gradient GEMMs of the layer below (the bottom layer's range goes out at once).  The caller makes its
+ * compute stream wait for `comm_stream` before the optimizer reads the gradients.
+ * Co-scheduling: a cluster sweep needs all of its workgroups resident (one per CU, most of the CU's registers and LDS); a
+ * collective kernel that holds CUs when a sweep is dispatched would stall it until the collective's peers let it finish.  So
+ * collectives are ordered behind the sweeps and only ever run beside GEMMs (DEP_COMM_OVERLAP=sweep restores the earlier
+ * enqueue point, beside the next backward sweep); the forward sweeps never have a collective beside them because the
  * optimizer step that precedes the next forward waits for the communication stream. */
 typedef struct {
     dep_comm* comm;
