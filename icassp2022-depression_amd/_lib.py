@@ -49,6 +49,7 @@ _SIGS = {
     'dep_rnn_forward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     'dep_rnn_backward': (C.c_int, _BWD_ARGS),
     'dep_rnn_backward_overlapped': (C.c_int, _BWD_ARGS + [C.POINTER(GradSync)]),
+    'dep_comm_available': (C.c_int, []),
     'dep_comm_unique_id': (C.c_int, [_P, C.c_size_t]),
     'dep_comm_init': (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, _P, C.c_size_t, C.c_int]),
     'dep_comm_world': (C.c_int, [_P]),

@@ -73,8 +73,10 @@ def train(epoch):
         a, b = _common.rank_slice(lo, hi)
         parallel.set_global_count(hi - lo)
         if b <= a:                                  # empty shard of a small (ragged) mini-batch: zero-contribution step
-            total_loss += nn.empty_shard_step(model, optimizer).item()
+            # same collective order as the working ranks: gradients, predictions (hi - lo floats), then the loss scalar
+            loss = nn.empty_shard_step(model, optimizer)
             pred = np.hstack((pred, parallel.all_reduce_sum(torch.zeros(hi - lo, device=model.device)).cpu().numpy()))
+            total_loss += loss.item()
             continue
         x = torch.from_numpy(np.ascontiguousarray(X_train[a:b])).type(torch.FloatTensor)
         y = torch.from_numpy(np.ascontiguousarray(Y_train[a:b])).type(torch.FloatTensor)

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -23,40 +24,49 @@ extern "C" int dep_version(void) { return 100; }
 extern "C" const char* dep_arch(void) { return "gfx950"; }
 
 // ---- event-based kernel timing -------------------------------------------------------
+// Process-wide recorder, safe to use from several host threads / streams at once (SURVEY 8b "reentrant per stream"): the open
+// begin/end pair is per thread, the event pool and the record list are guarded by one mutex (taken only while profiling is on).
 namespace {
 struct ProfRec { hipEvent_t a, b; int cat; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
 std::vector<ProfRec> g_recs;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
-ProfRec g_cur;
+thread_local ProfRec g_cur;
 }  // namespace
-bool dep_prof_on() { return g_prof_on; }
+bool dep_prof_on() { return g_prof_on.load(std::memory_order_relaxed); }
 void dep_prof_begin(int cat, hipStream_t s) {
-    if (g_pool.empty()) {
-        hipEvent_t a, b;
-        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-        g_pool.push_back({a, b});
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_pool.empty()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            g_pool.push_back({a, b});
+        }
+        g_cur.a = g_pool.back().first; g_cur.b = g_pool.back().second; g_cur.cat = cat;
+        g_pool.pop_back();
     }
-    g_cur.a = g_pool.back().first; g_cur.b = g_pool.back().second; g_cur.cat = cat;
-    g_pool.pop_back();
     (void)hipEventRecord(g_cur.a, s);
 }
 void dep_prof_end(hipStream_t s) {
     (void)hipEventRecord(g_cur.b, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_recs.push_back(g_cur);
 }
-extern "C" int dep_profile_enable(int on) { g_prof_on = on != 0; return DEP_OK; }
+extern "C" int dep_profile_enable(int on) { g_prof_on.store(on != 0); return DEP_OK; }
 // Sums the recorded launch durations per category (ms) and resets; blocks until the events completed.
 extern "C" int dep_profile_read(double* total_ms, int* counts, int ncat) {
     for (int i = 0; i < ncat; ++i) { total_ms[i] = 0.0; counts[i] = 0; }
-    for (auto& r : g_recs) {
+    std::vector<ProfRec> recs;
+    { std::lock_guard<std::mutex> lk(g_prof_mu); recs.swap(g_recs); }
+    for (auto& r : recs) {
         (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
         if (r.cat < ncat) { total_ms[r.cat] += ms; counts[r.cat] += 1; }
-        g_pool.push_back({r.a, r.b});
     }
-    g_recs.clear();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : recs) g_pool.push_back({r.a, r.b});
     return DEP_OK;
 }
 
@@ -260,7 +270,8 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     int rc;
     if (lo.cluster) { rc = dep_cluster_reset_status(W + lo.xbuf, s); if (rc) return rc; }
     // the recurrent-weight images packed below are precision-mode specific: remember which mode this reserve holds
-    record_reserve_mode(reserve, sweep_split_mode() ? 1 : 0);
+    // bit 0: precision mode; bit 1: the backward image is the 16-unit-member one (a caller flipping DEP_CLUSTER16_BWD is refused too)
+    record_reserve_mode(reserve, (sweep_split_mode() ? 1 : 0) | (lo.cluster16_bwd ? 2 : 0));
     if (lo.fused2 && sweep_split_mode()) {
         // both layers in one launch: layer 1 runs one step behind layer 0 and takes its input straight from the exchanged
         // h0_t (no layer-1 input-projection GEMM, no GI round trip through HBM for it)
@@ -270,8 +281,13 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         rc = dep_pack_cluster_fwd_split(w1[1], R + lo.wp[1][0], H, s); if (rc) return rc;
         rc = dep_pack_cluster_fwd_split(w1[0], W + lo.wih_img, H, s); if (rc) return rc;
         if (d->training) {
-            rc = dep_pack_cluster_bwd_split(w0[1], R + lo.wpT[0][0], H, s); if (rc) return rc;
-            rc = dep_pack_cluster_bwd_split(w1[1], R + lo.wpT[1][0], H, s); if (rc) return rc;
+            // same choice as the per-layer path below: the 16-unit-member backward (DEP_CLUSTER16_BWD=1) reads its own image
+            for (int l = 0; l < 2; ++l) {
+                const float* whh = l == 0 ? w0[1] : w1[1];
+                rc = lo.cluster16_bwd ? dep_pack_cluster16_bwd(whh, R + lo.wpT[l][0], H, s)
+                                      : dep_pack_cluster_bwd_split(whh, R + lo.wpT[l][0], H, s);
+                if (rc) return rc;
+            }
         }
         float* gi = W + lo.gi;
         rc = dep_gemm_internal(0, 1, BTr, G * H, d->F, x, d->F, w0[0], d->F, gi, G * H, w0[2], 0.f, 0, 0, nullptr, 0, s);
@@ -381,10 +397,15 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     }
     if (lo.cluster) {
         const int fm = lookup_reserve_mode(reserve);
-        if (fm >= 0 && fm != (sweep_split_mode() ? 1 : 0)) {
+        if (fm >= 0 && (fm & 1) != (sweep_split_mode() ? 1 : 0)) {
             dep_set_error("dep_rnn_backward: the reserve was produced by a forward in %s mode, the current mode is %s "
                           "(dep_set_gemm_mode / DEP_SWEEP_MODE must not change between a forward and its backward)",
-                          fm ? "bf16x3" : "f32", fm ? "f32" : "bf16x3");
+                          (fm & 1) ? "bf16x3" : "f32", (fm & 1) ? "f32" : "bf16x3");
+            return DEP_ERR_ARG;
+        }
+        if (fm >= 0 && ((fm >> 1) & 1) != (lo.cluster16_bwd ? 1 : 0)) {
+            dep_set_error("dep_rnn_backward: the reserve holds the %s backward weight image, this call would run the other kernel",
+                          (fm & 2) ? "16-unit-member" : "32-unit-member");
             return DEP_ERR_ARG;
         }
     }

@@ -64,6 +64,10 @@ struct dep_comm {
         if (r_ != ncclSuccess) { dep_set_error("%s: %s", what, g_rccl.GetErrorString(r_)); return DEP_ERR_HIP; } \
     } while (0)
 
+// 1 when librccl resolves in this process (no collective, no GPU work): lets every rank agree on the transport BEFORE
+// anybody enters a collective that the others would otherwise wait in for ever.
+extern "C" int dep_comm_available(void) { return load_rccl() ? 1 : 0; }
+
 extern "C" int dep_comm_unique_id(void* id_out, size_t bytes) {
     DEP_CHECK_ARG(id_out && bytes >= sizeof(ncclUniqueId));
     if (!load_rccl()) return DEP_ERR_HIP;

@@ -7,6 +7,7 @@
 // nn.GRU / nn.LSTM (Classification/audio_gru_whole.py:105, text_bilstm_whole.py:105), the
 // nn.Linear layers of the heads (audio_gru_whole.py:67,70) and, in backward, dX = dG W and the
 // weight gradients dW = dG^T X (split-K over the B*T rows, deterministic two-pass reduction).
+#include <atomic>
 #include "dep_common.h"
 
 namespace {
@@ -301,9 +302,9 @@ bool naive_forced() {
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
                            int splits, int kchunk, float* part, bool vec, hipStream_t s);
-static int g_split_mode = -1;
-static long g_split_min_macs = 1L << 28;
-static thread_local int g_force_exact = 0;
+static std::atomic<int> g_split_mode{-1};            // process-global (documented in dep_rnn.h)
+static std::atomic<long> g_split_min_macs{1L << 28};
+static thread_local int g_force_exact = 0;       // per calling thread: 1 = this call is exact fp32, 2 = this call is bf16x3 whatever the global mode
 static void init_split_mode() {
     if (g_split_mode < 0) { const char* e = getenv("DEP_GEMM_MODE"); g_split_mode = (e && e[0] == 'f') ? 0 : 1; }
 }
@@ -363,7 +364,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     dim3 g(p.gx * p.gy * splits);
     DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s);
     init_split_mode();
-    if (g_force_exact == 0 && g_split_mode == 1 && (long)M * N * K >= g_split_min_macs)
+    if (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode == 1 && (long)M * N * K >= g_split_min_macs))
         return dep_gemm_bf16x3_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
                                       splits, kchunk, p.part, vec, s);
 #define LAUNCH(TA, TB)                                                                    \
@@ -399,11 +400,9 @@ extern "C" int dep_gemm_f32(int transA, int transB, int M, int N, int K, const f
 extern "C" int dep_gemm_bf16x3(int transA, int transB, int M, int N, int K, const float* A, int lda,
                                const float* B, int ldb, float* C, int ldc, const float* bias, float beta,
                                int seq_T, int shiftB, void* workspace, size_t workspace_bytes, void* stream) {
-    init_split_mode();
-    const int mode = g_split_mode; const long mm = g_split_min_macs;
-    g_split_mode = 1; g_split_min_macs = 0;
+    g_force_exact = 2;                  // thread-local: the process-global mode is not touched (reentrancy)
     const int rc = dep_gemm_internal(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
                                      workspace, workspace_bytes, (hipStream_t)stream);
-    g_split_mode = mode; g_split_min_macs = mm;
+    g_force_exact = 0;
     return rc;
 }

@@ -101,8 +101,10 @@ def train(model, epoch):
         parallel.set_global_count(hi - lo)
         x, y = X_train[a:b], Y_train[a:b]
         if b <= a:                                  # empty shard of a small mini-batch: zero-contribution step
-            total_loss += nn.empty_shard_step(model, optimizer).item()
+            # same collective order as the working ranks: gradients, predictions (hi - lo floats), then the loss scalar
+            loss = nn.empty_shard_step(model, optimizer)
             pred = np.hstack((pred, parallel.all_reduce_sum(torch.zeros(hi - lo, device=model.device)).cpu().numpy()))
+            total_loss += loss.item()
             continue
         optimizer.zero_grad()
         text_feature, audio_feature = model.pretrained_feature(x)

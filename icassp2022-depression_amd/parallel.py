@@ -8,7 +8,7 @@ loss is a batch mean, so the path shards naturally:
     all-reduce of the single flat gradient bucket reproduces the reference's batch-mean gradient
     exactly, ragged last batches included;
   * the gradient exchange is a SUM all-reduce of the model's flat gradient buffer.  With the native RCCL communicator
-    (`init_native_comm`, the C-ABI's dep_comm_* entry points; default on GPUs) it is cut at layer boundaries and
+    (`init_native_comm`, the C-ABI's dep_comm_* entry points; built by `init_from_env` whenever the backend is nccl) it is cut at layer boundaries and
     overlapped with the backward pass: the top layer's range [layer L-1 | head] is enqueued on a communication stream behind
     the next layer's backward sweep and travels over xGMI beside that layer's weight-gradient GEMMs
     (dep_rnn_backward_overlapped); what becomes final later (layer 0, LayerNorm) follows as one grouped operation, and the
@@ -24,8 +24,10 @@ import torch
 _state = {'init': False}
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* when launched by torchrun."""
+def init_from_env(backend=None, native=True):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* when launched by torchrun.  On GPUs (backend "nccl")
+    this also builds the C-ABI's own RCCL communicator, so that the training scripts -- which call only this -- take the
+    overlapped gradient path bench.py measures; `native=False` / DEP_COMM=torch keeps torch.distributed's."""
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1 or dist.is_initialized():
@@ -36,6 +38,15 @@ def init_from_env(backend=None):
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=world)
+    if backend == 'nccl' and native:
+        init_native_comm()
+
+
+def transport():
+    """Which gradient transport the training step uses: 'none' (one rank), 'rccl-native' or 'torch.distributed'."""
+    if world_size() == 1 and _native['comm'] is None:
+        return 'none'
+    return 'rccl-native' if _native['comm'] is not None else 'torch.distributed'
 
 
 def _dist():
@@ -92,13 +103,28 @@ def all_reduce_grads(model):
 
 
 # ----------------------------------------------------------------------------- native RCCL communicator (C-ABI)
-_native = {'comm': None, 'stream': None, 'world': 1}
+_native = {'comm': None, 'stream': None, 'world': 1, 'why': None}
+
+
+def _agree(ok):
+    """MIN over ranks of a local success flag (torch.distributed side channel): every rank takes the same branch."""
+    d = _dist()
+    if not d or world_size() == 1:
+        return bool(ok)
+    dev = 'cuda' if d.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    d.all_reduce(t, op=d.ReduceOp.MIN)
+    return bool(int(t.item()))
 
 
 def init_native_comm(force_single=False):
     """Create the RCCL communicator through the C-ABI (dep_comm_unique_id / dep_comm_init): rank 0 obtains the id, the
     torch.distributed group (already initialised by init_from_env) carries it to the other ranks.  force_single builds a
-    one-rank communicator (tests on a single GPU)."""
+    one-rank communicator (tests on a single GPU).
+
+    No rank may enter a collective the others will not reach: the ranks first agree that librccl resolves
+    everywhere (dep_comm_available + MIN), rank 0's id travels WITH a status byte, and after ncclCommInitRank they agree
+    again.  Any disagreement -> None on EVERY rank (the torch.distributed all-reduce of the whole bucket is used instead)."""
     import ctypes as C
     from . import _lib as L
     if _native['comm'] is not None:
@@ -109,18 +135,35 @@ def init_native_comm(force_single=False):
         return None
     if os.environ.get('DEP_COMM', 'rccl') == 'torch':
         return None
-    lib = L.load()
+    try:
+        lib = L.load()
+        have = bool(lib.dep_comm_available()) and torch.cuda.is_available()
+    except Exception:                                       # noqa: BLE001 -- a rank without the library still has to vote
+        lib, have = None, False
+    if not _agree(have):
+        _native['why'] = 'librccl / the HIP library is not available on every rank'
+        return None
     dev = torch.cuda.current_device()
-    idbuf = (C.c_char * 128)()
+    msg = bytearray(129)                                    # [status | 128-byte id]
     if rk == 0:
-        L.check(lib.dep_comm_unique_id(idbuf, 128), 'dep_comm_unique_id')
-    t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone().cuda()
+        idbuf = (C.c_char * 128)()
+        if lib.dep_comm_unique_id(idbuf, 128) == 0:
+            msg[0] = 1; msg[1:] = idbuf.raw
+    t = torch.frombuffer(msg, dtype=torch.uint8).clone().cuda()
     if d and world > 1:
         d.broadcast(t, src=0)
     raw = bytes(t.cpu().numpy().tobytes())
+    if raw[0] != 1:
+        _native['why'] = 'rank 0 could not create the RCCL id'
+        return None
     comm = C.c_void_p()
-    L.check(lib.dep_comm_init(C.byref(comm), world, rk, raw, 128, dev), 'dep_comm_init')
-    _native.update(comm=comm, stream=torch.cuda.Stream(), world=world)
+    rc = lib.dep_comm_init(C.byref(comm), world, rk, raw[1:], 128, dev)
+    if not _agree(rc == 0):
+        if rc == 0:
+            lib.dep_comm_destroy(comm)
+        _native['why'] = 'ncclCommInitRank failed on some rank'
+        return None
+    _native.update(comm=comm, stream=torch.cuda.Stream(), world=world, why=None)
     return comm
 
 
@@ -133,7 +176,7 @@ def destroy_native_comm():
     if _native['comm'] is not None:
         torch.cuda.synchronize()
         L.load().dep_comm_destroy(_native['comm'])
-        _native.update(comm=None, stream=None, world=1)
+        _native.update(comm=None, stream=None, world=1, why=None)
 
 
 def layer_buckets(spans, n_live):

@@ -16,6 +16,10 @@
  *   - no allocation happens inside the library: workspace / reserve sizes come from the *_bytes
  *     queries and the caller provides the buffers (16-byte aligned);
  *   - gate order is PyTorch's: GRU r,z,n ; LSTM i,f,g,o ; h0 = c0 = 0 always.
+ *   - threads: entry points may be called concurrently from several host threads as long as each call has its own stream,
+ *     workspace and reserve (dep_last_error is per thread; the launch-time recorder behind dep_profile_* and the
+ *     reserve-mode record are mutex-guarded).  PROCESS-GLOBAL, not per stream: dep_set_gemm_mode (precision mode of every
+ *     later call on any thread), dep_profile_enable, and the DEP_* environment switches, which are read once per process.
  */
 #ifndef DEP_RNN_H
 #define DEP_RNN_H
@@ -124,6 +128,8 @@ int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const float* const* 
  * fp32 gradient buffer is SUM all-reduced (the reference's `loss.backward(); optimizer.step()`,
  * Classification/audio_gru_whole.py:190-191, then sees the batch-mean gradient on every rank).
  * librccl is loaded at the first call (dlopen): single-GPU processes never touch it.
+ *   dep_comm_available : 1 if librccl resolves in this process, else 0 (dep_last_error says why); not a collective -- the
+ *                        host agrees on it across ranks before anyone enters dep_comm_init;
  *   dep_comm_unique_id : rank 0 obtains the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other ranks
  *                        through whatever side channel the host has (the Python layer broadcasts it with torch.distributed);
  *   dep_comm_init      : collective over all ranks (ncclCommInitRank), binds the communicator to HIP device `device`;
@@ -131,6 +137,7 @@ int dep_rnn_backward(const dep_rnn_desc* d, const float* x, const float* const* 
  *   dep_comm_allreduce_ranges : several ranges as one grouped RCCL operation (one launch);
  *   dep_comm_destroy   : releases the communicator. */
 typedef struct dep_comm dep_comm;
+int dep_comm_available(void);
 int dep_comm_unique_id(void* id_out, size_t bytes);                    /* bytes >= 128 */
 int dep_comm_init(dep_comm** comm, int world, int rank, const void* unique_id, size_t id_bytes, int device);
 int dep_comm_world(const dep_comm* comm);
@@ -189,7 +196,7 @@ int dep_gemm_bf16x3(int transA, int transB, int M, int N, int K,
                     const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     const float* bias, float beta, int seq_T, int shiftB,
                     void* workspace, size_t workspace_bytes, void* stream);
-int dep_set_gemm_mode(int mode, long min_macs);   /* mode 0 exact f32 | 1 bf16x3 split ; min_macs < 0 keeps it */
+int dep_set_gemm_mode(int mode, long min_macs);   /* PROCESS-GLOBAL. mode 0 exact f32 | 1 bf16x3 split ; min_macs < 0 keeps it */
 int dep_get_gemm_mode(void);
 
 /* nn.LayerNorm(F) over the last axis (audio_gru_whole.py:62,104). rows = B*T.

@@ -231,3 +231,113 @@ def test_checkpoint_loader_is_safe_first_and_the_exporter_writes_a_module(tmp_pa
     monkeypatch.delenv('DEP_ALLOW_PICKLE')
     again = _common.load_checkpoint_state_dict(path)
     assert list(again) == list(sd)
+
+
+# ----------------------------------------------------------------------------- collective order of the regression train() loops
+def _order_worker(rank, world, port, q, modname):
+    """a rank whose shard of the last mini-batch is empty must issue the step's collectives in the order
+    the working ranks do -- gradients, predictions (hi - lo floats), loss scalar.  The script's real train() runs on every
+    rank with a CPU stand-in for the model (the HIP model needs a GPU; the loop, nn.empty_shard_step, nn.Loss.item and
+    parallel.* are the product's).  7 rows, batch 5, world 3: the second mini-batch (2 rows) leaves rank 2 empty; a size
+    mismatch makes gloo raise (or pairs the loss with a prediction)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch
+    import torch.distributed as dist
+    from icassp2022_depression_amd import nn, parallel as par
+    m = importlib.import_module('icassp2022_depression_amd.' + modname)
+    par.init_from_env('gloo')
+
+    class Out:
+        def __init__(self, v):
+            self.data = v
+
+    class Fake:
+        device = torch.device('cpu')
+        _grad_ready = False
+        _n_live = 4
+
+        def __init__(self):
+            self.bucket = torch.zeros(4)
+
+        def train(self):
+            pass
+
+        def live_grad_bucket(self):
+            return self.bucket
+
+        def sync_plan(self):
+            return {}, []
+
+        def _rows(self, x):
+            if isinstance(x, list):                         # fusion: list of (audio, text) pairs
+                return torch.tensor([float(np.asarray(p[0]).sum()) for p in x])
+            return x.reshape(x.shape[0], -1).sum(1)
+
+        def __call__(self, x):
+            return Out(self._rows(x).view(-1, 1) if not isinstance(x, torch.Tensor) or x.dim() != 2 else x.sum(1, keepdim=True))
+
+        def pretrained_feature(self, x):
+            r = self._rows(x).view(-1, 1)
+            return r, 2 * r
+
+    class Opt:
+        def zero_grad(self):
+            fake._grad_ready = False
+
+        def step(self):
+            pass
+
+    def crit(*a):
+        out = a[0].data if hasattr(a[0], 'data') and not isinstance(a[0], torch.Tensor) else a[0]
+        n_glob = par.global_count(out.shape[0])
+        val = out.double().sum().float().view(1) / n_glob
+
+        def bw():
+            fake.bucket = torch.full((4,), float(out.shape[0]))
+            fake._grad_ready = True
+            par.all_reduce_grads(fake)
+        return nn.Loss(val, bw, reduce=par.world_size() > 1)
+
+    fake = Fake()
+    N = 7
+    feats = np.arange(N * 6, dtype=np.float32).reshape(N, 3, 2) / 10
+    targs = np.arange(N, dtype=np.float32)
+    m.config.update(batch_size=5)
+    m.train_dep_idxs, m.train_non_idxs = [0, 1, 2], [3, 4, 5, 6]
+    if modname == 'fuse_net':
+        m.fuse_features = [[feats[i], feats[i] * 2] for i in range(N)]; m.fuse_targets = targs
+        m.optimizer, m.criterion = Opt(), crit
+        args = (fake, 1)
+    else:
+        which = 'audio' if modname.startswith('audio') else 'text'
+        setattr(m, which + '_features', feats); setattr(m, which + '_targets', targs)
+        m.model, m.optimizer, m.criterion = fake, Opt(), crit
+        args = (1,)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        mae = m.train(*args)
+    q.put((rank, float(mae)))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('modname', ['audio_bilstm_perm', 'text_bilstm_perm', 'fuse_net'])
+def test_regression_train_empty_shard_collective_order_gloo(modname):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 28100 + os.getpid() % 800 + {'audio_bilstm_perm': 0, 'text_bilstm_perm': 1, 'fuse_net': 2}[modname]
+    procs = [ctx.Process(target=_order_worker, args=(r, 3, port, q, modname)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every rank assembled the same predictions (row sums of its features) -> the same MAE, equal to the serial value
+    feats = np.arange(7 * 6, dtype=np.float32).reshape(7, 3, 2) / 10
+    pred = feats.reshape(7, -1).sum(1) * (3 if modname == 'fuse_net' else 1)      # the fusion stand-in outputs text + audio = 3 x
+    expect = float(np.mean(np.abs(np.arange(7) - pred)))
+    for r in range(3):
+        assert abs(got[r] - expect) < 1e-5, (r, got[r], expect)
