@@ -8,6 +8,7 @@
 // The split happens once per element while staging global -> LDS (v_cvt_pk_bf16_f32), never in HBM.
 //
 //   C[M,N] = opA(A)[M,K] * opB(B)[K,N] + bias[N] + beta*C        same operand forms / split-K / row shift as gemm.hip
+#include <type_traits>
 #include "dep_common.h"
 
 namespace {
@@ -80,16 +81,26 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const f32x2v v = {x0, x1};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
-    const f32x2v d = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2v));
-}
+// x - bf16(x) for both halves of a packed pair in ONE instruction each: v_dot2c_f32_bf16 d, a, b does d += a.lo*b.lo + a.hi*b.hi
+// on packed bf16 operands, so with b = {-1, 0} / {0, -1} and d = x it leaves x - hi exactly (the difference is representable:
+// hi is x rounded to 8 significant bits; checked against integer arithmetic on the GPU, tools/micro/t_dot2c).  That replaces
+// the shift / mask / two subtractions per pair: 4 VALU per pair instead of 6 -- these kernels are VALU-issue bound (the
+// conversions share the SIMD's issue port with the MFMAs), not matrix-pipe bound.
+// The instruction is issued from inline asm, so hipcc's hazard recognizer cannot see it: on gfx90a+ a DOT instruction's VGPR
+// result needs 3 wait states before a DIFFERENT VALU opcode reads or overwrites it (LLVM GCNHazardRecognizer:
+// DotWriteDifferentVALURead / ...Write = 3; without them the conversions below read stale registers -- seen as O(1) errors).
+// All four residuals of a quad are formed in one block that ends with the wait states.
 __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
-    unsigned h0, h1, l0, l1;
-    split2(x[0], x[1], h0, l0);
-    split2(x[2], x[3], h1, l1);
+    const f32x2v v01 = {x[0], x[1]}, v23 = {x[2], x[3]};
+    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2v));
+    const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2v));
+    float d0 = x[0], d1 = x[1], d2 = x[2], d3 = x[3];
+    asm("v_dot2c_f32_bf16 %0, %4, %6\n\tv_dot2c_f32_bf16 %1, %5, %6\n\tv_dot2c_f32_bf16 %2, %4, %7\n\tv_dot2c_f32_bf16 %3, %5, %7\n\ts_nop 2"
+        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+        : "s"(0x0000bf80u), "s"(0xbf800000u), "v"(h0), "v"(h1));
+    const f32x2v e01 = {d0, d1}, e23 = {d2, d3};
+    const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_convertvector(e01, bf16x2v));
+    const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_convertvector(e23, bf16x2v));
     const u32x2v h = {h0, h1}, l = {l0, l1};
     hi = __builtin_bit_cast(bf16x4, h);
     lo = __builtin_bit_cast(bf16x4, l);
@@ -252,6 +263,345 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant (round 3).  What held the kernel above at 5.5-6.3 TB/s of L2 -> CU traffic was not the feed
+// (tools/micro/l2bw.hip: 30 TB/s of L2 hits, 6.3-7.0 TB/s from HBM with the same 16-byte loads) but its prefetch distance:
+// a k-tile's loads are issued one MFMA phase (~1 us) before the conversion that needs them, while a loaded HBM round trip is
+// 1.5-3 us -- every iteration stalled on them (3.9 us per 256x128x32 step for 0.77 us of MFMAs).
+//
+// One workgroup of EIGHT waves per CU, tile 256 x 128 x 32:
+//   * waves 4-7, the PRODUCERS: global loads D k-tiles ahead into D register sets (16-byte loads, 48 KB per set and
+//     workgroup -> up to D x 48 KB in flight per CU), fp32 -> (hi, lo) bf16 split, ds_write into the LDS stage the consumers
+//     will read NEXT step;
+//   * waves 0-3, the CONSUMERS: ds_read_b128 fragments + 48 v_mfma_f32_32x32x16_bf16 per step and wave (a 128 x 64 sub-tile, 128
+//     accumulator registers), epilogue stores at a tile's end.
+//   One LDS-only barrier per step (raw s_barrier: __syncthreads() would drain vmcnt, i.e. the producers' prefetches); the
+//   two LDS stages alternate.  Each SIMD carries one consumer and one producer wave, so the conversions' VALU work and the
+//   loads' address arithmetic fill issue slots beside the other wave's MFMAs instead of in front of them.
+constexpr int WS_BM = 256, WS_NT = 512;
+constexpr int WS_PLANE_A = WS_BM * LDK, WS_PLANE_B = BN * LDK;
+constexpr int WS_STAGE = 2 * (WS_PLANE_A + WS_PLANE_B);               // bf16 elements per stage: Ah, Al, Bh, Bl
+constexpr size_t WS_LDS_BYTES = (size_t)2 * WS_STAGE * sizeof(__bf16);    // 122,880 B
+
+__device__ __forceinline__ void ws_bar() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+struct WsWalk {
+    int tile, hi, slots, gx, gy, kchunk, K, seqT;
+    int m0, n0, kbeg, kend, bz, k0, t0;      // t0 = k0 % seqT (position inside the sequence, for the row-shifted operand)
+    bool valid;
+    __device__ __forceinline__ void coords() {
+        const int bx = tile % gx, by = (tile / gx) % gy; bz = tile / (gx * gy);
+        m0 = by * WS_BM; n0 = bx * BN; kbeg = bz * kchunk; kend = min(K, kbeg + kchunk); k0 = kbeg;
+        t0 = seqT > 0 ? kbeg % seqT : 0;
+    }
+    __device__ __forceinline__ void init(const GemmP& p, int first, int hi_, int slots_) {
+        tile = first; hi = hi_; slots = slots_; gx = p.gx; gy = p.gy; kchunk = p.kchunk; K = p.K; seqT = p.seqT;
+        valid = tile < hi;
+        if (valid) coords(); else { m0 = n0 = kbeg = kend = bz = k0 = t0 = 0; }
+    }
+    __device__ __forceinline__ bool last_k() const { return k0 + BK >= kend; }
+    __device__ __forceinline__ void advance() {
+        k0 += BK;
+        if (seqT > 0) { t0 += BK; while (t0 >= seqT) t0 -= seqT; }
+        if (k0 >= kend) { tile += slots; valid = tile < hi; if (valid) coords(); }
+    }
+};
+
+// Producer-side tile movers.  The loads are UNCONDITIONAL (addresses clamped into the operand, nothing predicated): a
+// predicated load compiles to a branch plus a copy of the loaded value into the rotating register set, i.e. an
+// s_waitcnt vmcnt(0) behind every single load (seen in the first version of this kernel).  Elements outside the tile's
+// valid range are zeroed when the set is converted, from the coordinates remembered with the set.
+struct WsTag { int mn0a, mn0b, k0, kend; bool fast; };
+
+template <bool TR, bool VEC, int ROWS>
+__device__ __forceinline__ void ws_load(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int Ktot, int tid,
+                                        float (&r)[ROWS / 32][4], int shift) {
+    const int a = tid & 7, bq = tid >> 3;
+    if (!TR) {
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int mn = min(mn0 + bq + 32 * i, MN - 1);
+            if (VEC) {
+                const int k = min(k0 + a * 4, Ktot - 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)mn * ld + k);
+                r[i][0] = v[0]; r[i][1] = v[1]; r[i][2] = v[2]; r[i][3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i][e] = P[(size_t)mn * ld + min(k0 + a * 4 + e, Ktot - 1)];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < ROWS / 128; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = min(max(k0 + a * 4 + i + shift, 0), Ktot - 1);
+                float (&rr)[4] = r[jj * 4 + i];
+                if (VEC) {
+                    const int mn = min(mn0 + (bq + 32 * jj) * 4, MN - 4);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + mn);
+                    rr[0] = v[0]; rr[1] = v[1]; rr[2] = v[2]; rr[3] = v[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rr[e] = P[(size_t)k * ld + min(mn0 + (bq + 32 * jj) * 4 + e, MN - 1)];
+                }
+            }
+    }
+}
+
+// zero what lies outside [mn0, MN) x [k0, kend) (and, for the row-shifted operand, outside its sequence), then split + store
+template <bool TR, int ROWS>
+__device__ __forceinline__ void ws_store(__bf16* Sh, __bf16* Sl, int tid, float (&r)[ROWS / 32][4], int mn0, int MN, int k0,
+                                         int kend, int seqT, int shift) {
+    const int a = tid & 7, bq = tid >> 3;
+    if (!TR) {
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const bool okr = mn0 + bq + 32 * i < MN;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(okr && k0 + a * 4 + e < kend)) r[i][e] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < ROWS / 128; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + a * 4 + i;
+                bool ok = k < kend;
+                if (seqT > 0) { const int tt = k % seqT + shift; ok = ok && tt >= 0 && tt < seqT; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (!(ok && mn0 + (bq + 32 * jj) * 4 + e < MN)) r[jj * 4 + i][e] = 0.f;
+            }
+    }
+    store_tile<TR, ROWS>(Sh, Sl, tid, r);
+}
+
+template <bool TA, bool TB, bool VEC, int D>
+__global__ __launch_bounds__(WS_NT, 1) void gemm_bf16x3_ws(GemmP p) {
+    constexpr bool A_TR = TA, B_TR = !TB;
+    extern __shared__ __attribute__((aligned(16))) __bf16 ws_smem[];
+
+    const int ntiles = p.gx * p.gy * p.splits;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int q = ntiles / 8, r = ntiles % 8;
+    const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int hi = lo + (xcd < r ? q + 1 : q);
+    if (lo + slot >= hi) return;
+    // number of (tile, k-tile) steps of this workgroup: identical in both roles (they meet at one barrier per step);
+    // rounded up to a multiple of D so that the producers' loop over the rotating register sets has no partial round
+    int G = 0;
+    for (int t = lo + slot; t < hi; t += slots) {
+        const int bz = t / (p.gx * p.gy), kb = bz * p.kchunk, ke = min(p.K, kb + p.kchunk);
+        G += (ke - kb + BK - 1) / BK;
+    }
+    const int Gr = (G + D - 1) / D * D;
+
+    if (threadIdx.x >= 256) {
+        // ------------------------------------------------------------------ producers
+        const int tid = threadIdx.x - 256;
+        WsWalk wl; wl.init(p, lo + slot, hi, slots);
+        float ra[D][WS_BM / 32][4], rb[D][BN / 32][4];
+        WsTag tag[D];
+        // per-thread byte offsets inside an operand tile: loop invariants, so an interior step's loads are
+        // global_load_dwordx4 v, v_off, s[base] with a scalar base that moves per step -- no VALU per load
+        const int la = tid & 7, lbq = tid >> 3;
+        unsigned offA[WS_BM / 32], offB[BN / 32];
+#pragma unroll
+        for (int i = 0; i < WS_BM / 32; ++i)
+            offA[i] = A_TR ? (unsigned)(((la * 4 + (i & 3)) * p.lda + (lbq + 32 * (i >> 2)) * 4) * 4)
+                           : (unsigned)(((lbq + 32 * i) * p.lda + la * 4) * 4);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i)
+            offB[i] = B_TR ? (unsigned)(((la * 4 + (i & 3)) * p.ldb + (lbq + 32 * (i >> 2)) * 4) * 4)
+                           : (unsigned)(((lbq + 32 * i) * p.ldb + la * 4) * 4);
+        typedef const char __attribute__((address_space(1)))* gcp;          // global address space: global_load, not flat_load
+        typedef const f32x4 __attribute__((address_space(1)))* gv4p;
+        auto sgpr_ptr = [](const char* q) {          // pin a uniform pointer into SGPRs: the loads below then take the saddr form
+            const unsigned long long u = reinterpret_cast<unsigned long long>(q);
+            const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)u), h = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            return (gcp)(((unsigned long long)h << 32) | l);
+        };
+        auto issue = [&](auto SET) {
+            constexpr int S = decltype(SET)::value;
+            // interior step: whole tile inside the operands, a full k-tile, no sequence boundary of the row-shifted operand
+            bool fast = VEC && wl.valid && wl.m0 + WS_BM <= p.M && wl.n0 + BN <= p.N && wl.k0 + BK <= wl.kend;
+            if (p.seqT > 0) fast = fast && wl.t0 + min(p.shiftB, 0) >= 0 && wl.t0 + BK - 1 + max(p.shiftB, 0) < p.seqT;
+            // past the last step the walker stays on its last coordinates: the loads stay valid, nobody consumes them
+            tag[S] = WsTag{wl.m0, wl.n0, wl.k0, wl.valid ? wl.kend : 0, fast};
+            if constexpr (VEC) {
+                // ONE load stream for both kinds of step (scalar base + 32-bit lane offset); only the offsets differ.  Two
+                // separate streams would meet in copies of the loaded registers, i.e. in waits for the loads just issued.
+                const char* ba; const char* bb;
+                unsigned va[WS_BM / 32], vb[BN / 32];
+                if (fast) {
+                    ba = reinterpret_cast<const char*>(p.A) + (A_TR ? ((size_t)wl.k0 * p.lda + wl.m0) : ((size_t)wl.m0 * p.lda + wl.k0)) * 4;
+                    bb = reinterpret_cast<const char*>(p.B) + (B_TR ? ((size_t)(wl.k0 + p.shiftB) * p.ldb + wl.n0) : ((size_t)wl.n0 * p.ldb + wl.k0)) * 4;
+#pragma unroll
+                    for (int i = 0; i < WS_BM / 32; ++i) va[i] = offA[i];
+#pragma unroll
+                    for (int i = 0; i < BN / 32; ++i) vb[i] = offB[i];
+                } else {
+                    ba = reinterpret_cast<const char*>(p.A); bb = reinterpret_cast<const char*>(p.B);
+#pragma unroll
+                    for (int i = 0; i < WS_BM / 32; ++i) {
+                        if (A_TR) {
+                            const int k = min(max(wl.k0 + la * 4 + (i & 3), 0), p.K - 1), mn = min(wl.m0 + (lbq + 32 * (i >> 2)) * 4, p.M - 4);
+                            va[i] = (unsigned)(k * p.lda + mn) * 4u;
+                        } else {
+                            const int mn = min(wl.m0 + lbq + 32 * i, p.M - 1), k = min(wl.k0 + la * 4, p.K - 4);
+                            va[i] = (unsigned)(mn * p.lda + k) * 4u;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < BN / 32; ++i) {
+                        if (B_TR) {
+                            const int k = min(max(wl.k0 + la * 4 + (i & 3) + p.shiftB, 0), p.K - 1), mn = min(wl.n0 + (lbq + 32 * (i >> 2)) * 4, p.N - 4);
+                            vb[i] = (unsigned)(k * p.ldb + mn) * 4u;
+                        } else {
+                            const int mn = min(wl.n0 + lbq + 32 * i, p.N - 1), k = min(wl.k0 + la * 4, p.K - 4);
+                            vb[i] = (unsigned)(mn * p.ldb + k) * 4u;
+                        }
+                    }
+                }
+                const gcp ga = sgpr_ptr(ba), gb = sgpr_ptr(bb);
+#pragma unroll
+                for (int i = 0; i < WS_BM / 32; ++i) {
+                    const f32x4 v = *(gv4p)(ga + va[i]);
+                    ra[S][i][0] = v[0]; ra[S][i][1] = v[1]; ra[S][i][2] = v[2]; ra[S][i][3] = v[3];
+                }
+#pragma unroll
+                for (int i = 0; i < BN / 32; ++i) {
+                    const f32x4 v = *(gv4p)(gb + vb[i]);
+                    rb[S][i][0] = v[0]; rb[S][i][1] = v[1]; rb[S][i][2] = v[2]; rb[S][i][3] = v[3];
+                }
+            } else {
+                ws_load<A_TR, false, WS_BM>(p.A, p.lda, wl.m0, p.M, wl.k0, p.K, tid, ra[S], 0);
+                ws_load<B_TR, false, BN>(p.B, p.ldb, wl.n0, p.N, wl.k0, p.K, tid, rb[S], p.shiftB);
+            }
+            if (wl.valid) wl.advance();
+        };
+        auto stage_out = [&](auto SET, int stage) {
+            constexpr int S = decltype(SET)::value;
+            __bf16* base = ws_smem + stage * WS_STAGE;
+            if (tag[S].fast) {
+                store_tile<A_TR, WS_BM>(base, base + WS_PLANE_A, tid, ra[S]);
+                store_tile<B_TR, BN>(base + 2 * WS_PLANE_A, base + 2 * WS_PLANE_A + WS_PLANE_B, tid, rb[S]);
+            } else {
+                ws_store<A_TR, WS_BM>(base, base + WS_PLANE_A, tid, ra[S], tag[S].mn0a, p.M, tag[S].k0, tag[S].kend, 0, 0);
+                ws_store<B_TR, BN>(base + 2 * WS_PLANE_A, base + 2 * WS_PLANE_A + WS_PLANE_B, tid, rb[S], tag[S].mn0b, p.N,
+                                   tag[S].k0, tag[S].kend, p.seqT, p.shiftB);
+            }
+        };
+#define WS_ISSUE(S) issue(std::integral_constant<int, S>{})
+        WS_ISSUE(0);
+        if constexpr (D > 1) WS_ISSUE(1);
+        if constexpr (D > 2) WS_ISSUE(2);
+        if constexpr (D > 3) WS_ISSUE(3);                        // steps 0 .. D-1 in flight
+        stage_out(std::integral_constant<int, 0>{}, 0);          // step 0 -> stage 0
+        WS_ISSUE(0);                                             // step D
+        ws_bar();
+        // step g: the consumers multiply stage g & 1; convert step g+1 (register set (g+1) % D) into the other stage and
+        // refill that set with step g+1+D.  (The last step converts a set nobody reads: cheaper than a conditional that
+        // would make hipcc drain the load queue at the loop head.)
+#define WS_STEP(S, GG) { if (!(p.ablate & 8)) stage_out(std::integral_constant<int, S>{}, ((GG) + 1) & 1); if (!(p.ablate & 4)) WS_ISSUE(S); ws_bar(); }
+        for (int g = 0; g < Gr; g += D) {
+            if constexpr (D == 1) { WS_STEP(0, g) }
+            if constexpr (D == 2) { WS_STEP(1, g) WS_STEP(0, g + 1) }
+            if constexpr (D == 3) { WS_STEP(1, g) WS_STEP(2, g + 1) WS_STEP(0, g + 2) }
+            if constexpr (D == 4) { WS_STEP(1, g) WS_STEP(2, g + 1) WS_STEP(3, g + 2) WS_STEP(0, g + 3) }
+        }
+#undef WS_STEP
+#undef WS_ISSUE
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    constexpr int MI = WS_BM / 64;
+    WsWalk wc; wc.init(p, lo + slot, hi, slots);
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    ws_bar();                                                    // stage 0 is ready
+    for (int g = 0; g < Gr; ++g) {
+        if (g >= G) { ws_bar(); continue; }                      // padding steps of the producers' last round
+        const __bf16* Ah = ws_smem + (g & 1) * WS_STAGE; const __bf16* Al = Ah + WS_PLANE_A;
+        const __bf16* Bh = Ah + 2 * WS_PLANE_A; const __bf16* Bl = Bh + WS_PLANE_B;
+        if (!(p.ablate & 2))
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int ko = s * 16 + half * 8;
+            bf16x8 ah[MI], al[MI], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int ro = (wm * (WS_BM / 2) + i * 32 + l31) * LDK + ko;
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro); al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ro = (wn * 64 + j * 32 + l31) * LDK + ko;
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro); bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                }
+        }
+        const bool fin = wc.last_k();
+        const int m0 = wc.m0, n0 = wc.n0, bz = wc.bz;
+        wc.advance();
+        ws_bar();                                                // the producers go on with the next stage while a finished tile is stored
+        if (fin) {
+            const bool split = p.part != nullptr;
+            float* outp = split ? p.part + (size_t)bz * p.M * p.N : p.C;
+            const int ldo = split ? p.N : p.ldc;
+            const bool v4 = ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0);
+            const bool addb = !split && p.bias;
+            const bool rmw = !split && p.beta != 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * (WS_BM / 2) + i * 32 + l31;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int n = n0 + wn * 64 + j * 32 + 8 * gq + 4 * half;
+                        f32x4 v = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+                        acc[i][j][4 * gq] = 0.f; acc[i][j][4 * gq + 1] = 0.f; acc[i][j][4 * gq + 2] = 0.f; acc[i][j][4 * gq + 3] = 0.f;
+                        if (m >= p.M || n >= p.N) continue;
+                        float* dst = outp + (size_t)m * ldo + n;
+                        if (v4 && n + 3 < p.N) {
+                            if (addb) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                            if (rmw) v += p.beta * *reinterpret_cast<const f32x4*>(dst);
+                            *reinterpret_cast<f32x4*>(dst) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < p.N) {
+                                    float x = v[e] + (addb ? p.bias[n + e] : 0.f);
+                                    if (rmw) x += p.beta * dst[e];
+                                    dst[e] = x;
+                                }
+                        }
+                    }
+            }
+        }
+    }
+}
+
 __global__ void splitk_reduce2(const float* __restrict__ part, int splits, int M, int N, float* C, int ldc,
                                const float* bias, float beta) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -279,7 +629,41 @@ __global__ void splitk_reduce2(const float* __restrict__ part, int splits, int M
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
                            int splits, int kchunk, float* part, bool vec, hipStream_t s) {
-    static int abl = -1, persist = -1, bm256 = -1;
+    static int abl = -1, persist = -1, bm256 = -1, wsd = -2;
+    if (abl < 0) { const char* e = getenv("DEP_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (wsd == -2) { const char* e = getenv("DEP_GEMM_WS"); wsd = e ? atoi(e) : 0; if (wsd < 0 || wsd > 4) wsd = 0; }
+    // (32-bit lane offsets: every operand must span less than 4 GB)
+    const size_t spanA = (size_t)(transA ? K : M) * lda * 4, spanB = (size_t)(transB ? N : K) * ldb * 4;
+    if (wsd > 0 && M >= 256 && spanA < (1ull << 32) && spanB < (1ull << 32)) {
+        // wave-specialised kernel: one 8-wave workgroup per CU, 256 x 128 tiles, `wsd` register sets of prefetch
+        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl};
+        const int ntiles = p.gx * p.gy * splits;
+        int ncu = 256;
+        { static int cus = -1; if (cus < 0) { hipDeviceProp_t pr; int dv = 0; cus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; } ncu = cus / 8 * 8; if (ncu < 8) ncu = 8; }
+        dim3 g(ntiles < ncu ? (ntiles + 7) / 8 * 8 : ncu);
+        static bool attr = false;
+#define WS_ATTR1(TA, TB, V, DD) (void)hipFuncSetAttribute((const void*)gemm_bf16x3_ws<TA, TB, V, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES)
+#define WS_ATTR(DD) WS_ATTR1(false, true, true, DD); WS_ATTR1(false, true, false, DD); WS_ATTR1(false, false, true, DD); \
+                    WS_ATTR1(false, false, false, DD); WS_ATTR1(true, false, true, DD); WS_ATTR1(true, false, false, DD)
+        if (!attr) { WS_ATTR(2); WS_ATTR(3); WS_ATTR(4); attr = true; }
+#undef WS_ATTR
+#undef WS_ATTR1
+#define WS_L1(TA, TB, DD) do { if (vec) hipLaunchKernelGGL((gemm_bf16x3_ws<TA, TB, true, DD>), g, dim3(WS_NT), WS_LDS_BYTES, s, p); \
+                               else     hipLaunchKernelGGL((gemm_bf16x3_ws<TA, TB, false, DD>), g, dim3(WS_NT), WS_LDS_BYTES, s, p); } while (0)
+#define WS_L(TA, TB) do { if (wsd == 2) WS_L1(TA, TB, 2); else if (wsd == 4) WS_L1(TA, TB, 4); else WS_L1(TA, TB, 3); } while (0)
+        if (!transA && transB) WS_L(false, true);
+        else if (!transA && !transB) WS_L(false, false);
+        else WS_L(true, false);
+#undef WS_L
+#undef WS_L1
+        DEP_CHECK_LAUNCH();
+        if (splits > 1) {
+            const long n = (long)M * N;
+            hipLaunchKernelGGL(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, part, splits, M, N, C, ldc, bias, beta);
+            DEP_CHECK_LAUNCH();
+        }
+        return DEP_OK;
+    }
     if (abl < 0) { const char* e = getenv("DEP_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
     if (persist < 0) { const char* e = getenv("DEP_GEMM_PERSIST"); persist = e ? atoi(e) : 768; if (persist < 8) persist = 8; persist = persist / 8 * 8; }
     if (bm256 < 0) { const char* e = getenv("DEP_GEMM_BM"); bm256 = (e && atoi(e) == 128) ? 0 : 1; }

@@ -1,0 +1,65 @@
+// What does the chip sustain on v_mfma_f32_32x32x16_bf16 when every SIMD issues them back to back?  (are the
+// split-precision GEMMs bound by the schedule or by the package power?)  Pure register loop, no LDS, no memory:
+//   waves per SIMD 1 / 2, independent accumulators 2 / 4 / 8, operand data zeros / random bits.
+// Prints wall time (events), shader cycles of wave 0 (s_memtime), effective clock, TFLOP/s.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NACC>
+__global__ __launch_bounds__(512) void mfma_loop(const unsigned* seed, int iters, float* out, long long* cyc) {
+    unsigned s0 = seed[threadIdx.x & 63], s1 = seed[64 + (threadIdx.x & 63)];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 ua = {s0, s1, s0 * 3u, s1 * 5u}, ub = {s1, s0 * 7u, s1 * 11u, s0};
+    // keep exponents sane: clear the top exponent bits of every bf16 half (|x| < 2)
+    for (int i = 0; i < 4; ++i) { ua[i] &= 0xbfffbfffu; ub[i] &= 0xbfffbfffu; }
+    bf16x8 a = __builtin_bit_cast(bf16x8, ua), b = __builtin_bit_cast(bf16x8, ub);
+    f32x16 acc[NACC];
+    for (int n = 0; n < NACC; ++n) for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[n], 0, 0, 0);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int n = 0; n < NACC; ++n) s += acc[n][0];
+    if (s == 1.2345e30f) out[threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int NACC>
+static void run(int waves_per_simd, bool random, int cus) {
+    unsigned h[128];
+    for (int i = 0; i < 128; ++i) h[i] = random ? (unsigned)rand() * 2654435761u + (unsigned)rand() : 0u;
+    unsigned* d; float* out; long long* cyc;
+    hipMalloc(&d, sizeof(h)); hipMalloc(&out, 4096); hipMalloc(&cyc, 8);
+    hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
+    const int threads = 256 * waves_per_simd, iters = 20000;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(a, 0);
+        hipLaunchKernelGGL(mfma_loop<NACC>, dim3(cus), dim3(threads), 0, 0, d, iters, out, cyc);
+        hipEventRecord(b, 0); hipEventSynchronize(b);
+    }
+    float ms; hipEventElapsedTime(&ms, a, b);
+    long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    const double nm = (double)cus * 4 * waves_per_simd * iters * NACC;      // MFMAs
+    printf("acc %d  waves/SIMD %d  data %-6s: %8.3f ms  wave0 %lld cyc (%.1f cyc per MFMA and SIMD)  clock %.2f GHz  %7.1f TFLOP/s\n", NACC,
+           waves_per_simd, random ? "random" : "zeros", ms, c, (double)c / ((double)iters * NACC * waves_per_simd), c / ms / 1e6,
+           nm * 32768.0 / ms / 1e9);
+    hipFree(d); hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
+    const int cus = pr.multiProcessorCount;
+    printf("%s, %d CUs\n", pr.name, cus);
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        run<2>(1, rnd, cus); run<4>(1, rnd, cus); run<8>(1, rnd, cus);
+        run<4>(2, rnd, cus); run<8>(2, rnd, cus);
+    }
+    return 0;
+}
