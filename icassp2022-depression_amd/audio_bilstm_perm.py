@@ -125,6 +125,22 @@ def evaluate(fold, model, train_mae):
     return total_loss
 
 
+def fold_split(fold):
+    """Fold `fold`'s index lists (reference lines 216-240), left in the module globals train() / evaluate() read: test =
+    dep_idxs[10 fold : 10 fold + 10] + non_idxs[44 fold : 44 fold + 44]; the first 14 depressed training volunteers (in
+    list(set(...)) order, as the reference iterates them) are replaced by all 6 time-axis permutations with their own score."""
+    global audio_features, audio_targets, train_dep_idxs, train_non_idxs, test_dep_idxs, test_non_idxs
+    test_dep_idxs_tmp = dep_idxs[fold * 10:(fold + 1) * 10]
+    test_non_idxs = non_idxs[fold * 44:(fold + 1) * 44]
+    train_dep_idxs_tmp = list(set(dep_idxs) - set(test_dep_idxs_tmp))
+    train_non_idxs = list(set(non_idxs) - set(test_non_idxs))
+    first14 = set(train_dep_idxs_tmp[:14])
+    audio_features, audio_targets, train_dep_idxs = _common.permutation_augment(
+        audio_features, audio_targets, train_dep_idxs_tmp, lambda i: i in first14, (0, 1, 2, 3, 4, 5))
+    test_dep_idxs = test_dep_idxs_tmp
+    return train_dep_idxs, train_non_idxs, test_dep_idxs, test_non_idxs
+
+
 def main(epochs=None):
     """3-fold driver (reference lines 215-260): 10 dep / 44 non test volunteers per fold; the first 14 depressed
     training volunteers are expanded to all 6 time-axis permutations."""
@@ -134,14 +150,7 @@ def main(epochs=None):
     if audio_features is None:
         load_features()
     for fold in range(3):
-        test_dep_idxs_tmp = dep_idxs[fold * 10:(fold + 1) * 10]
-        test_non_idxs = non_idxs[fold * 44:(fold + 1) * 44]
-        train_dep_idxs_tmp = list(set(dep_idxs) - set(test_dep_idxs_tmp))
-        train_non_idxs = list(set(non_idxs) - set(test_non_idxs))
-        first14 = set(train_dep_idxs_tmp[:14])
-        audio_features, audio_targets, train_dep_idxs = _common.permutation_augment(
-            audio_features, audio_targets, train_dep_idxs_tmp, lambda i: i in first14, (0, 1, 2, 3, 4, 5))
-        test_dep_idxs = test_dep_idxs_tmp
+        fold_split(fold)
         model = AudioBiLSTM(config)
         parallel.broadcast_params(model)
         optimizer = nn.Adam(model.parameters(), lr=config['learning_rate'])

@@ -137,6 +137,21 @@ def get_param_group(model):
     return [{'params': param_list, 'weight_decay': 1e-5}, {'params': nd_list, 'weight_decay': 0}]
 
 
+def fold_split(train_idxs_tmp):
+    """One fold's index lists (reference lines 268-299): the test volunteers are everyone outside `train_idxs_tmp`; every
+    depressed TRAINING volunteer is replaced by all 6 time-axis permutations, every depressed TEST volunteer by permutations
+    0, 1, 4, 5, appended to the module's feature / label arrays (which therefore grow from fold to fold).  Returns
+    (train_idxs, test_idxs).  Pinned to the reference's own loop statements by tests/golden/fold_bodies.npz."""
+    global audio_features, audio_targets
+    dep = set(audio_dep_idxs_tmp.tolist())
+    test_idxs_tmp = list(set(list(audio_dep_idxs_tmp) + list(audio_non_idxs)) - set(train_idxs_tmp))
+    audio_features, audio_targets, train_idxs = _common.permutation_augment(
+        audio_features, audio_targets, train_idxs_tmp, lambda i: i in dep, (0, 1, 2, 3, 4, 5), label=1)
+    audio_features, audio_targets, test_idxs = _common.permutation_augment(
+        audio_features, audio_targets, test_idxs_tmp, lambda i: i in dep, (0, 1, 4, 5), label=1)
+    return train_idxs, test_idxs
+
+
 def main(fold_files=('train_idxs_0.63_1.npy', 'train_idxs_0.60_2.npy', 'train_idxs_0.60_3.npy'), epochs=None):
     """The 3-fold driver (reference lines 257-319): permutation augmentation of the depressed class
     (train: all 6 orders, test: orders 0,1,4,5), fresh model + AdamW + CE per fold, epochs-1 epochs."""
@@ -147,12 +162,7 @@ def main(fold_files=('train_idxs_0.63_1.npy', 'train_idxs_0.60_2.npy', 'train_id
         load_features()
     folds = [np.load(os.path.join(prefix, 'Features/TextWhole', f), allow_pickle=True) for f in fold_files]
     for fold, train_idxs_tmp in enumerate(folds, start=1):
-        dep = set(audio_dep_idxs_tmp.tolist())
-        test_idxs_tmp = list(set(list(audio_dep_idxs_tmp) + list(audio_non_idxs)) - set(train_idxs_tmp))
-        audio_features, audio_targets, train_idxs = _common.permutation_augment(
-            audio_features, audio_targets, train_idxs_tmp, lambda i: i in dep, (0, 1, 2, 3, 4, 5), label=1)
-        audio_features, audio_targets, test_idxs = _common.permutation_augment(
-            audio_features, audio_targets, test_idxs_tmp, lambda i: i in dep, (0, 1, 4, 5), label=1)
+        train_idxs, test_idxs = fold_split(train_idxs_tmp)
         model = AudioBiLSTM(config)
         parallel.broadcast_params(model)
         optimizer = nn.AdamW(get_param_group(model), lr=config['learning_rate'])

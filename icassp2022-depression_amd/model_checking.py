@@ -1,8 +1,18 @@
-"""Post-hoc evaluators: the reference's `*ModelChecking.py` scripts reload saved checkpoints,
-rebuild the folds (with the test-side permutation augmentation) and print precision / recall / F1 averaged over the
-three folds (Classification/AudioModelChecking.py:127-208, TextModelChecking.py:266-395, FuseModelChecking.py:22-105)
-or MAE / RMSE (Regression/AudioModelChecking.py:129-208).  Same flow here on the HIP-backed modules; checkpoints may
-be this package's `{state_dict, ...}` files or reference-made pickles of a whole torch module."""
+"""Post-hoc evaluators: the reference's `*ModelChecking.py` scripts reload saved checkpoints, rebuild the
+folds (train- and test-side permutation augmentation) and print precision / recall / F1 per fold and averaged
+(Classification/AudioModelChecking.py:127-208, TextModelChecking.py:266-395, FuseModelChecking.py:22-105) or MAE / RMSE
+(Regression/AudioModelChecking.py:129-208).  Same flow, same prints, same index lists here on the HIP-backed modules -- pinned
+to fixtures the reference's own `evaluate` functions and fold-loop statements produced (tests/golden/checker_*.npz).
+
+Checkpoints may be this package's `{state_dict, ...}` files or reference-made pickles of a whole torch module.
+
+Reference quirks that are results-visible and therefore kept:
+  * every checker ALSO appends the training-side permutations (6 per depressed training volunteer), although it evaluates only
+    the test rows: the appended rows decide the row numbers of the test-side permutations;
+  * TextModelChecking.py keeps `resample_idxs` in a module global that the first fold's test loop leaves at [0, 1, 4, 5]
+    (line 340): from the second fold on only 4 permutations per depressed TRAINING volunteer are appended;
+  * evaluation is mini-batched (config['batch_size']) in the three classification checkers, full-batch in the regression one.
+"""
 import os
 
 import numpy as np
@@ -17,8 +27,18 @@ def _load_into(model, path, strict=True):
     return model
 
 
+def _report(conf_matrix):
+    """The metric block every classification checker prints after model_performance (AudioModelChecking.py:150-160)."""
+    print('Calculating additional test metrics...')
+    accuracy, precision, recall, f1_score = _common.prf(conf_matrix)
+    print("Accuracy: {}".format(accuracy)); print("Precision: {}".format(precision))
+    print("Recall: {}".format(recall)); print("F1-Score: {}\n".format(f1_score)); print('=' * 89)
+    return precision, recall, f1_score
+
+
 def evaluate_classifier(model, features, targets, test_idxs, batch_size):
-    """Mini-batched evaluation -> (precision, recall, f1) as AudioModelChecking.evaluate (lines 127-161)."""
+    """Mini-batched evaluation -> (precision, recall, f1): AudioModelChecking.evaluate (127-161) / TextModelChecking.evaluate
+    (266-306)."""
     model.eval()
     X_test = features[test_idxs]; Y_test = targets[test_idxs]
     preds = []
@@ -28,21 +48,60 @@ def evaluate_classifier(model, features, targets, test_idxs, batch_size):
     pred = torch.cat(preds).numpy()
     conf_matrix = _common.standard_confusion_matrix(Y_test, pred)
     print("Confusion Matrix:"); print(conf_matrix)
-    print('Calculating additional test metrics...')
-    accuracy, precision, recall, f1_score = _common.prf(conf_matrix)
-    print("Accuracy: {}".format(accuracy)); print("Precision: {}".format(precision))
-    print("Recall: {}".format(recall)); print("F1-Score: {}\n".format(f1_score)); print('=' * 89)
-    return precision, recall, f1_score
+    return _report(conf_matrix)
 
 
-def _folds_clf(features, targets, dep_idxs, non_idxs, train_idxs_tmp):
-    dep = set(np.asarray(dep_idxs).tolist())
-    test_idxs_tmp = list(set(list(dep_idxs) + list(non_idxs)) - set(train_idxs_tmp))
-    features, targets, _ = _common.permutation_augment(features, targets, train_idxs_tmp, lambda i: i in dep,
-                                                       (0, 1, 2, 3, 4, 5), label=1)
-    features, targets, test_idxs = _common.permutation_augment(features, targets, test_idxs_tmp, lambda i: i in dep,
-                                                               (0, 1, 4, 5), label=1)
-    return features, targets, test_idxs
+def evaluate_fusion(model, fuse_features, fuse_targets, test_idxs, batch_size):
+    """FuseModelChecking.evaluate (22-60): mini-batched pretrained_feature -> concat(text, audio) -> head -> argmax."""
+    model.eval()
+    X = [fuse_features[i] for i in test_idxs]; Y = [fuse_targets[i] for i in test_idxs]
+    preds = []
+    for lo, hi in _common.minibatches(len(X), batch_size):
+        tf, af = model.pretrained_feature(X[lo:hi])
+        preds.append(model(torch.cat((tf, af), dim=1)).data.max(1, keepdim=True)[1].cpu())
+    conf_matrix = _common.standard_confusion_matrix(np.asarray(Y), torch.cat(preds).numpy())
+    print("Confusion Matrix:"); print(conf_matrix)
+    return _report(conf_matrix)
+
+
+def _mean_report(ps, rs, fs):
+    print('precison: {} \n recall: {} \n f1 score: {}'.format(np.mean(ps), np.mean(rs), np.mean(fs)))
+    return float(np.mean(ps)), float(np.mean(rs)), float(np.mean(fs))
+
+
+def check_audio_folds(models, folds, batch_size):
+    """Fold loop of Classification/AudioModelChecking.py:170-208 on the features already held by audio_gru_whole: `models[k]`
+    is evaluated on fold k's test rows.  Returns ([p], [r], [f], [test_idxs])."""
+    m = audio_gru_whole
+    ps, rs, fs, tests = [], [], [], []
+    for k, train_idxs_tmp in enumerate(folds):
+        _, test_idxs = m.fold_split(train_idxs_tmp)
+        p, r, f = evaluate_classifier(models[k], m.audio_features, m.audio_targets, test_idxs, batch_size)
+        ps.append(p); rs.append(r); fs.append(f); tests.append(test_idxs)
+    return ps, rs, fs, tests
+
+
+def check_text_folds(models, folds, batch_size):
+    """Fold loop of Classification/TextModelChecking.py:316-394 (with its leaking `resample_idxs`, see the module docstring)."""
+    m = text_bilstm_whole
+    ps, rs, fs, tests = [], [], [], []
+    for k, train_idxs_tmp in enumerate(folds):
+        _, test_idxs = m.fold_split(train_idxs_tmp, train_keep=(0, 1, 2, 3, 4, 5) if k == 0 else (0, 1, 4, 5))
+        p, r, f = evaluate_classifier(models[k], m.text_features, m.text_targets, test_idxs, batch_size)
+        ps.append(p); rs.append(r); fs.append(f); tests.append(test_idxs)
+    return ps, rs, fs, tests
+
+
+def check_fusion_folds(models, folds, batch_size):
+    """Fold loop of Classification/FuseModelChecking.py:63-104 on fuse_net_whole's pair list."""
+    m = fuse_net_whole
+    ps, rs, fs, tests = [], [], [], []
+    for k, train_idxs_tmp in enumerate(folds):
+        te_tmp = list(set(list(m.fuse_dep_idxs) + list(m.fuse_non_idxs)) - set(train_idxs_tmp))
+        _, test_idxs = m.augment_pairs(train_idxs_tmp, te_tmp)
+        p, r, f = evaluate_fusion(models[k], m.fuse_features, m.fuse_targets, test_idxs, batch_size)
+        ps.append(p); rs.append(r); fs.append(f); tests.append(test_idxs)
+    return ps, rs, fs, tests
 
 
 def check_audio_classifier(root, idxs_paths=('train_idxs_0.63_1.npy', 'train_idxs_0.65_2.npy', 'train_idxs_0.60_3.npy'),
@@ -51,33 +110,21 @@ def check_audio_classifier(root, idxs_paths=('train_idxs_0.63_1.npy', 'train_idx
     m = audio_gru_whole
     m.load_features(root)
     cfg = dict(m.config if config is None else config)
-    feats, targs = m.audio_features, m.audio_targets
-    ps, rs, fs = [], [], []
-    for fold in range(3):
-        tr = np.load(os.path.join(m.prefix, 'Features/TextWhole', idxs_paths[fold]), allow_pickle=True)
-        feats, targs, test_idxs = _folds_clf(feats, targs, m.audio_dep_idxs_tmp, m.audio_non_idxs, tr)
-        model = _load_into(m.AudioBiLSTM(cfg), os.path.join(m.prefix, 'Model/ClassificationWhole/Audio', model_paths[fold]))
-        p, r, f = evaluate_classifier(model, feats, targs, test_idxs, cfg['batch_size'])
-        ps.append(p); rs.append(r); fs.append(f)
-    print('precison: {} \n recall: {} \n f1 score: {}'.format(np.mean(ps), np.mean(rs), np.mean(fs)))
-    return float(np.mean(ps)), float(np.mean(rs)), float(np.mean(fs))
+    folds = [np.load(os.path.join(m.prefix, 'Features/TextWhole', f), allow_pickle=True) for f in idxs_paths]
+    models = [_load_into(m.AudioBiLSTM(cfg), os.path.join(m.prefix, 'Model/ClassificationWhole/Audio', f)) for f in model_paths]
+    ps, rs, fs, _ = check_audio_folds(models, folds, cfg['batch_size'])
+    return _mean_report(ps, rs, fs)
 
 
-def check_text_classifier(root, idxs_paths=('train_idxs_0.63_1.npy', 'train_idxs_0.65_2.npy', 'train_idxs_0.60_3.npy'),
-                          model_paths=('BiLSTM_128_0.64_1.pt', 'BiLSTM_128_0.66_2.pt', 'BiLSTM_128_0.62_3.pt'), config=None):
+def check_text_classifier(root, idxs_paths=('train_idxs_0.63_1.npy', 'train_idxs_0.60_2.npy', 'train_idxs_0.60_3.npy'),
+                          model_paths=('BiLSTM_128_0.64_1.pt', 'BiLSTM_128_0.66_2.pt', 'BiLSTM_128_0.66_3.pt'), config=None):
     m = text_bilstm_whole
     m.load_features(root)
     cfg = dict(m.config if config is None else config)
-    feats, targs = m.text_features, m.text_targets
-    ps, rs, fs = [], [], []
-    for fold in range(3):
-        tr = np.load(os.path.join(m.prefix, 'Features/TextWhole', idxs_paths[fold]), allow_pickle=True)
-        feats, targs, test_idxs = _folds_clf(feats, targs, m.text_dep_idxs_tmp, m.text_non_idxs, tr)
-        model = _load_into(m.TextBiLSTM(cfg), os.path.join(m.prefix, 'Model/ClassificationWhole/Text', model_paths[fold]))
-        p, r, f = evaluate_classifier(model, feats, targs, test_idxs, cfg['batch_size'])
-        ps.append(p); rs.append(r); fs.append(f)
-    print('precison: {} \n recall: {} \n f1 score: {}'.format(np.mean(ps), np.mean(rs), np.mean(fs)))
-    return float(np.mean(ps)), float(np.mean(rs)), float(np.mean(fs))
+    folds = [np.load(os.path.join(m.prefix, 'Features/TextWhole', f), allow_pickle=True) for f in idxs_paths]
+    models = [_load_into(m.TextBiLSTM(cfg), os.path.join(m.prefix, 'Model/ClassificationWhole/Text', f)) for f in model_paths]
+    ps, rs, fs, _ = check_text_folds(models, folds, cfg['batch_size'])
+    return _mean_report(ps, rs, fs)
 
 
 def check_fusion_classifier(root, idxs_paths=('train_idxs_0.63_1.npy', 'train_idxs_0.65_2.npy', 'train_idxs_0.60_3.npy'),
@@ -85,38 +132,29 @@ def check_fusion_classifier(root, idxs_paths=('train_idxs_0.63_1.npy', 'train_id
     """FuseModelChecking.py: mini-batched fusion evaluate over the three saved fusion checkpoints."""
     m = fuse_net_whole
     m.load_features(root)
-    m.build()
-    ps, rs, fs = [], [], []
-    for fold in range(3):
-        tr = np.load(os.path.join(m.prefix, 'Features/TextWhole', idxs_paths[fold]), allow_pickle=True)
-        te_tmp = list(set(list(m.fuse_dep_idxs) + list(m.fuse_non_idxs)) - set(tr))
-        _, test_idxs = m.augment_pairs([], te_tmp)
-        _load_into(m.model, os.path.join(m.prefix, 'Model/ClassificationWhole/Fuse', model_paths[fold]))
-        m.model.eval()
-        preds = []
-        X = [m.fuse_features[i] for i in test_idxs]; Y = [m.fuse_targets[i] for i in test_idxs]
-        for lo, hi in _common.minibatches(len(X), m.config['batch_size']):
-            tf, af = m.model.pretrained_feature(X[lo:hi])
-            preds.append(m.model(torch.cat((tf, af), dim=1)).data.max(1, keepdim=True)[1].cpu())
-        conf = _common.standard_confusion_matrix(np.asarray(Y), torch.cat(preds).numpy())
-        _, p, r, f = _common.prf(conf)
-        print(conf); print('precision {} recall {} f1 {}'.format(p, r, f))
-        ps.append(p); rs.append(r); fs.append(f)
-    print('precison: {} \n recall: {} \n f1 score: {}'.format(np.mean(ps), np.mean(rs), np.mean(fs)))
-    return float(np.mean(ps)), float(np.mean(rs)), float(np.mean(fs))
+    folds = [np.load(os.path.join(m.prefix, 'Features/TextWhole', f), allow_pickle=True) for f in idxs_paths]
+    c = m.config
+    models = [_load_into(m.fusion_net(c['text_embed_size'], c['text_hidden_dims'], c['rnn_layers'], c['dropout'], c['num_classes'],
+                                      c['audio_hidden_dims'], c['audio_embed_size']),
+                         os.path.join(m.prefix, 'Model/ClassificationWhole/Fuse', f)) for f in model_paths]
+    ps, rs, fs, _ = check_fusion_folds(models, folds, c['batch_size'])
+    return _mean_report(ps, rs, fs)
 
 
-def check_audio_regressor(root, model_path, fold=0, config=None):
-    """Regression/AudioModelChecking.py:129-208: strict load of one regression checkpoint, full-batch MAE / RMSE on
-    the fold's 10 depressed + 44 non-depressed test volunteers."""
+def check_audio_regressor(root, model_path, fold=2, config=None):
+    """Regression/AudioModelChecking.py:157-208: strict load of one regression checkpoint, the fold's split (training-side
+    permutations appended as the script does, unused by the evaluation), full-batch MAE / RMSE on the fold's 10 depressed + 44
+    other test volunteers (`fold = 2` is what the script hard-codes)."""
     m = audio_bilstm_perm
     m.load_features(root)
     cfg = dict(m.config if config is None else config)
     model = _load_into(m.AudioBiLSTM(cfg), os.path.join(m.prefix, model_path), strict=True)
-    idx = list(m.dep_idxs[fold * 10:(fold + 1) * 10]) + list(m.non_idxs[fold * 44:(fold + 1) * 44])
+    m.fold_split(fold)
+    idx = list(m.test_dep_idxs) + list(m.test_non_idxs)
     model.eval()
     pred = model(np.ascontiguousarray(m.audio_features[idx], dtype=np.float32)).data.flatten().cpu().numpy()
     y = np.asarray(m.audio_targets[idx], np.float64)
     mae = float(np.mean(np.abs(y - pred))); rmse = float(np.sqrt(np.mean((y - pred) ** 2)))
     print('MAE: {:.4f}\t RMSE: {:.4f}\n'.format(mae, rmse))
+    print('=' * 89)
     return mae, rmse

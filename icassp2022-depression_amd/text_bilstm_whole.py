@@ -130,6 +130,19 @@ def get_param_group(model):
     return [{'params': param_list, 'weight_decay': 1e-5}, {'params': nd_list, 'weight_decay': 0}]
 
 
+def fold_split(train_idxs_tmp, train_keep=(0, 1, 2, 3, 4, 5)):
+    """One fold's index lists (reference lines 263-292): as audio_gru_whole.fold_split, on the text arrays.  (`train_keep` is
+    for the checker, whose copy of this loop leaks the test-side selection into later folds: model_checking.py.)"""
+    global text_features, text_targets
+    dep = set(text_dep_idxs_tmp.tolist())
+    test_idxs_tmp = list(set(list(text_dep_idxs_tmp) + list(text_non_idxs)) - set(train_idxs_tmp))
+    text_features, text_targets, train_idxs = _common.permutation_augment(
+        text_features, text_targets, train_idxs_tmp, lambda i: i in dep, tuple(train_keep), label=1)
+    text_features, text_targets, test_idxs = _common.permutation_augment(
+        text_features, text_targets, test_idxs_tmp, lambda i: i in dep, (0, 1, 4, 5), label=1)
+    return train_idxs, test_idxs
+
+
 def main(fold_files=('train_idxs_0.63_1.npy', 'train_idxs_0.60_2.npy', 'train_idxs_0.60_3.npy'), epochs=None):
     """3-fold driver (reference lines 260-314)."""
     global model, optimizer, criterion, text_features, text_targets
@@ -139,12 +152,7 @@ def main(fold_files=('train_idxs_0.63_1.npy', 'train_idxs_0.60_2.npy', 'train_id
         load_features()
     folds = [np.load(os.path.join(prefix, 'Features/TextWhole', f), allow_pickle=True) for f in fold_files]
     for fold, train_idxs_tmp in enumerate(folds, start=1):
-        dep = set(text_dep_idxs_tmp.tolist())
-        test_idxs_tmp = list(set(list(text_dep_idxs_tmp) + list(text_non_idxs)) - set(train_idxs_tmp))
-        text_features, text_targets, train_idxs = _common.permutation_augment(
-            text_features, text_targets, train_idxs_tmp, lambda i: i in dep, (0, 1, 2, 3, 4, 5), label=1)
-        text_features, text_targets, test_idxs = _common.permutation_augment(
-            text_features, text_targets, test_idxs_tmp, lambda i: i in dep, (0, 1, 4, 5), label=1)
+        train_idxs, test_idxs = fold_split(train_idxs_tmp)
         model = TextBiLSTM(config)
         parallel.broadcast_params(model)
         optimizer = nn.AdamW(get_param_group(model), lr=config['learning_rate'])

@@ -66,13 +66,12 @@ def test_audio_classifier_fold_driver_and_checker(dataset):
         p_, r_, f_ = quiet(model_checking.check_audio_classifier, dataset['root'], dataset['folds'], tuple(paths), dict(m.config))
         # direct evaluation of the same weights on the same rebuilt folds must agree
         m.load_features(dataset['root'])
-        feats, targs = m.audio_features, m.audio_targets
         model = m.AudioBiLSTM(m.config); model.load_state_dict(ref_sd)
         ps = []
         for k in range(3):
             tr = np.load(os.path.join(dataset['root'], 'Features/TextWhole', dataset['folds'][k]), allow_pickle=True)
-            feats, targs, te = model_checking._folds_clf(feats, targs, m.audio_dep_idxs_tmp, m.audio_non_idxs, tr)
-            ps.append(quiet(model_checking.evaluate_classifier, model, feats, targs, te, m.config['batch_size'])[0])
+            _, te = m.fold_split(tr)
+            ps.append(quiet(model_checking.evaluate_classifier, model, m.audio_features, m.audio_targets, te, m.config['batch_size'])[0])
         assert np.allclose(np.nanmean(ps), p_, equal_nan=True)
     finally:
         m.config.clear(); m.config.update(saved)

@@ -234,11 +234,11 @@ def test_text_model_checker_equals_direct_evaluation(dataset):
     (p_, r_, f_), printed = capture(model_checking.check_text_classifier, dataset['root'], dataset['folds'], tuple(names), cfg)
     assert printed.count('Confusion Matrix:') == 3
     m.load_features(dataset['root'])
-    feats, targs = m.text_features, m.text_targets
     ps, rs = [], []
     for k in range(3):
         tr = np.load(os.path.join(dataset['root'], 'Features/TextWhole', dataset['folds'][k]), allow_pickle=True)
-        feats, targs, te = model_checking._folds_clf(feats, targs, m.text_dep_idxs_tmp, m.text_non_idxs, tr)
+        _, te = m.fold_split(tr, train_keep=(0, 1, 2, 3, 4, 5) if k == 0 else (0, 1, 4, 5))
+        feats, targs = m.text_features, m.text_targets
         model = m.TextBiLSTM(cfg, seed=0); model.load_state_dict(sds[k])
         model.eval()
         pred = model(np.ascontiguousarray(feats[te], dtype=np.float32)).data.max(1)[1].cpu().numpy()     # ONE full batch
@@ -270,7 +270,7 @@ def test_fusion_model_checker_equals_direct_evaluation(dataset):
         for k in range(3):
             tr = np.load(os.path.join(dataset['root'], 'Features/TextWhole', dataset['folds'][k]), allow_pickle=True)
             te_tmp = list(set(list(m.fuse_dep_idxs) + list(m.fuse_non_idxs)) - set(tr))
-            _, te = m.augment_pairs([], te_tmp)
+            _, te = m.augment_pairs(tr, te_tmp)
             fm = m.fusion_net(dataset['Ft'], 16, 2, 0.0, 2, 16, dataset['Fa'], seed=0); fm.load_state_dict(sds[k])
             fm.eval()
             tf, af = fm.pretrained_feature([m.fuse_features[i] for i in te])
