@@ -90,3 +90,115 @@ def test_native_rccl_comm_overlapped_backward_single_rank():
     parallel.destroy_native_comm()
     for name in ('audio', 'text'):
         assert torch.equal(grads[(name, False)], grads[(name, True)]), name
+
+
+# ------------------------------------------------------------------------------------------- the other train() loops
+def _run_generic(case, rank, world, port, q, dropout):
+    """One rank of `case`'s train() on the reference-made train/eval fixture of that script."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    sys.path.insert(0, ROOT)
+    import importlib
+    from icassp2022_depression_amd import nn, parallel
+    torch.manual_seed(2024)                   # the dropout keys derive from torch.initial_seed(), the step counter and the rank
+    if world > 1:
+        parallel.init_from_env('gloo')
+    out = {}
+    if case == 'text_clf':
+        m = importlib.import_module('icassp2022_depression_amd.text_bilstm_whole')
+        g = load_golden('text_clf_train_eval')
+        N, T, F, H = [int(v) for v in g['shape']]
+        m.config.update(embedding_size=F, hidden_dims=H, dropout=dropout, batch_size=5, learning_rate=float(g['lr']))
+        m.text_features = g['feats']; m.text_targets = g['targs']
+        m.model = m.TextBiLSTM(m.config, seed=0)
+        m.model.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()})
+        m.optimizer = nn.AdamW(m.get_param_group(m.model), lr=m.config['learning_rate']); m.criterion = nn.CrossEntropyLoss()
+        idx = list(range(12))                 # 5, 5, 2: world 3 leaves rank 2 an empty shard of the last mini-batch
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.train(1, idx); m.train(2, idx)
+        out = dict(acc=int(m.train_acc))
+        model = m.model
+    elif case == 'audio_reg':
+        m = importlib.import_module('icassp2022_depression_amd.audio_bilstm_perm')
+        g = load_golden('audio_reg_train_eval')
+        N, T, F, H = [int(v) for v in g['shape']]
+        m.config.update(embedding_size=F, hidden_dims=H, dropout=dropout, batch_size=5, learning_rate=float(g['lr']))
+        m.audio_features = g['feats']; m.audio_targets = g['targs']
+        m.model = m.AudioBiLSTM(m.config, seed=0)
+        m.model.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()})
+        m.optimizer = nn.Adam(m.model.parameters(), lr=m.config['learning_rate']); m.criterion = nn.L1Loss()
+        m.train_dep_idxs = [0, 1, 2, 3, 4]; m.train_non_idxs = [5, 6, 7, 8, 9, 10, 11]        # 12 rows: 5, 5, 2
+        with contextlib.redirect_stdout(io.StringIO()):
+            mae1 = m.train(1); mae2 = m.train(2)
+        out = dict(mae=(float(mae1), float(mae2)))                # predictions assembled over the ranks (hi - lo floats per step)
+        model = m.model
+    else:
+        m = importlib.import_module('icassp2022_depression_amd.fuse_net_whole')
+        g = load_golden('fuse_clf')
+        N, T, Fa, Ft, Ha, Ht = [int(v) for v in g['dims']]
+        m.config.update(audio_embed_size=Fa, text_embed_size=Ft, audio_hidden_dims=Ha, text_hidden_dims=Ht, dropout=dropout,
+                        batch_size=2, learning_rate=float(g['lr']))
+        m.build(seed=0)
+        m.model.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()})
+        m.optimizer = nn.Adam(m.model.parameters(), lr=m.config['learning_rate'])
+        m.fuse_features = [[g['xa'][i], g['xt'][i]] for i in range(N)]; m.fuse_targets = g['y']
+        idx = list(range(min(N, 7)))          # batch_size 2 (the reference's): 2, 2, 2, 1 -> empty shards at world 3 in EVERY step
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.train(1, idx); m.train(2, idx)
+        out = dict(acc=int(m.train_acc))
+        model = m.model
+    if world > 1:                                 # the replicas must still be bit-identical: compare every rank's flat buffer with rank 0's
+        import torch.distributed as dist
+        ref = model._flat.clone(); dist.broadcast(ref, src=0)
+        d = (model._flat - ref).abs().max().reshape(1); dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        out['replica_diff'] = float(d.item())
+    if rank == 0:
+        q.put(({k: v.cpu().numpy() for k, v in model.state_dict().items()}, out))
+    if world > 1:
+        parallel.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn(case, world, dropout, port_base):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = port_base + os.getpid() % 500 + world
+    procs = [ctx.Process(target=_run_generic, args=(case, r, world, port, q, dropout)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
+@pytest.mark.parametrize('case,port', [('text_clf', 26000), ('audio_reg', 26600), ('fuse_clf', 27200)])
+def test_data_parallel_training_equals_single_process_for_every_loop(case, port):
+    """text_bilstm_whole.train (attention + BiLSTM gradient ranges), audio_bilstm_perm.train (regression: the prediction
+    all-reduce between the gradient exchange and the loss scalar -- ADVICE r2's ordering bug lived here) and fuse_net_whole.train
+    (768 trainable floats, batch_size 2 < world 3): 2 and 3 ranks must leave the parameters and the aggregates of the
+    single-process run."""
+    sd1, out1 = _spawn(case, 1, 0.0, port)
+    for world in (2, 3):
+        sdw, outw = _spawn(case, world, 0.0, port)
+        assert outw.pop('replica_diff') == 0.0
+        for k, v in out1.items():
+            assert np.allclose(v, outw[k], rtol=0, atol=1e-4), (case, world, k, v, outw[k])
+        for k in sd1:
+            assert np.abs(sd1[k] - sdw[k]).max() < 2e-6 + 1e-5 * np.abs(sd1[k]).max(), (case, world, k)
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
+def test_data_parallel_with_dropout_is_deterministic_per_rank_and_keeps_replicas_identical():
+    """Dropout on: a 2-rank run repeated from the same seeds gives bit-identical parameters (each rank's Philox streams depend
+    only on seed, site and element), and rank 0's parameters equal rank 1's (checked through the all-reduced update: both ranks
+    apply the same summed gradient; the queue carries rank 0's copy of two independent runs)."""
+    a, oa = _spawn('text_clf', 2, 0.5, 27800)
+    b, ob = _spawn('text_clf', 2, 0.5, 27800)
+    assert oa['replica_diff'] == 0.0 and ob['replica_diff'] == 0.0
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    c, _ = _spawn('text_clf', 1, 0.5, 27800)                  # other mask partition (rank-keyed streams): close, not equal
+    assert any(not np.array_equal(a[k], c[k]) for k in a) and max(np.abs(a[k] - c[k]).max() for k in a) < 0.1
