@@ -92,9 +92,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='audio_gru', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-run', action='store_true', help='warm-up + timed steps only (rocprofv3 passes: every launch belongs to a train step)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (gloo: launch check on CPU)')
     ap.add_argument('--launch-check', action='store_true', help='only exercise the N-rank launch + one all-reduce')
     args = ap.parse_args()
@@ -109,22 +110,12 @@ def main():
     import importlib
     comm_kind = 'none'
     if world_env > 1:
+        # init_from_env builds the C-ABI's own RCCL communicator too (per-layer ranges overlapped with the backward pass); if it
+        # cannot be built on EVERY rank all ranks agree to fall back -- visibly, in `config.backend` -- to torch.distributed
         parallel.init_from_env('nccl')
-        # gradient transport: the C-ABI's own RCCL communicator (per-layer ranges overlapped with the backward pass); if it
-        # cannot be built on EVERY rank the job falls back -- visibly, in `config.backend` -- to torch.distributed's all-reduce
-        ok = 1
-        try:
-            ok = 1 if parallel.init_native_comm() is not None else 0
-        except Exception as e:                                   # noqa: BLE001
-            print(f'[rank {os.environ.get("RANK")}] native RCCL communicator failed: {e}', file=sys.stderr)
-            ok = 0
-        import torch.distributed as dist
-        flag = torch.tensor([ok], device='cuda'); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            comm_kind = 'rccl via dep_comm_* (layer ranges overlapped with backward)'
-        else:
-            parallel.destroy_native_comm()
-            comm_kind = 'rccl via torch.distributed (single bucket after backward)'
+        comm_kind = {'rccl-native': 'rccl via dep_comm_* (layer ranges overlapped with backward)',
+                     'torch.distributed': 'rccl via torch.distributed (single bucket after backward): ' + str(parallel._native.get('why'))
+                     }.get(parallel.transport(), parallel.transport())
     rank, world = parallel.rank(), parallel.world_size()
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the process group has {world} ranks '
@@ -192,18 +183,92 @@ def main():
     dt = float(tmax.item())
     final_loss = loss.item()
 
-    # forward-only (evaluate) rate, outside the headline region: eval-mode kernels, nothing saved for a backward
-    model.eval()
-    eval_fn = (lambda: model.pretrained_feature((xa, xt))) if args.workload == 'fusion' else (lambda: model(x))
-    eval_fn(); torch.cuda.synchronize()
-    n_eval = max(3, min(args.steps, 10))
-    t1 = time.perf_counter()
-    for _ in range(n_eval):
-        eval_fn()
-    torch.cuda.synchronize()
-    eval_ms = (time.perf_counter() - t1) / n_eval * 1e3
-    model.train()
+    extras = not args.profile_run
+    # gradient exchange alone (every rank; gathered on rank 0): the same ranges the step reduces, nothing beside them
+    comm_alone = None
+    if world > 1 and extras:
+        import torch.distributed as dist
+        in_call, post = model.sync_plan()
+        model._grad_ready = True
+        torch.cuda.synchronize(); parallel.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            parallel.reduce_zero_contribution(model, in_call, post) if parallel.native_comm() is not None else parallel.all_reduce_grads(model)
+        e1.record(); torch.cuda.synchronize()
+        mine = torch.tensor([e0.elapsed_time(e1) / 10], device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        comm_alone = [round(float(t.item()), 4) for t in allr]
 
+    # forward-only (evaluate) rate, outside the headline region: eval-mode kernels, nothing saved for a backward
+    eval_ms = None
+    if extras:
+        model.eval()
+        eval_fn = (lambda: model.pretrained_feature((xa, xt))) if args.workload == 'fusion' else (lambda: model(x))
+        eval_fn(); torch.cuda.synchronize()
+        n_eval = max(3, min(args.steps, 10))
+        t1 = time.perf_counter()
+        for _ in range(n_eval):
+            eval_fn()
+        torch.cuda.synchronize()
+        eval_ms = (time.perf_counter() - t1) / n_eval * 1e3
+        model.train()
+
+    # the same step with EXACT fp32 products everywhere (DEP_GEMM_MODE=f32): the headline runs the 3-term bf16 split
+    split_mode = L.get_gemm_mode() == 1
+    f32_exact = None
+    if extras and split_mode and rank == 0 and world == 1:
+        L.set_gemm_mode(0)
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            n_f = max(3, min(args.steps, 8))
+            t2 = time.perf_counter()
+            for _ in range(n_f):
+                lf = step()
+            torch.cuda.synchronize()
+            ms_f = (time.perf_counter() - t2) / n_f * 1e3
+            f32_exact = {'ms_per_step': round(ms_f, 3), 'value': round(B / (ms_f * 1e-3), 1), 'unit': 'utterances/s',
+                         'final_loss': round(lf.item(), 6), 'note': 'dep_set_gemm_mode(0): fp32 MFMA for every contraction and sweep'}
+        finally:
+            L.set_gemm_mode(1)
+
+    # train() as a user calls it: the script's own epoch loop over a host-resident corpus of 4 mini-batches (features uploaded
+    # once and gathered on the device, labels / loss.item() / accuracy count per step as in the reference)
+    train_e2e = None
+    if extras and rank == 0 and world == 1 and args.workload != 'fusion':
+        import contextlib, io
+        import numpy as np
+        nb = 6
+        rng = np.random.default_rng(7)
+        feats = rng.standard_normal((nb * B, T, F), dtype=np.float32)
+        targs = rng.integers(0, 2, nb * B)
+        which = 'audio' if args.workload == 'audio_gru' else 'text'
+        saved_cfg = dict(mod.config)
+        mod.config.update(cfg); mod.config['batch_size'] = B
+        setattr(mod, which + '_features', feats); setattr(mod, which + '_targets', targs)
+        mod.model, mod.optimizer, mod.criterion = model, optimizer, criterion
+        idx = list(range(nb * B))
+        with contextlib.redirect_stdout(io.StringIO()):
+            mod.train(1, idx)                                   # includes the one-time upload of the corpus
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            mod.train(2, idx)
+            torch.cuda.synchronize()
+        ms_e = (time.perf_counter() - t3) / nb * 1e3
+        train_e2e = {'ms_per_minibatch': round(ms_e, 3), 'value': round(B / (ms_e * 1e-3), 1), 'unit': 'utterances/s',
+                     'vs_bench_step': round(ms_e / (dt / args.steps * 1e3), 3),
+                     'note': f'{modname}.train() over {nb} host mini-batches of {B}: features resident in HBM after one upload, '
+                             'labels uploaded once per epoch, loss sum and accuracy count read once per epoch'}
+        mod.config.clear(); mod.config.update(saved_cfg)
+        from icassp2022_depression_amd import _common
+        _common.invalidate_device_features()
+
+    if world > 1:
+        parallel.barrier()
+        parallel.destroy_native_comm()                          # every rank tears its communicator down
     if rank != 0:
         return
     ms_per_step = dt / args.steps * 1e3
@@ -257,10 +322,23 @@ def main():
             traffic_note = 'PMC record is from other kernel sources (digest mismatch): refused'
     except Exception:
         pass
-    # intensity is far above the ridge, so the matrix pipe is the binding roof of this kernel; the HBM fractions
-    # (compulsory and design bytes) and the serial floor are reported beside it.
-    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tflops, 3), 'peak': round(mfma_peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(frac_mfma, 4), 'traffic': traffic, 'traffic_note': traffic_note,
+    step_traffic = None
+    try:
+        step_traffic = rec.get('step_bytes', {}).get(args.workload) if rec.get('kernel_digest') == stamp else None
+    except Exception:
+        pass
+    # which roof is nearer, from SURVEY 8(d)'s algorithmic figures (flops; compulsory bytes): derived, not assumed.  Neither
+    # binds: the sweep is limited by the serial hand-off latency of its T dependent steps (serial_floor below).
+    frac_hbm_alg = compulsory_bytes / sec / 1e9 / PEAK_HBM_GBS
+    bound = 'mfma' if frac_mfma >= frac_hbm_alg else 'hbm'
+    roofline = {'bound': bound, 'kernel': dom,
+                'achieved': round(tflops, 3) if bound == 'mfma' else round(compulsory_bytes / sec / 1e9, 1),
+                'peak': round(mfma_peak, 1) if bound == 'mfma' else PEAK_HBM_GBS, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+                'frac': round(frac_mfma if bound == 'mfma' else frac_hbm_alg, 4), 'traffic': traffic, 'traffic_note': traffic_note,
+                'limiter': 'serial hand-off latency of the recurrent steps (see serial_floor); sustained bf16 MFMA rate under the '
+                           'package power cap is 1.6-1.7 PFLOP/s (profiles/r03_micro_mfma_rate.txt), the guide peak is kept as `peak`',
+                'step_traffic': {'pmc_bytes_per_step': step_traffic, 'survey_8d_bytes_per_step': 0.944e9 if args.workload == 'audio_gru' else None,
+                                 'note': 'sum over all kernels of (2*FETCH_SIZE + WRITE_SIZE) per train step, rocprofv3 --pmc passes'},
                 'mfma_pipe': 'bf16 x3 split (peak = bf16 dense / 3)' if split else 'fp32',
                 'flops_per_launch': sweep_flops, 'avg_launch_ms': round(dom_ms, 4), 'launches_per_step': launches_per_step,
                 'achieved_mfma': {'tflops': round(tflops, 3), 'frac': round(frac_mfma, 4)},
@@ -285,17 +363,21 @@ def main():
                                 'linear head) on (B,T,Fa,Ft)=(512,300,256,1024)'}[args.workload],
            'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'vs_baseline': None, 'dtype': 'f32', 'precision_mode': 'bf16x3-split' if split_mode else 'f32', 'data': 'synthetic',
            'config': {'workload': (f'{modname}.{cls} train step, B={B}/GPU T={T} F={F} H={H_model} L=2 dropout={cfg["dropout"]} '
                                    + ('Adam, MyLoss (split-weight CE)' if fusion else 'AdamW, CE-on-softmax')),
                       'global_batch': B * world, 'parallelism': f'dp{world}', 'ranks': world,
                       'backend': comm_kind},
            'final_loss': round(final_loss, 6),
-           'eval_forward': {'value': round(B / (eval_ms * 1e-3), 1), 'unit': 'utterances/s', 'ms_per_batch': round(eval_ms, 3),
-                            'note': 'forward only (evaluate), rank 0, outside the headline region'},
            'roofline': roofline}
+    if eval_ms is not None:
+        out['eval_forward'] = {'value': round(B / (eval_ms * 1e-3), 1), 'unit': 'utterances/s', 'ms_per_batch': round(eval_ms, 3),
+                               'note': 'forward only (evaluate), rank 0, outside the headline region'}
+    out['extra'] = {'f32_exact': f32_exact, 'train_e2e': train_e2e, 'comm_alone_ms_per_step_by_rank': comm_alone,
+                    'precision_note': 'storage, state, accumulation and elementwise math fp32; products of the large contractions '
+                                      'and of the recurrent sweeps: 3-term bf16 split on the bf16 matrix cores (DEP_GEMM_MODE=f32 = exact)'}
 
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and extras:
         import platform
         from oracle import torch_cpu_baseline as tb
         threads = usable_cores()

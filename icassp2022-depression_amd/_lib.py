@@ -312,6 +312,14 @@ class Rnn:
         """Synchronise and raise if a cluster sweep gave up on a bounded spin (never silently wrong)."""
         check(self.lib.dep_rnn_status(C.byref(self.desc), _ptr(self.workspace), stream()), 'dep_rnn_status')
 
+    def status_word(self):
+        """Device view (0-dim int32) of the sweeps' status word inside the workspace, or None for layouts without one: lets a
+        training loop fold the per-step status into a device-side flag instead of synchronising every step (nn.LossSum)."""
+        off = self.lib.dep_rnn_workspace_xbuf_offset(C.byref(self.desc))
+        if off == C.c_size_t(-1).value:
+            return None
+        return self.workspace.view(torch.int32)[off // 4]
+
     def layer_output(self, layer=None):
         """Zero-copy view of a layer's output sequence (B,T,H*dirs) inside the reserve."""
         d = self.desc

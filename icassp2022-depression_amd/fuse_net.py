@@ -91,8 +91,8 @@ def _mae_rmse(y, pred):
 def train(model, epoch):
     """Reference lines 373-412."""
     model.train()
-    total_loss = 0
-    pred = np.array([])
+    total = nn.LossSum(model.device)                 # device-side sum of the step losses, read once per epoch
+    preds = []
     idx = list(train_dep_idxs) + list(train_non_idxs)
     X_train = [fuse_features[i] for i in idx]
     Y_train = [fuse_targets[i] for i in idx]
@@ -101,10 +101,8 @@ def train(model, epoch):
         parallel.set_global_count(hi - lo)
         x, y = X_train[a:b], Y_train[a:b]
         if b <= a:                                  # empty shard of a small mini-batch: zero-contribution step
-            # same collective order as the working ranks: gradients, predictions (hi - lo floats), then the loss scalar
-            loss = nn.empty_shard_step(model, optimizer)
-            pred = np.hstack((pred, parallel.all_reduce_sum(torch.zeros(hi - lo, device=model.device)).cpu().numpy()))
-            total_loss += loss.item()
+            total.add(nn.empty_shard_step(model, optimizer))
+            preds.append(torch.zeros(hi - lo, device=model.device))
             continue
         optimizer.zero_grad()
         text_feature, audio_feature = model.pretrained_feature(x)
@@ -113,12 +111,16 @@ def train(model, epoch):
         loss.backward()
         optimizer.step()
         out_all = output.data.flatten()
-        if parallel.world_size() > 1:
+        if parallel.world_size() > 1:               # this rank's rows of the global mini-batch; the others' stay zero until the epoch-end SUM
             full = torch.zeros(hi - lo, device=out_all.device); full[a - lo:b - lo] = out_all
-            out_all = parallel.all_reduce_sum(full)
-        pred = np.hstack((pred, out_all.cpu().numpy()))
-        total_loss += loss.item()
+            out_all = full
+        preds.append(out_all)
+        total.add(loss, model)
     parallel.set_global_count(None)
+    total_loss = total.item()                        # the epoch's only host synchronisation on the loss (raises if a sweep gave up)
+    # per step every rank issues: the gradient exchange, then the loss scalar (nn.Loss.item); the predictions of the whole epoch
+    # are assembled by ONE all-reduce here -- same sequence on working and empty-shard ranks, no per-step host copy
+    pred = parallel.all_reduce_sum(torch.cat(preds)).cpu().numpy().astype(np.float64) if preds else np.array([])
     train_mae, train_rmse = _mae_rmse(Y_train, pred)
     if parallel.rank() == 0:
         print('Train Epoch: {:2d}\t Learning rate: {:.4f}\t Loss: {:.4f}\t MAE: {:.4f}\t RMSE: {:.4f}\n '

@@ -101,16 +101,15 @@ def train(epoch, train_idxs):
     """Reference lines 421-465."""
     global max_train_acc, train_acc
     model.train()
-    total_loss = 0
-    correct = 0
+    total = nn.LossSum(model.device)                 # device-side sum of the step losses, read once per epoch
+    correct_dev = torch.zeros((), dtype=torch.int64, device=model.device)      # counted on the device, read once per epoch
     X_train = [fuse_features[idx] for idx in train_idxs]
     Y_train = [fuse_targets[idx] for idx in train_idxs]
     for lo, hi in _common.minibatches(len(X_train), config['batch_size']):
         x, y = _batch(X_train, Y_train, lo, hi)
         parallel.set_global_count(hi - lo)
         if len(x) == 0:                             # empty shard of a small mini-batch (batch_size 2 < world): zero-contribution step
-            total_loss += nn.empty_shard_step(model, optimizer).item()
-            correct += int(parallel.all_reduce_sum(torch.zeros((), dtype=torch.int64, device=model.device)).item())
+            total.add(nn.empty_shard_step(model, optimizer))
             continue
         optimizer.zero_grad()
         text_feature, audio_feature = model.pretrained_feature(x)
@@ -121,9 +120,11 @@ def train(epoch, train_idxs):
         loss = criterion(text_feature, audio_feature, y, model)
         loss.backward()
         optimizer.step()
-        total_loss += loss.item()
-        correct += int(parallel.all_reduce_sum(n_ok).item())
+        total.add(loss, model)
+        correct_dev += n_ok
     parallel.set_global_count(None)
+    total_loss = total.item()                        # the epoch's only host synchronisation on the loss (raises if a sweep gave up)
+    correct = int(parallel.all_reduce_sum(correct_dev).item())                  # one collective per epoch, on every rank
     max_train_acc = correct
     train_acc = correct
     if parallel.rank() == 0:

@@ -55,6 +55,9 @@ class _RnnCache:
         if getattr(self, 'last', None) is not None:
             self.last.check()
 
+    def status_word(self):
+        return self.last.status_word() if getattr(self, 'last', None) is not None else None
+
 
 class _MLPHead:
     """[Dropout] -> Linear(H,H) -> ReLU -> Dropout -> [Linear(H,C)]   (fc_audio / fc_out Sequentials)."""
@@ -165,6 +168,10 @@ class AudioGRU(nn.Module):
     def check_health(self):
         self._rnns.check()
 
+    def status_words(self):
+        w = self._rnns.status_word()
+        return [] if w is None else [w]
+
     # encoder part shared with FusionNet
     def encode(self, x, training, seed):
         B, T, F = x.shape
@@ -256,6 +263,10 @@ class TextBiLSTM(nn.Module):
 
     def check_health(self):
         self._rnns.check()
+
+    def status_words(self):
+        w = self._rnns.status_word()
+        return [] if w is None else [w]
 
     def sync_plan(self):
         """Flat layout [attention | l0 (both directions) | l1 .. | fc_out]: the attention pair (final before the stack's
@@ -351,6 +362,9 @@ class FusionNet(nn.Module):
 
     def check_health(self):
         self._rnn_t.check(); self._rnn_a.check()
+
+    def status_words(self):
+        return [w for w in (self._rnn_t.status_word(), self._rnn_a.status_word()) if w is not None]
 
     def _split(self, x):
         """Accept the reference's list of (audio_i, text_i) pairs or an (audio, text) pair of arrays."""

@@ -222,6 +222,38 @@ class Loss:
         return self.item()
 
 
+class LossSum:
+    """`total_loss += loss.item()` of the reference's loops (audio_gru_whole.py:195) without a host synchronisation per
+    mini-batch: the step losses are added on the device in float64 -- exactly what Python's float accumulation of the fp32
+    `loss.item()` values computes, in the same order -- and read ONCE with item().  The sweeps' status word is folded into a
+    device flag at every add(), so a sweep that gave up in any step of the epoch still raises (at item(), not silently).  Under
+    data parallelism the per-rank parts are summed by one all-reduce in item() (every rank calls it)."""
+
+    def __init__(self, device):
+        self._acc = torch.zeros((), dtype=torch.float64, device=device)
+        self._bad = None
+        self._reduce = False
+
+    def add(self, loss, model=None):
+        self._acc += loss._v.reshape(-1)[0].double()
+        self._reduce = self._reduce or loss._reduce
+        loss._reduce = False                              # summed here, once
+        for w in (model.status_words() if model is not None and hasattr(model, 'status_words') else []):
+            self._bad = w.clone() if self._bad is None else torch.maximum(self._bad, w)
+        return self
+
+    def item(self):
+        if self._reduce:
+            parallel.all_reduce_sum(self._acc)
+            self._reduce = False
+        v = float(self._acc.item())
+        if self._bad is not None and int(self._bad.item()) != 0:
+            raise L.DepError('a recurrent sweep gave up waiting for a cluster member during this epoch (status %d): the GPU was '
+                             'shared with another kernel; DEP_FUSED2=0 DEP_CLUSTER16=0 selects the sweeps that tolerate it'
+                             % int(self._bad.item()))
+        return v
+
+
 def _check_labels(t, num_classes):
     """torch's CrossEntropyLoss raises on a class index outside [0, C); the loss kernel indexes with the label, so the
     range is validated here, on the host copy the training loops hand over (device-resident labels are the caller's)."""

@@ -64,34 +64,37 @@ def _mae_rmse(y, pred):
 def train(epoch):
     """Reference lines 131-169."""
     model.train()
-    total_loss = 0
-    pred = np.array([])
+    total = nn.LossSum(model.device)                 # device-side sum of the step losses, read once per epoch
+    preds = []
     idx = list(train_dep_idxs) + list(train_non_idxs)
-    X_train = text_features[idx]
     Y_train = text_targets[idx]
-    for lo, hi in _common.minibatches(X_train.shape[0], config['batch_size']):
-        a, b = _common.rank_slice(lo, hi)
+    Y_dev = _common.device_labels(Y_train, model.device)
+    feed = _common.FeatureFeeder(text_features, idx, model.device, role='text_features')       # rows of X_train = text_features[idx], in HBM
+    batches = [((lo, hi), _common.rank_slice(lo, hi)) for lo, hi in _common.minibatches(len(idx), config['batch_size'])]
+    for bi, ((lo, hi), (a, b)) in enumerate(batches):
         parallel.set_global_count(hi - lo)
         if b <= a:                                  # empty shard of a small (ragged) mini-batch: zero-contribution step
-            # same collective order as the working ranks: gradients, predictions (hi - lo floats), then the loss scalar
-            loss = nn.empty_shard_step(model, optimizer)
-            pred = np.hstack((pred, parallel.all_reduce_sum(torch.zeros(hi - lo, device=model.device)).cpu().numpy()))
-            total_loss += loss.item()
+            total.add(nn.empty_shard_step(model, optimizer))
+            preds.append(torch.zeros(hi - lo, device=model.device))
             continue
-        x = torch.from_numpy(np.ascontiguousarray(X_train[a:b])).type(torch.FloatTensor)
-        y = torch.from_numpy(np.ascontiguousarray(Y_train[a:b])).type(torch.FloatTensor)
+        x = feed.rows(a, b, then=batches[bi + 1][1] if bi + 1 < len(batches) else None)
+        y = Y_dev[a:b]
         optimizer.zero_grad()
         output = model(x)
         loss = criterion(output, y.view(-1, 1))
         loss.backward()
         optimizer.step()
         out_all = output.data.flatten()
-        if parallel.world_size() > 1:
+        if parallel.world_size() > 1:               # this rank's rows of the global mini-batch; the others' stay zero until the epoch-end SUM
             full = torch.zeros(hi - lo, device=out_all.device); full[a - lo:b - lo] = out_all
-            out_all = parallel.all_reduce_sum(full)
-        pred = np.hstack((pred, out_all.cpu().numpy()))
-        total_loss += loss.item()
+            out_all = full
+        preds.append(out_all)
+        total.add(loss, model)
     parallel.set_global_count(None)
+    total_loss = total.item()                        # the epoch's only host synchronisation on the loss (raises if a sweep gave up)
+    # per step every rank issues: the gradient exchange, then the loss scalar (nn.Loss.item); the predictions of the whole epoch
+    # are assembled by ONE all-reduce here -- same sequence on working and empty-shard ranks (ADVICE r2), no per-step host copy
+    pred = parallel.all_reduce_sum(torch.cat(preds)).cpu().numpy().astype(np.float64) if preds else np.array([])
     train_mae, train_rmse = _mae_rmse(Y_train, pred)
     if parallel.rank() == 0:
         print('Train Epoch: {:2d}\t Learning rate: {:.4f}\t Loss: {:.4f}\t MAE: {:.4f}\t RMSE: {:.4f}\n '
@@ -104,9 +107,8 @@ def evaluate(fold, model, train_mae):
     global min_mae, min_rmse
     model.eval()
     idx = list(test_dep_idxs) + list(test_non_idxs)
-    X_test = text_features[idx]
     Y_test = text_targets[idx]
-    x = torch.from_numpy(np.ascontiguousarray(X_test)).type(torch.FloatTensor)
+    x = _common.FeatureFeeder(text_features, idx, model.device, role='text_features').rows(0, len(idx))
     y = torch.from_numpy(np.ascontiguousarray(Y_test)).type(torch.FloatTensor)
     output = model(x)
     loss = criterion(output, y.view(-1, 1))

@@ -66,41 +66,43 @@ def train(epoch, train_idxs):
     """Reference lines 154-193; data-parallel aware like audio_gru_whole.train."""
     global train_acc
     model.train()
-    total_loss = 0
-    correct = 0
-    X_train = text_features[train_idxs]
-    Y_train = text_targets[train_idxs]
-    for lo, hi in _common.minibatches(X_train.shape[0], config['batch_size']):
-        a, b = _common.rank_slice(lo, hi)
-        parallel.set_global_count(hi - lo)
+    total = nn.LossSum(model.device)                 # device-side sum of the step losses, read once per epoch
+    correct_dev = torch.zeros((), dtype=torch.int64, device=model.device)      # counted on the device, read once per epoch
+    n_train = len(train_idxs)
+    Y_dev = _common.device_labels(text_targets[train_idxs], model.device, config['num_classes'])
+    feed = _common.FeatureFeeder(text_features, train_idxs, model.device, role='text_features')       # rows of X_train = text_features[train_idxs], in HBM
+    batches = [(_common.rank_slice(lo, hi), hi - lo) for lo, hi in _common.minibatches(n_train, config['batch_size'])]
+    for bi, ((a, b), n_glob) in enumerate(batches):
+        parallel.set_global_count(n_glob)
         if b <= a:                                  # this rank owns no row of a small (ragged) mini-batch: zero-contribution step
-            total_loss += nn.empty_shard_step(model, optimizer).item()
-            correct += int(parallel.all_reduce_sum(torch.zeros((), dtype=torch.int64, device=model.device)).item())
+            total.add(nn.empty_shard_step(model, optimizer))
             continue
-        x = torch.from_numpy(np.ascontiguousarray(X_train[a:b])).type(torch.FloatTensor)
-        y = torch.from_numpy(np.ascontiguousarray(Y_train[a:b]))
+        x = feed.rows(a, b, then=batches[bi + 1][0] if bi + 1 < len(batches) else None)
+        y = Y_dev[a:b]
         optimizer.zero_grad()
         output = model(x)
         pred = output.data.max(1, keepdim=True)[1]
-        n_ok = pred.eq(y.to(pred.device).view_as(pred)).sum()
+        n_ok = pred.eq(y.view_as(pred)).sum()
         loss = criterion(output, y)
         loss.backward()
         optimizer.step()
-        total_loss += loss.item()
-        correct += int(parallel.all_reduce_sum(n_ok).item())
+        total.add(loss, model)
+        correct_dev += n_ok
     parallel.set_global_count(None)
+    total_loss = total.item()                        # the epoch's only host synchronisation on the loss (raises if a sweep gave up)
+    correct = int(parallel.all_reduce_sum(correct_dev).item())                  # one collective per epoch, on every rank
     train_acc = correct
     if parallel.rank() == 0:
         print('Train Epoch: {:2d}\t Learning rate: {:.4f}\tLoss: {:.6f}\t Accuracy: {}/{} ({:.0f}%)\n '
-              .format(epoch + 1, config['learning_rate'], total_loss, correct, X_train.shape[0],
-                      100. * correct / X_train.shape[0]))
+              .format(epoch + 1, config['learning_rate'], total_loss, correct, n_train,
+                      100. * correct / n_train))
 
 
 def evaluate(model, test_idxs, fold, train_idxs):
     """Reference lines 196-235."""
     global max_f1, max_acc, max_prec, max_rec
     model.eval()
-    x = torch.from_numpy(np.ascontiguousarray(text_features[test_idxs])).type(torch.FloatTensor)
+    x = _common.FeatureFeeder(text_features, test_idxs, model.device, role='text_features').rows(0, len(test_idxs))
     y = torch.from_numpy(np.ascontiguousarray(text_targets[test_idxs])).type(torch.LongTensor)
     output = model(x)
     loss = criterion(output, y)
