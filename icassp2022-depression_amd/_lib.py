@@ -45,6 +45,8 @@ _SIGS = {
     'dep_rnn_reserve_y_offset': (C.c_size_t, [C.POINTER(RnnDesc), C.c_int]),
     'dep_rnn_reserve_ydrop_offset': (C.c_size_t, [C.POINTER(RnnDesc), C.c_int]),
     'dep_rnn_status': (C.c_int, [C.POINTER(RnnDesc), _P, _P]),
+    'dep_rnn_set_exclusive': (C.c_int, [C.c_int]),
+    'dep_rnn_get_exclusive': (C.c_int, []),
     'dep_rnn_workspace_xbuf_offset': (C.c_size_t, [C.POINTER(RnnDesc)]),
     'dep_rnn_forward': (C.c_int, [C.POINTER(RnnDesc), _P, C.POINTER(_P), _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     'dep_rnn_backward': (C.c_int, _BWD_ARGS),
@@ -291,6 +293,21 @@ def attn_bwd(dctx, out, Wa, saved, K, dWa, dba):
     return dout, dh_n
 
 
+_fallback_noted = [False]
+
+
+def note_fallback():
+    """The exclusive GRU forward gave way to foreign work at least once: results are right (the device redid the forward on
+    the tolerant kernels), but every such step pays the hello time-out -- switch the attempt off for the rest of the process."""
+    load().dep_rnn_set_exclusive(0)
+    if not _fallback_noted[0]:
+        _fallback_noted[0] = True
+        import warnings
+        warnings.warn('icassp2022_depression_amd: the GPU is shared with other kernels -- the fused GRU forward fell back to the '
+                      'co-schedule-tolerant sweeps (results unaffected); using those directly from now on '
+                      '(dep_rnn_set_exclusive(0); set DEP_EXCLUSIVE=0 to start that way)', RuntimeWarning, stacklevel=3)
+
+
 class Rnn:
     """One dep_rnn_desc + its reserve/workspace buffers (allocated once per shape, reused per step)."""
 
@@ -309,8 +326,20 @@ class Rnn:
         self._garr = (_P * self.n_w)()
 
     def check(self):
-        """Synchronise and raise if a cluster sweep gave up on a bounded spin (never silently wrong)."""
+        """Synchronise and raise if a cluster sweep gave up on a bounded spin (never silently wrong).  Also the place where the
+        host learns that the exclusive forward had to fall back (soft word): it then stops attempting it in this process."""
         check(self.lib.dep_rnn_status(C.byref(self.desc), _ptr(self.workspace), stream()), 'dep_rnn_status')
+        w = self.fallback_word()
+        if w is not None and self.lib.dep_rnn_get_exclusive() and int(w.item()) != 0:
+            note_fallback()
+
+    def fallback_word(self):
+        """Device view of the soft word (include/dep_rnn.h, dep_rnn_set_exclusive): non-zero when the forward that just ran on
+        this workspace was redone by the co-schedule-tolerant kernels."""
+        off = self.lib.dep_rnn_workspace_xbuf_offset(C.byref(self.desc))
+        if off == C.c_size_t(-1).value:
+            return None
+        return self.workspace.view(torch.int32)[off // 4 + 1]
 
     def status_word(self):
         """Device view (0-dim int32) of the sweeps' status word inside the workspace, or None for layouts without one: lets a

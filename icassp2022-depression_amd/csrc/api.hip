@@ -216,6 +216,17 @@ extern "C" int dep_rnn_status(const dep_rnn_desc* d, void* workspace, void* stre
     return DEP_OK;
 }
 
+// Kernels that need every CU to themselves (the fused two-layer GRU forward, the 16-unit-member forward): allowed unless the
+// process said otherwise (DEP_EXCLUSIVE=0 / dep_rnn_set_exclusive(0): the GPU is shared with other streams or processes).
+static std::atomic<int> g_exclusive{-1};
+bool dep_exclusive_on() {
+    int v = g_exclusive.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = getenv("DEP_EXCLUSIVE"); v = (e && e[0] == '0') ? 0 : 1; g_exclusive.store(v); }
+    return v == 1;
+}
+extern "C" int dep_rnn_set_exclusive(int on) { g_exclusive.store(on ? 1 : 0); return DEP_OK; }
+extern "C" int dep_rnn_get_exclusive(void) { return dep_exclusive_on() ? 1 : 0; }
+
 // Precision of the recurrent products inside the cluster sweeps: follows the GEMM mode (include/dep_rnn.h,
 // dep_set_gemm_mode): 1 = 3-term bf16 split on the bf16 matrix cores, 0 = exact fp32 MFMA.  DEP_SWEEP_MODE=f32 pins the
 // sweeps to fp32 while leaving the GEMMs alone (A/B).
@@ -264,15 +275,17 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     const int B = d->B, T = d->T, H = d->H, D = d->dirs, G = lo.G, L = d->L;
     const int BTr = (int)lo.BT;
     const bool mfma = lo.cluster || dep_sweep_use_mfma(H, d->impl);
-    const bool split_fwd = lo.cluster16 && sweep_split_mode();
-    const bool split_fwd32 = lo.cluster && !lo.cluster16 && d->cell == DEP_CELL_GRU && sweep_split_mode();     // 32-unit members
+    const bool excl = dep_exclusive_on();
+    const bool use16 = lo.cluster16 && excl;                        // the 16-unit-member forward fills the CUs: not on a shared GPU
+    const bool split_fwd = use16 && sweep_split_mode();
+    const bool split_fwd32 = lo.cluster && !use16 && d->cell == DEP_CELL_GRU && sweep_split_mode();     // 32-unit members
     const bool split_lstm = lo.cluster && d->cell == DEP_CELL_LSTM && sweep_split_mode();
     int rc;
     if (lo.cluster) { rc = dep_cluster_reset_status(W + lo.xbuf, s); if (rc) return rc; }
     // the recurrent-weight images packed below are precision-mode specific: remember which mode this reserve holds
     // bit 0: precision mode; bit 1: the backward image is the 16-unit-member one (a caller flipping DEP_CLUSTER16_BWD is refused too)
     record_reserve_mode(reserve, (sweep_split_mode() ? 1 : 0) | (lo.cluster16_bwd ? 2 : 0));
-    if (lo.fused2 && sweep_split_mode()) {
+    if (lo.fused2 && sweep_split_mode() && excl) {
         // both layers in one launch: layer 1 runs one step behind layer 0 and takes its input straight from the exchanged
         // h0_t (no layer-1 input-projection GEMM, no GI round trip through HBM for it)
         const float* const* w0 = weights; const float* const* w1 = weights + 4;
@@ -303,7 +316,36 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         f.hn0 = h_n; f.hn1 = h_n ? h_n + (size_t)B * H : nullptr;
         for (int l = 0; l < 2; ++l) for (int k = 0; k < 4; ++k) f.sv[l][k] = d->training ? R + lo.sv[l][k] : nullptr;
         f.stream = s;
+        f.soft_fallback = 1;
         rc = dep_launch_fused2_fwd(f, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
+        // Fallback, decided ON THE DEVICE (no host synchronisation, identical on every data-parallel rank): the launch above
+        // needs every CU to itself; if a foreign workgroup kept its clusters from assembling it has set the workspace's soft
+        // flag and left.  The per-layer kernels that tolerate co-scheduled work are enqueued behind it in any case and return
+        // at entry unless the flag is set (3 near-empty launches per forward, ~10 us); they write the same reserve layout, so
+        // the backward does not care which of the two produced it.
+        const unsigned* soft = reinterpret_cast<const unsigned*>(W + lo.xbuf) + 1;
+        for (int l = 0; l < 2; ++l) {
+            const float* const* wl = l == 0 ? w0 : w1;
+            if (l == 1) {
+                const float* in = lo.drop ? R + lo.ydrop[0] : R + lo.y[0];
+                dep_gemm_set_predicate(soft);
+                rc = dep_gemm_internal(0, 1, BTr, G * H, H, in, H, wl[0], H, gi, G * H, wl[2], 0.f, 0, 0, nullptr, 0, s);
+                dep_gemm_set_predicate(nullptr);
+                if (rc) return rc;
+            }
+            dep_sweep_args a{};
+            a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = 1; a.training = d->training; a.impl = d->impl; a.split = 1;
+            a.w_hh[0] = wl[1]; a.b_hh[0] = wl[3]; a.wp[0] = R + lo.wp[l][0];
+            a.gi = gi; a.y = R + lo.y[l]; a.ldy = H;
+            const bool dropl = lo.drop && l == 0;
+            a.ydrop = dropl ? R + lo.ydrop[0] : nullptr;
+            a.drop_p = dropl ? d->dropout_p : 0.f; a.seed = d->seed; a.site = DEP_SITE_RNN0 + l;
+            a.pooled = (l == 1 && pooled) ? pooled : nullptr; a.pool_scale = f.pool_scale;
+            a.h_n = h_n ? h_n + (size_t)l * B * H : nullptr;
+            if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
+            a.only_if = soft; a.stream = s;
+            rc = dep_launch_cluster_fwd(a, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
+        }
         if (y) { rc = dep_axpby(R + lo.y[1], y, (long)lo.BT * H, 1.f, 0.f, s); if (rc) return rc; }
         return DEP_OK;
     }
@@ -361,7 +403,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         a.h_n = h_n ? h_n + (size_t)l * D * B * H : nullptr;
         if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
         a.stream = s;
-        rc = lo.cluster16 ? dep_launch_cluster16_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
+        rc = use16 ? dep_launch_cluster16_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : lo.cluster ? dep_launch_cluster_fwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_fwd(a);
         if (rc) return rc;

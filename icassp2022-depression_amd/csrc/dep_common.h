@@ -84,12 +84,18 @@ __device__ __forceinline__ void dep_xcd_tile(int gx, int gy, int gz, int& bx, in
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
 enum { DEP_PROF_GRU_FWD = 0, DEP_PROF_GRU_BWD = 1, DEP_PROF_LSTM_FWD = 2, DEP_PROF_LSTM_BWD = 3,
        DEP_PROF_GEMM_NT = 4, DEP_PROF_GEMM_NN = 5, DEP_PROF_GEMM_TN = 6, DEP_PROF_NCAT = 7 };
+// GEMM predicate of the calling thread: launches of dep_gemm_internal made while it is set return at kernel entry unless the
+// device word is non-zero (the conditional fallback of dep_rnn_forward).  nullptr = unconditional.
+void dep_gemm_set_predicate(const unsigned* only_if);
+const unsigned* dep_gemm_predicate();
+// process-wide: may dep_rnn_forward use kernels that need every CU to themselves (dep_rnn_set_exclusive, include/dep_rnn.h)
+bool dep_exclusive_on();
 bool dep_prof_on();
 void dep_prof_begin(int cat, hipStream_t s);
 void dep_prof_end(hipStream_t s);
 struct DepProfScope {
     hipStream_t s; bool on;
-    DepProfScope(int cat, hipStream_t st) : s(st), on(dep_prof_on()) { if (on) dep_prof_begin(cat, s); }
+    DepProfScope(int cat, hipStream_t st, bool enable = true) : s(st), on(enable && dep_prof_on()) { if (on) dep_prof_begin(cat, s); }
     ~DepProfScope() { if (on) dep_prof_end(s); }
 };
 
@@ -113,6 +119,7 @@ struct dep_sweep_args {
     float* h_n;              // (dirs,B,H) final states or NULL
     // reserve (training): GRU r,z,n,hn each (B,T,H) ; LSTM gates (B,T,dirs*4H) + c (B,T,dirs*H)
     float* sv0; float* sv1; float* sv2; float* sv3;
+    const unsigned* only_if;  // cluster forward: run only when this device word is non-zero (fallback behind an exclusive kernel), or NULL
     hipStream_t stream;
 };
 int dep_launch_sweep_fwd(const dep_sweep_args& a);
@@ -171,6 +178,7 @@ struct dep_fused2_args {
     float drop_p; uint64_t seed; uint32_t site;
     float* pooled; float pool_scale; float* hn0; float* hn1;
     float* sv[2][4];
+    int soft_fallback;                                        // 1: a failed hello sets the workspace's soft flag instead of the status word
     hipStream_t stream;
 };
 bool dep_fused2_ok(int cell, int H, int L, int dirs);

@@ -26,6 +26,7 @@ struct GemmP {
     int kchunk, splits;
     float* part;
     int gx, gy;             // tile grid (x: N tiles, y: M tiles); the launch is 1-D, see dep_xcd_tile            // split-K partials [splits][M][N] or nullptr
+    const unsigned* only_if;    // run only if this device word is non-zero (dep_gemm_set_predicate), or nullptr
 };
 
 // Load one (128 x 32) operand tile into registers.  TR = operand stored MN-contiguous.
@@ -88,6 +89,7 @@ __device__ __forceinline__ void store_tile(float* S, int tid, const float (&r)[4
 // TA: A stored (K,M) ; TB: B stored (N,K)  [note the asymmetry, matches the public API]
 template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_mfma(GemmP p) {
+    if (p.only_if && *p.only_if == 0) return;
     constexpr bool A_TR = TA;        // A MN-contiguous when stored (K,M)
     constexpr bool B_TR = !TB;       // B MN-contiguous when stored (K,N)
     constexpr int LDA_S = A_TR ? LD_M : LD_K;
@@ -164,8 +166,9 @@ __global__ __launch_bounds__(NT) void gemm_mfma(GemmP p) {
         }
 }
 
-__global__ void splitk_reduce(const float* __restrict__ part, int splits, int M, int N, float* C, int ldc,
+__global__ void splitk_reduce(const unsigned* only_if, const float* __restrict__ part, int splits, int M, int N, float* C, int ldc,
                               const float* bias, float beta) {
+    if (only_if && *only_if == 0) return;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)M * N) return;
     const int m = (int)(idx / N), n = (int)(idx % N);
@@ -187,6 +190,7 @@ __global__ void splitk_reduce(const float* __restrict__ part, int splits, int M,
 
 // Reference-quality fallback (any shape/alignment); selected with DEP_GEMM_NAIVE=1 for A/B checks.
 __global__ void gemm_naive(GemmP p, int TA, int TB) {
+    if (p.only_if && *p.only_if == 0) return;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int m = blockIdx.y;
     if (n >= p.N || m >= p.M) return;
@@ -220,9 +224,11 @@ struct SmallP {
     const float* B; long sbk, sbn;
     float* C; int ldc;
     const float* bias; float beta;
+    const unsigned* only_if;
 };
 
 __global__ __launch_bounds__(256) void gemm_small(SmallP p) {
+    if (p.only_if && *p.only_if == 0) return;
     __shared__ float red[4][16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -304,6 +310,9 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
                            int splits, int kchunk, float* part, bool vec, hipStream_t s);
 static std::atomic<int> g_split_mode{-1};            // process-global (documented in dep_rnn.h)
 static std::atomic<long> g_split_min_macs{1L << 28};
+static thread_local const unsigned* g_only_if = nullptr;
+void dep_gemm_set_predicate(const unsigned* only_if) { g_only_if = only_if; }
+const unsigned* dep_gemm_predicate() { return g_only_if; }
 static thread_local int g_force_exact = 0;       // per calling thread: 1 = this call is exact fp32, 2 = this call is bf16x3 whatever the global mode
 static void init_split_mode() {
     if (g_split_mode < 0) { const char* e = getenv("DEP_GEMM_MODE"); g_split_mode = (e && e[0] == 'f') ? 0 : 1; }
@@ -328,7 +337,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     DEP_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C);
     DEP_CHECK_ARG(!(transA && transB));
     DEP_CHECK_ARG(!(seq_T > 0 && transB));
-    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, K, 1, nullptr, 1, 1};
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, K, 1, nullptr, 1, 1, dep_gemm_predicate()};
     if (naive_forced()) {
         dim3 g(dep_cdiv(N, 128), M);
         hipLaunchKernelGGL(gemm_naive, g, dim3(128), 0, s, p, transA, transB);
@@ -337,8 +346,8 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     }
     if (seq_T <= 0 && (long)dep_cdiv(M, BM) * dep_cdiv(N, BN) < 32 && K <= 8192 && (long)M * N * K <= (1L << 27)) {
         SmallP q{M, N, K, A, transA ? 1L : (long)lda, transA ? (long)lda : 1L, B, transB ? 1L : (long)ldb,
-                 transB ? (long)ldb : 1L, C, ldc, bias, beta};
-        DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s);
+                 transB ? (long)ldb : 1L, C, ldc, bias, beta, dep_gemm_predicate()};
+        DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s, dep_gemm_predicate() == nullptr);
         hipLaunchKernelGGL(gemm_small, dim3(dep_cdiv(N, 32), dep_cdiv(M, 32)), dim3(256), 0, s, q);
         DEP_CHECK_LAUNCH();
         return DEP_OK;
@@ -362,7 +371,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     const bool vec = a16 && b16 && adim && bdim;
     p.gx = dep_cdiv(N, BN); p.gy = dep_cdiv(M, BM);
     dim3 g(p.gx * p.gy * splits);
-    DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s);
+    DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s, dep_gemm_predicate() == nullptr);
     init_split_mode();
     if (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode == 1 && (long)M * N * K >= g_split_min_macs))
         return dep_gemm_bf16x3_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
@@ -379,7 +388,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     DEP_CHECK_LAUNCH();
     if (splits > 1) {
         const long n = (long)M * N;
-        hipLaunchKernelGGL(splitk_reduce, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, p.part, splits, M, N, C, ldc,
+        hipLaunchKernelGGL(splitk_reduce, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, p.only_if, p.part, splits, M, N, C, ldc,
                            bias, beta);
         DEP_CHECK_LAUNCH();
     }

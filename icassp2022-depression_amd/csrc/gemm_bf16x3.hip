@@ -30,6 +30,7 @@ struct GemmP {
     float* part;
     int gx, gy;             // tile grid (x: N tiles, y: M tiles); the launch is 1-D, see dep_xcd_tile
     int ablate;             // debug (DEP_GEMM_ABLATE): 1 no epilogue stores, 2 no MFMA, 4 no tile reloads, 8 no LDS staging
+    const unsigned* only_if;    // run only if this device word is non-zero (dep_gemm_set_predicate), or nullptr
 };
 
 // Operand tile of ROWS (128 or 256) rows x 32 k, 256 threads: a = tid&7, bq = tid>>3.
@@ -140,6 +141,7 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
 // each (BMT/2) x 64 = (BMT/64) x 2 MFMA tiles of 32x32.
 template <bool TA, bool TB, bool VEC, int BMT>
 __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p) {
+    if (p.only_if && *p.only_if == 0) return;
     constexpr bool A_TR = TA, B_TR = !TB;
     constexpr int MI = BMT / 64;
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * (BMT + BN) * LDK];
@@ -381,6 +383,7 @@ __device__ __forceinline__ void ws_store(__bf16* Sh, __bf16* Sl, int tid, float 
 
 template <bool TA, bool TB, bool VEC, int D>
 __global__ __launch_bounds__(WS_NT, 1) void gemm_bf16x3_ws(GemmP p) {
+    if (p.only_if && *p.only_if == 0) return;
     constexpr bool A_TR = TA, B_TR = !TB;
     extern __shared__ __attribute__((aligned(16))) __bf16 ws_smem[];
 
@@ -602,8 +605,9 @@ __global__ __launch_bounds__(WS_NT, 1) void gemm_bf16x3_ws(GemmP p) {
     }
 }
 
-__global__ void splitk_reduce2(const float* __restrict__ part, int splits, int M, int N, float* C, int ldc,
+__global__ void splitk_reduce2(const unsigned* only_if, const float* __restrict__ part, int splits, int M, int N, float* C, int ldc,
                                const float* bias, float beta) {
+    if (only_if && *only_if == 0) return;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)M * N) return;
     const int m = (int)(idx / N), n = (int)(idx % N);
@@ -636,7 +640,7 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     const size_t spanA = (size_t)(transA ? K : M) * lda * 4, spanB = (size_t)(transB ? N : K) * ldb * 4;
     if (wsd > 0 && M >= 256 && spanA < (1ull << 32) && spanB < (1ull << 32)) {
         // wave-specialised kernel: one 8-wave workgroup per CU, 256 x 128 tiles, `wsd` register sets of prefetch
-        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl};
+        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl, dep_gemm_predicate()};
         const int ntiles = p.gx * p.gy * splits;
         int ncu = 256;
         { static int cus = -1; if (cus < 0) { hipDeviceProp_t pr; int dv = 0; cus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; } ncu = cus / 8 * 8; if (ncu < 8) ncu = 8; }
@@ -659,7 +663,7 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
         DEP_CHECK_LAUNCH();
         if (splits > 1) {
             const long n = (long)M * N;
-            hipLaunchKernelGGL(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, part, splits, M, N, C, ldc, bias, beta);
+            hipLaunchKernelGGL(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, dep_gemm_predicate(), part, splits, M, N, C, ldc, bias, beta);
             DEP_CHECK_LAUNCH();
         }
         return DEP_OK;
@@ -670,7 +674,7 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     // measured at cfg2: 256-row tiles win 8-10 % on the NN (dX) and TN (dW) forms, lose 6 % on the short-K NT projection
     const bool big = bm256 && M >= 512 && !(!transA && transB);
     const int BMT = big ? 256 : 128;
-    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl};
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl, dep_gemm_predicate()};
     // persistent launch: at most `persist` workgroups (a multiple of 8: one share per XCD), each walks a list of tiles
     const int ntiles = p.gx * p.gy * splits;
     const int cap = big ? persist * 2 / 3 : persist;              // 2 resident workgroups per CU with 256-row tiles, 3 otherwise
@@ -689,7 +693,7 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     DEP_CHECK_LAUNCH();
     if (splits > 1) {
         const long n = (long)M * N;
-        hipLaunchKernelGGL(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, part, splits, M, N, C, ldc, bias, beta);
+        hipLaunchKernelGGL(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, dep_gemm_predicate(), part, splits, M, N, C, ldc, bias, beta);
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;

@@ -386,6 +386,7 @@ struct F2 {
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
     int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
     long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
+    const unsigned* only_if; // run only if this word is set (fallback behind an exclusive forward kernel), or nullptr
 };
 
 template <int KCH, bool SPLIT>      // SPLIT: 3-term bf16 split of the recurrent product, as in gru_fwd_cluster16
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
     if (p.b0 + bt * BT >= p.B) return;
     if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
+    if (p.only_if && ld_agent(const_cast<unsigned*>(p.only_if)) == 0) return;      // the exclusive kernel in front of us did the work
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4, jl = w >> 1, kh = w & 1;
     const int jt = c * 2 + jl;
@@ -643,7 +645,8 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
     p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
     p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
-    DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
+    p.only_if = a.only_if;
+    DepProfScope prof(DEP_PROF_GRU_FWD, a.stream, a.only_if == nullptr);      // a conditional fallback launch is not a sweep of the step
     // Ask for more than half of the CU's 160 KiB LDS: the dispatcher can then never co-locate two members on one
     // CU (they would share the four matrix pipes and stretch every step of BOTH clusters).
     const size_t lds = EXCLUSIVE_LDS;

@@ -9,7 +9,12 @@ constexpr int BT = 16;                      // utterances per tile = MFMA N
 constexpr int LPAD = 4;                     // LDS row padding (floats)
 constexpr int CT = 256;                     // compute threads per workgroup
 constexpr unsigned SPIN_LIMIT = 1u << 20;   // bounded spins: ~1 s, then the status word is raised and the kernel leaves
-// exchange buffer header (zeroed before every launch): [0] status | flags (<= 512 words) | hello (<= 512 words) | trace
+constexpr unsigned HELLO_LIMIT_SOFT = 1u << 13;    // hello of a kernel that has a fallback: a few ms (a normal hello takes ~20 us)
+// exchange buffer header: word [0] status, word [1] "soft" flag (both cleared by dep_rnn_forward) | flags (<= 512 words) |
+// hello (<= 512 words) | trace (zeroed before every launch)
+//   soft flag: a forward kernel that needs every CU to itself (rnn_fused2.hip) could not assemble its clusters -- a foreign
+//   workgroup sat in the dispatcher.  It leaves WITHOUT raising the status; the co-schedule-tolerant per-layer kernels
+//   enqueued behind it run only when this word is set (dep_rnn_forward, api.hip) and redo the forward.
 constexpr size_t FLAG_OFF = 256, HELLO_OFF = 3328, TRACE_OFF = 6144, PAYLOAD_OFF = 8192;
 
 typedef unsigned long long u64;
@@ -77,7 +82,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
 // (plain stores are acknowledged by L2) and readers (sc1 loads bypass L1 and are served by L2), and a step's hand-off
 // costs L2 round trips instead of trips through the fabric.  1 = same XCD, 0 = not, -1 = gave up (status raised).
 // Every wave of the workgroup must call it (it contains two workgroup barriers).
-__device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, unsigned* status) {
+__device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, unsigned* status, unsigned* soft = nullptr) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc = 0x100u | (xcc & 0xffu);
@@ -88,7 +93,10 @@ __device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, 
         for (unsigned spins = 0;; ++spins) {
             const unsigned v = lane < NC ? ld_agent(hello + lane) : xcc;
             if (__all(v != 0)) { verdict = __all(v == xcc) ? 1 : 0; break; }
-            if (spins > SPIN_LIMIT) { st_agent(status, 5); verdict = -1; break; }
+            if (soft) {
+                if (spins > HELLO_LIMIT_SOFT) { st_agent(soft, 1); verdict = -1; break; }
+                if ((spins & 15) == 15 && ld_agent(soft) != 0) { verdict = -1; break; }
+            } else if (spins > SPIN_LIMIT) { st_agent(status, 5); verdict = -1; break; }
             if ((spins & 63) == 63 && ld_agent(status) != 0) { verdict = -1; break; }
             __builtin_amdgcn_s_sleep(1);
         }

@@ -46,6 +46,8 @@ struct FF {
     float* pooled; float pool_scale; float* hn0; float* hn1;
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes; int nofast;
     long long* trace;
+    unsigned* soft;          // fallback flag (rnn_cluster_common.h), or nullptr: a failed hello then raises the status word
+    int force_soft;          // test hook (DEP_FORCE_SOFT_FALLBACK=1): behave as if the hello had timed out
 };
 
 #define FSTAMP(slot) do { if (TRACE && trl && s >= 100 && s < 104) trl[(s - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -63,6 +65,8 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
     if (p.b0 + bt * BT >= p.B) return;
     if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up (sticky status)
+    if (p.soft && ld_agent(p.soft) != 0) return;   // dispatched after the clusters gave this launch up: the fallback kernels redo it
+    if (p.soft && p.force_soft) { if (threadIdx.x == 0) st_agent(p.soft, 1); return; }
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: role tests become scalar branches
     const int grp = w >> 2, gw = w & 3, jl = gw >> 1, kh = gw & 1;
@@ -107,7 +111,9 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
     unsigned* myflag = p.flags + bt * FNC + c;
     unsigned* tflags = p.flags + bt * FNC;
-    const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * FNC, FNC, c, p.status);
+    // (with a fallback the hello also runs under DEP_CLUSTER_NOFAST: it is what proves that every member is resident)
+    const int sxh = (p.nofast && !p.soft) ? 0 : cluster_same_xcd(p.hello + bt * FNC, FNC, c, p.status, p.soft);
+    const int sx = (p.nofast && sxh >= 0) ? 0 : sxh;
     if (sx < 0) return;
     const bool fast = sx == 1;
     const int b0t = p.b0 + bt * BT;                   // first utterance of the tile
@@ -385,6 +391,8 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
+    p.soft = a.soft_fallback ? (unsigned*)xbuf + 1 : nullptr;
+    { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] == '1') ? 1 : 0; } p.force_soft = fs; }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);

@@ -58,6 +58,9 @@ class _RnnCache:
     def status_word(self):
         return self.last.status_word() if getattr(self, 'last', None) is not None else None
 
+    def fallback_word(self):
+        return self.last.fallback_word() if getattr(self, 'last', None) is not None else None
+
 
 class _MLPHead:
     """[Dropout] -> Linear(H,H) -> ReLU -> Dropout -> [Linear(H,C)]   (fc_audio / fc_out Sequentials)."""
@@ -172,6 +175,10 @@ class AudioGRU(nn.Module):
         w = self._rnns.status_word()
         return [] if w is None else [w]
 
+    def fallback_words(self):
+        w = self._rnns.fallback_word()
+        return [] if w is None else [w]
+
     # encoder part shared with FusionNet
     def encode(self, x, training, seed):
         B, T, F = x.shape
@@ -266,6 +273,10 @@ class TextBiLSTM(nn.Module):
 
     def status_words(self):
         w = self._rnns.status_word()
+        return [] if w is None else [w]
+
+    def fallback_words(self):
+        w = self._rnns.fallback_word()
         return [] if w is None else [w]
 
     def sync_plan(self):
@@ -365,6 +376,9 @@ class FusionNet(nn.Module):
 
     def status_words(self):
         return [w for w in (self._rnn_t.status_word(), self._rnn_a.status_word()) if w is not None]
+
+    def fallback_words(self):
+        return [w for w in (self._rnn_a.fallback_word(),) if w is not None]
 
     def _split(self, x):
         """Accept the reference's list of (audio_i, text_i) pairs or an (audio, text) pair of arrays."""

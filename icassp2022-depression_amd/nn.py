@@ -232,6 +232,7 @@ class LossSum:
     def __init__(self, device):
         self._acc = torch.zeros((), dtype=torch.float64, device=device)
         self._bad = None
+        self._fell_back = None
         self._reduce = False
 
     def add(self, loss, model=None):
@@ -240,6 +241,8 @@ class LossSum:
         loss._reduce = False                              # summed here, once
         for w in (model.status_words() if model is not None and hasattr(model, 'status_words') else []):
             self._bad = w.clone() if self._bad is None else torch.maximum(self._bad, w)
+        for w in (model.fallback_words() if model is not None and hasattr(model, 'fallback_words') else []):
+            self._fell_back = w.clone() if self._fell_back is None else torch.maximum(self._fell_back, w)
         return self
 
     def item(self):
@@ -247,6 +250,8 @@ class LossSum:
             parallel.all_reduce_sum(self._acc)
             self._reduce = False
         v = float(self._acc.item())
+        if self._fell_back is not None and int(self._fell_back.item()) != 0:
+            L.note_fallback()                             # right results, but stop paying the hello time-out
         if self._bad is not None and int(self._bad.item()) != 0:
             raise L.DepError('a recurrent sweep gave up waiting for a cluster member during this epoch (status %d): the GPU was '
                              'shared with another kernel; DEP_FUSED2=0 DEP_CLUSTER16=0 selects the sweeps that tolerate it'

@@ -83,6 +83,16 @@ int dep_rnn_status(const dep_rnn_desc* d, void* workspace, void* stream);
  * With DEP_TRACE=1 workgroup 0 of the GRU sweeps leaves shader-clock stamps of its phases at +6144
  * (tools/trace_fwd.py, tools/trace_bwd.py). */
 size_t dep_rnn_workspace_xbuf_offset(const dep_rnn_desc* d);
+/* Kernels that need every CU to themselves.  The default GRU forward at H = 256 (both layers fused into one launch of twelve
+ * 168-register waves per CU) cannot share the GPU: a foreign workgroup in the dispatcher keeps its clusters from assembling.
+ * It then gives up within a few ms WITHOUT an error -- it sets the "soft" word (the uint32 after the status word, i.e. at
+ * dep_rnn_workspace_xbuf_offset() + 4) and the per-layer kernels enqueued behind it, which tolerate co-scheduled work and are
+ * no-ops otherwise, redo the forward: same reserve layout, results within the same 1e-4 of the reference, no host
+ * synchronisation, every data-parallel rank decides for itself on the device.  A host that finds the soft word set at a
+ * synchronisation point it has anyway should call dep_rnn_set_exclusive(0): later forwards then skip the attempt (and its
+ * time-out) for the rest of the process.  PROCESS-GLOBAL; default 1, or 0 with DEP_EXCLUSIVE=0 in the environment. */
+int dep_rnn_set_exclusive(int on);
+int dep_rnn_get_exclusive(void);
 
 /* ------------------------------------------------------------------ RNN stacks ----- */
 /* weights: array of 4*L*dirs device pointers ordered, for layer l and direction d (index
