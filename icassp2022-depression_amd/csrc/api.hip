@@ -233,7 +233,7 @@ extern "C" int dep_rnn_get_exclusive(void) { return dep_exclusive_on() ? 1 : 0; 
 static bool sweep_split_mode() {
     static int pin = -1;
     if (pin < 0) { const char* e = getenv("DEP_SWEEP_MODE"); pin = (e && e[0] == 'f') ? 1 : 0; }
-    return !pin && dep_get_gemm_mode() == 1;
+    return !pin && dep_get_gemm_mode() >= 1;        // mode 2 (single bf16 products in the GEMMs) keeps the split sweeps
 }
 
 // Precision mode of the packed recurrent-weight images a reserve holds (host-side record, no device traffic): the

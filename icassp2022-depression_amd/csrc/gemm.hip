@@ -8,6 +8,7 @@
 // nn.Linear layers of the heads (audio_gru_whole.py:67,70) and, in backward, dX = dG W and the
 // weight gradients dW = dG^T X (split-K over the B*T rows, deterministic two-pass reduction).
 #include <atomic>
+#include <string.h>
 #include "dep_common.h"
 
 namespace {
@@ -307,7 +308,7 @@ bool naive_forced() {
 // always exact.  Default: DEP_GEMM_MODE env ("f32" -> 0), else 1.
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
-                           int splits, int kchunk, float* part, bool vec, hipStream_t s);
+                           int splits, int kchunk, float* part, bool vec, hipStream_t s, int terms);
 static std::atomic<int> g_split_mode{-1};            // process-global (documented in dep_rnn.h)
 static std::atomic<long> g_split_min_macs{1L << 28};
 static thread_local const unsigned* g_only_if = nullptr;
@@ -315,10 +316,10 @@ void dep_gemm_set_predicate(const unsigned* only_if) { g_only_if = only_if; }
 const unsigned* dep_gemm_predicate() { return g_only_if; }
 static thread_local int g_force_exact = 0;       // per calling thread: 1 = this call is exact fp32, 2 = this call is bf16x3 whatever the global mode
 static void init_split_mode() {
-    if (g_split_mode < 0) { const char* e = getenv("DEP_GEMM_MODE"); g_split_mode = (e && e[0] == 'f') ? 0 : 1; }
+    if (g_split_mode < 0) { const char* e = getenv("DEP_GEMM_MODE"); g_split_mode = (e && e[0] == 'f') ? 0 : ((e && !strcmp(e, "bf16")) ? 2 : 1); }   // "f32" | "bf16" | default ("bf16x3")
 }
 extern "C" int dep_set_gemm_mode(int mode, long min_macs) {
-    if (mode != 0 && mode != 1) { dep_set_error("dep_set_gemm_mode: mode must be 0 (f32) or 1 (bf16x3 split)"); return DEP_ERR_ARG; }
+    if (mode < 0 || mode > 2) { dep_set_error("dep_set_gemm_mode: mode must be 0 (f32), 1 (bf16x3 split) or 2 (bf16 products)"); return DEP_ERR_ARG; }
     g_split_mode = mode;
     if (min_macs >= 0) g_split_min_macs = min_macs;
     return DEP_OK;
@@ -373,9 +374,9 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     dim3 g(p.gx * p.gy * splits);
     DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s, dep_gemm_predicate() == nullptr);
     init_split_mode();
-    if (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode == 1 && (long)M * N * K >= g_split_min_macs))
+    if (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs))
         return dep_gemm_bf16x3_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
-                                      splits, kchunk, p.part, vec, s);
+                                      splits, kchunk, p.part, vec, s, g_split_mode == 2 ? 1 : 3);
 #define LAUNCH(TA, TB)                                                                    \
     do {                                                                                   \
         if (vec) hipLaunchKernelGGL((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \

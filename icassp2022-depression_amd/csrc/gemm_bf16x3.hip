@@ -107,17 +107,26 @@ __device__ __forceinline__ void split4(f32x4 x, bf16x4& hi, bf16x4& lo) {
     lo = __builtin_bit_cast(bf16x4, l);
 }
 
+// hi plane only (single-product mode, see gemm_bf16x3's TERMS): two conversions per quad, nothing else
+__device__ __forceinline__ void hi4(f32x4 x, bf16x4& hi) {
+    const f32x2v v01 = {x[0], x[1]}, v23 = {x[2], x[3]};
+    const u32x2v h = {__builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2v)),
+                      __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2v))};
+    hi = __builtin_bit_cast(bf16x4, h);
+}
+
 // LDS images Sh/Sl: [ROWS rows (m or n)][LDK] bf16, k contiguous
-template <bool TR, int ROWS>
+template <bool TR, int ROWS, int TERMS = 3>
 __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, const float (&r)[ROWS / 32][4]) {
     const int a = tid & 7, bq = tid >> 3;
     if (!TR) {
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
             f32x4 x = {r[i][0], r[i][1], r[i][2], r[i][3]};
-            bf16x4 hi, lo; split4(x, hi, lo);
             const int o = (bq + 32 * i) * LDK + a * 4;
-            *reinterpret_cast<bf16x4*>(Sh + o) = hi; *reinterpret_cast<bf16x4*>(Sl + o) = lo;
+            bf16x4 hi, lo;
+            if constexpr (TERMS == 3) { split4(x, hi, lo); *reinterpret_cast<bf16x4*>(Sl + o) = lo; } else hi4(x, hi);
+            *reinterpret_cast<bf16x4*>(Sh + o) = hi;
         }
     } else {
 #pragma unroll
@@ -125,9 +134,10 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 f32x4 x = {r[jj * 4 + 0][e], r[jj * 4 + 1][e], r[jj * 4 + 2][e], r[jj * 4 + 3][e]};
-                bf16x4 hi, lo; split4(x, hi, lo);
                 const int o = ((bq + 32 * jj) * 4 + e) * LDK + a * 4;
-                *reinterpret_cast<bf16x4*>(Sh + o) = hi; *reinterpret_cast<bf16x4*>(Sl + o) = lo;
+                bf16x4 hi, lo;
+                if constexpr (TERMS == 3) { split4(x, hi, lo); *reinterpret_cast<bf16x4*>(Sl + o) = lo; } else hi4(x, hi);
+                *reinterpret_cast<bf16x4*>(Sh + o) = hi;
             }
     }
 }
@@ -139,7 +149,10 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
 // Tile = BMT x 128 (BMT = 256 for the big contractions: these kernels are bound by the L2 -> CU operand feed, not by
 // the matrix pipes, and a 256-row tile moves 25 % fewer operand bytes per flop than 128 x 128), 4 waves as 2 x 2,
 // each (BMT/2) x 64 = (BMT/64) x 2 MFMA tiles of 32x32.
-template <bool TA, bool TB, bool VEC, int BMT>
+// TERMS = 3: the split-precision product (default).  TERMS = 1: a_hi * b_hi only -- plain bf16 products with fp32 accumulation
+// (dep_set_gemm_mode(2), the "bf16" throughput mode of BASELINE configs[1]: a third of the MFMAs, no lo planes; relative error
+// per product ~4e-3, so it is a separately labelled mode with its own tolerance, never the parity path).
+template <bool TA, bool TB, bool VEC, int BMT, int TERMS = 3>
 __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p) {
     if (p.only_if && *p.only_if == 0) return;
     constexpr bool A_TR = TA, B_TR = !TB;
@@ -185,8 +198,8 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
 
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             if (!(p.ablate & 8) || k0 == kbeg) {
-                store_tile<A_TR, BMT>(Ah, Al, tid, ra);
-                store_tile<B_TR, BN>(Bh, Bl, tid, rb);
+                store_tile<A_TR, BMT, TERMS>(Ah, Al, tid, ra);
+                store_tile<B_TR, BN, TERMS>(Bh, Bl, tid, rb);
             }
             __syncthreads();
             if (!(p.ablate & 4)) {
@@ -206,12 +219,14 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const int ro = (wm * (BMT / 2) + i * 32 + l31) * LDK + ko;
-                    ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro); al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
+                    ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro);
+                    if constexpr (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int ro = (wn * 64 + j * 32 + l31) * LDK + ko;
-                    bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro); bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro);
+                    if constexpr (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -219,8 +234,10 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
                     for (int j = 0; j < 2; ++j) {
                         // operands swapped (D = B-rows x A-rows^T): a lane then owns ONE output row m = l31 and, per register
                         // quad, 4 consecutive n -> the epilogue stores 16 bytes per lane instead of 4
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        if constexpr (TERMS == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
                     }
             }
@@ -632,13 +649,13 @@ __global__ void splitk_reduce2(const unsigned* only_if, const float* __restrict_
 // Same contract as dep_gemm_internal (gemm.hip); `splits` is decided by the caller's shared heuristic.
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
-                           int splits, int kchunk, float* part, bool vec, hipStream_t s) {
+                           int splits, int kchunk, float* part, bool vec, hipStream_t s, int terms) {
     static int abl = -1, persist = -1, bm256 = -1, wsd = -2;
     if (abl < 0) { const char* e = getenv("DEP_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
     if (wsd == -2) { const char* e = getenv("DEP_GEMM_WS"); wsd = e ? atoi(e) : 0; if (wsd < 0 || wsd > 4) wsd = 0; }
     // (32-bit lane offsets: every operand must span less than 4 GB)
     const size_t spanA = (size_t)(transA ? K : M) * lda * 4, spanB = (size_t)(transB ? N : K) * ldb * 4;
-    if (wsd > 0 && M >= 256 && spanA < (1ull << 32) && spanB < (1ull << 32)) {
+    if (wsd > 0 && terms == 3 && M >= 256 && spanA < (1ull << 32) && spanB < (1ull << 32)) {
         // wave-specialised kernel: one 8-wave workgroup per CU, 256 x 128 tiles, `wsd` register sets of prefetch
         GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl, dep_gemm_predicate()};
         const int ntiles = p.gx * p.gy * splits;
@@ -679,17 +696,19 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     const int ntiles = p.gx * p.gy * splits;
     const int cap = big ? persist * 2 / 3 : persist;              // 2 resident workgroups per CU with 256-row tiles, 3 otherwise
     dim3 g(ntiles < cap ? (ntiles + 7) / 8 * 8 : cap / 8 * 8);
-#define LAUNCH(TA, TB)                                                                               \
+#define LAUNCH1(TA, TB, TERMS)                                                                       \
     do {                                                                                             \
-        if (big) { if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, 256>), g, dim3(NT), 0, s, p);      \
-                   else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false, 256>), g, dim3(NT), 0, s, p); }   \
-        else     { if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, 128>), g, dim3(NT), 0, s, p);      \
-                   else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false, 128>), g, dim3(NT), 0, s, p); }   \
+        if (big) { if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, 256, TERMS>), g, dim3(NT), 0, s, p);      \
+                   else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false, 256, TERMS>), g, dim3(NT), 0, s, p); }   \
+        else     { if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, 128, TERMS>), g, dim3(NT), 0, s, p);      \
+                   else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false, 128, TERMS>), g, dim3(NT), 0, s, p); }   \
     } while (0)
+#define LAUNCH(TA, TB) do { if (terms == 1) LAUNCH1(TA, TB, 1); else LAUNCH1(TA, TB, 3); } while (0)
     if (!transA && transB) LAUNCH(false, true);
     else if (!transA && !transB) LAUNCH(false, false);
     else LAUNCH(true, false);
 #undef LAUNCH
+#undef LAUNCH1
     DEP_CHECK_LAUNCH();
     if (splits > 1) {
         const long n = (long)M * N;

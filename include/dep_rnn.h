@@ -206,7 +206,10 @@ int dep_gemm_bf16x3(int transA, int transB, int M, int N, int K,
                     const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     const float* bias, float beta, int seq_T, int shiftB,
                     void* workspace, size_t workspace_bytes, void* stream);
-int dep_set_gemm_mode(int mode, long min_macs);   /* PROCESS-GLOBAL. mode 0 exact f32 | 1 bf16x3 split ; min_macs < 0 keeps it */
+/* mode 2 (DEP_GEMM_MODE=bf16) is the THROUGHPUT mode BASELINE configs[1] calls "bf16": the large contractions form a_hi * b_hi only
+ * (plain bf16 products, fp32 accumulation; a third of the MFMAs).  Relative error per product ~4e-3: it cannot meet the path's
+ * 1e-4 parity bar, is never the default and is benchmarked on its own labelled line (bench.py extra.bf16_products). */
+int dep_set_gemm_mode(int mode, long min_macs);   /* PROCESS-GLOBAL. mode 0 exact f32 | 1 bf16x3 split | 2 bf16 products ; min_macs < 0 keeps it */
 int dep_get_gemm_mode(void);
 
 /* nn.LayerNorm(F) over the last axis (audio_gru_whole.py:62,104). rows = B*T.

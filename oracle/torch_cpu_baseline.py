@@ -3,7 +3,7 @@
 The reference's CPU path *is* stock PyTorch (`'cuda': False` in every script), and its files cannot travel
 to the GPU box, so this module restates the two benchmarked layer stacks on stock torch.nn (allowed here:
 the "no torch.nn.GRU/LSTM" rule governs the HIP product path, not the CPU yardstick -- SURVEY 8d).
-tests/test_oracle_golden.py::test_torch_baseline_matches_reference_fixture loads the reference's own
+tests/test_host_cpu.py::test_torch_baseline_matches_reference_fixture (and ..._fusion_...) loads the reference's own
 state_dict fixture into these classes and checks identical outputs, so timing them is timing the
 reference's arithmetic (kind = "port").
 

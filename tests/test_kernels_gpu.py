@@ -66,6 +66,30 @@ def test_gemm_bf16x3_split_accuracy(tA, tB, M, N, K):
     assert err.mean() < 2e-6
 
 
+@pytest.mark.parametrize('tA,tB,M,N,K', [(0, 1, 1200, 768, 256), (0, 0, 1300, 260, 768), (1, 0, 768, 256, 4096)])
+def test_gemm_bf16_products_mode_has_its_own_tolerance(tA, tB, M, N, K):
+    """dep_set_gemm_mode(2): a_hi * b_hi only (the "bf16" throughput mode, never the parity path).  Error relative to
+    sum_k |a||b| is ~1e-3 -- two orders above the 3-term split's bound, which proves the mode is really in effect -- and bounded."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32).astype(np.float64)
+    B = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32).astype(np.float64)
+    opA = A.T if tA else A; opB = B.T if tB else B
+    ref = opA @ opB
+    scale = np.abs(opA) @ np.abs(opB)
+    a, b = dev(A), dev(B)
+    c = torch.empty(M, N, device=DEV)
+    ws = L.gemm_ws(tA, tB, M, N, K, DEV)
+    L.set_gemm_mode(2)
+    try:
+        L.gemm_split(tA, tB, M, N, K, a, a.stride(0), b, b.stride(0), c, N, ws=ws)
+    finally:
+        L.set_gemm_mode(1)
+    err = np.abs(host(c) - ref) / scale
+    assert 2e-5 < err.max() < 1e-2, err.max()
+    L.gemm_split(tA, tB, M, N, K, a, a.stride(0), b, b.stride(0), c, N, ws=ws)
+    assert (np.abs(host(c) - ref) / scale).max() < 1.5e-5          # and the default mode is back
+
+
 def test_gemm_bf16x3_shift_and_splitk_match_exact_kernel():
     rng = np.random.default_rng(15)
     Bsz, T, M, N = 9, 300, 96, 64

@@ -228,3 +228,76 @@ def test_transplant_name_mismatch_behaviour():
     assert np.array_equal(sd['lstm_net_audio.weight_ih_l0'].cpu().numpy(), ga['sd']['lstm_net_audio.weight_ih_l0'])
     assert np.array_equal(sd['ln.weight'].cpu().numpy(), ga['sd']['ln.weight'])
     assert [p.name for p in model.parameters() if p.requires_grad] == ['fc_final.0.weight']
+
+
+def test_initial_weight_distributions_follow_the_reference_constructors():
+    """AudioBiLSTM keeps PyTorch's defaults -- every GRU tensor and every Linear weight / bias ~ U(-1/sqrt(fan), 1/sqrt(fan))
+    with fan = H for the GRU and in_features for a Linear, `init_weight` is NOT called (audio_gru_whole.py:36); TextBiLSTM.init_weight
+    (text_bilstm_whole.py:37-43) puts xavier_uniform on every `weight` (LSTM matrices included: bound sqrt(6 / (rows + cols))) and 0 on
+    every `bias`, except names containing 'ln' (LayerNorm stays ones / zeros).  Checked on the bounds (hard) and on the spread
+    (std of U(-a, a) = a / sqrt(3), 10 % slack on the large tensors)."""
+    import math
+    H, F = 64, 48
+    cfg = dict(audio_gru_whole.config); cfg.update(embedding_size=F, hidden_dims=H)
+    sd = {k: v.cpu().numpy() for k, v in audio_gru_whole.AudioBiLSTM(cfg, seed=11).state_dict().items()}
+    for name, v in sd.items():
+        if name.startswith('lstm_net_audio.'):
+            a = 1 / math.sqrt(H)
+        elif name.startswith('fc_audio.') or name.startswith('attention_layer.'):
+            a = 1 / math.sqrt(H)                                   # every Linear of the audio model has in_features = H
+        elif name == 'ln.weight':
+            assert np.all(v == 1); continue
+        elif name == 'ln.bias':
+            assert np.all(v == 0); continue
+        else:
+            continue
+        assert np.abs(v).max() <= a * (1 + 1e-6), name
+        if v.size >= 2048:
+            assert abs(v.std() - a / math.sqrt(3)) < 0.1 * a / math.sqrt(3), (name, v.std())
+            assert abs(v.mean()) < 0.05 * a, name
+    Ht, Ft = 32, 40
+    cfg = dict(text_bilstm_whole.config); cfg.update(embedding_size=Ft, hidden_dims=Ht)
+    sd = {k: v.cpu().numpy() for k, v in text_bilstm_whole.TextBiLSTM(cfg, seed=12).state_dict().items()}
+    seen_w = 0
+    for name, v in sd.items():
+        if 'ln' in name:
+            assert np.all(v == (1 if name.endswith('weight') else 0)), name
+        elif 'bias' in name:
+            assert np.all(v == 0), name
+        elif 'weight' in name:
+            a = math.sqrt(6.0 / (v.shape[0] + v.shape[1]))
+            assert np.abs(v).max() <= a * (1 + 1e-6), name
+            if v.size >= 2048:
+                assert abs(v.std() - a / math.sqrt(3)) < 0.1 * a / math.sqrt(3), (name, v.std())
+            seen_w += 1
+    assert seen_w >= 2 * 2 * 2 + 3                                 # 8 LSTM matrices + attention + two head Linears
+
+
+def test_bf16_products_mode_stays_within_its_own_tolerance():
+    """BASELINE configs[1] says "bf16": dep_set_gemm_mode(2) forms the LARGE contractions from single bf16 products (small ones stay
+    exact, the recurrent sweeps keep the 3-term split).  Not the parity path: against the default mode -- which is pinned to the
+    reference within 1e-4 -- outputs and loss must stay within 5e-3 and the gradients within 25 % of their largest entry (a random
+    model's gradients are small differences of large sums: bf16 products show there first), and must
+    NOT coincide (the mode is really on)."""
+    from icassp2022_depression_amd import _lib as L_
+    B, T, F, H = 64, 100, 256, 256
+    cfg = dict(audio_gru_whole.config); cfg.update(embedding_size=F, hidden_dims=H, dropout=0.0)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B, T, F)).astype(np.float32); y = rng.integers(0, 2, B)
+    res = {}
+    for mode in (1, 2):
+        L_.set_gemm_mode(mode, 1 << 28)
+        try:
+            model = audio_gru_whole.AudioBiLSTM(cfg, seed=4)
+            model.eval(); out = model(x).numpy()
+            model.train()
+            loss = nn.CrossEntropyLoss()(model(x), y); loss.backward()
+            res[mode] = (out, loss.item(), {k: p.grad.cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            L_.set_gemm_mode(1, 1 << 28)
+    d_out = np.abs(res[1][0] - res[2][0]).max()
+    assert 1e-7 < d_out < 5e-3, d_out
+    assert abs(res[1][1] - res[2][1]) < 5e-3
+    for k in ('lstm_net_audio.weight_ih_l0', 'lstm_net_audio.weight_hh_l1', 'lstm_net_audio.weight_ih_l1', 'fc_audio.1.weight'):
+        a1, a2 = res[1][2][k], res[2][2][k]
+        assert np.abs(a1 - a2).max() <= 0.25 * np.abs(a1).max() + 1e-9, k
