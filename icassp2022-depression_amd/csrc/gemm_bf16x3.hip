@@ -31,6 +31,7 @@ struct GemmP {
     int gx, gy;             // tile grid (x: N tiles, y: M tiles); the launch is 1-D, see dep_xcd_tile
     int ablate;             // debug (DEP_GEMM_ABLATE): 1 no epilogue stores, 2 no MFMA, 4 no tile reloads, 8 no LDS staging
     const unsigned* only_if;    // run only if this device word is non-zero (dep_gemm_set_predicate), or nullptr
+    int xcd_lo, xcd_n;          // experiment (dep_gemm_set_xcds): only the workgroups of XCDs [xcd_lo, xcd_lo + xcd_n) work; 0, 8 = all
 };
 
 // Operand tile of ROWS (128 or 256) rows x 32 k, 256 threads: a = tid&7, bq = tid>>3.
@@ -165,8 +166,10 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
     const int half = lane >> 5, l31 = lane & 31;
 
     const int ntiles = p.gx * p.gy * p.splits;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    const int q = ntiles / 8, r = ntiles % 8;
+    const int x8 = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    if (x8 < p.xcd_lo || x8 >= p.xcd_lo + p.xcd_n) return;
+    const int xcd = x8 - p.xcd_lo;
+    const int q = ntiles / p.xcd_n, r = ntiles % p.xcd_n;
     const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int hi = lo + (xcd < r ? q + 1 : q);
     int tile = lo + slot;
@@ -646,6 +649,10 @@ __global__ void splitk_reduce2(const unsigned* only_if, const float* __restrict_
 
 }  // namespace
 
+// experiment hook: confine the persistent kernel's working workgroups to a range of XCDs (per calling thread)
+static thread_local int g_xcd_lo = 0, g_xcd_n = 8;
+extern "C" int dep_gemm_set_xcds(int lo, int n) { if (lo < 0 || n < 1 || lo + n > 8) return DEP_ERR_ARG; g_xcd_lo = lo; g_xcd_n = n; return DEP_OK; }
+
 // Same contract as dep_gemm_internal (gemm.hip); `splits` is decided by the caller's shared heuristic.
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
@@ -657,7 +664,7 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     const size_t spanA = (size_t)(transA ? K : M) * lda * 4, spanB = (size_t)(transB ? N : K) * ldb * 4;
     if (wsd > 0 && terms == 3 && M >= 256 && spanA < (1ull << 32) && spanB < (1ull << 32)) {
         // wave-specialised kernel: one 8-wave workgroup per CU, 256 x 128 tiles, `wsd` register sets of prefetch
-        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl, dep_gemm_predicate()};
+        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl, dep_gemm_predicate(), 0, 8};
         const int ntiles = p.gx * p.gy * splits;
         int ncu = 256;
         { static int cus = -1; if (cus < 0) { hipDeviceProp_t pr; int dv = 0; cus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; } ncu = cus / 8 * 8; if (ncu < 8) ncu = 8; }
@@ -691,11 +698,12 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     // measured at cfg2: 256-row tiles win 8-10 % on the NN (dX) and TN (dW) forms, lose 6 % on the short-K NT projection
     const bool big = bm256 && M >= 512 && !(!transA && transB);
     const int BMT = big ? 256 : 128;
-    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl, dep_gemm_predicate()};
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl, dep_gemm_predicate(), g_xcd_lo, g_xcd_n};
     // persistent launch: at most `persist` workgroups (a multiple of 8: one share per XCD), each walks a list of tiles
     const int ntiles = p.gx * p.gy * splits;
     const int cap = big ? persist * 2 / 3 : persist;              // 2 resident workgroups per CU with 256-row tiles, 3 otherwise
-    dim3 g(ntiles < cap ? (ntiles + 7) / 8 * 8 : cap / 8 * 8);
+    const int per_xcd = (ntiles + g_xcd_n - 1) / g_xcd_n;
+    dim3 g((per_xcd < cap / 8 ? per_xcd : cap / 8) * 8);
 #define LAUNCH1(TA, TB, TERMS)                                                                       \
     do {                                                                                             \
         if (big) { if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, 256, TERMS>), g, dim3(NT), 0, s, p);      \

@@ -33,6 +33,7 @@ struct P2 {
     int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
     long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
     int trall_off;           // debug: LDS offset (32-bit words) of the per-step stamp array
+    int xhalf;               // experiment (DEP_BWD_XHALF=1): the sweep's workgroups on XCDs 0-3 only, two per CU; the launch has twice the blocks and those of XCDs 4-7 leave at once
 };
 
 struct StepIn { float2 r, z, n, hn, hp, dy; };
@@ -66,7 +67,12 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     constexpr int KS = 96, KCB = KS / 16, LDG = KS + LPAD;
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane (208-byte rows)
     const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
-    const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
+    int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
+    if (p.xhalf) {                                    // block 8k + x, x < 4  ->  member k / (nbtp/4) of tile (k % (nbtp/4)) * 4 + x: a tile's members share XCD x
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+        if (x >= 4) return;
+        c = k / (p.nbtp / 4); bt = (k % (p.nbtp / 4)) * 4 + x;
+    }
     if (p.b0 + bt * BT >= p.B) return;
     if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -702,8 +708,12 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
     static int kb_env = -1;                           // DEP_BWD_BURST=0: the round-1 kernel (every wave streams for itself, every step); 4 (default) or 6: burst length
     if (kb_env < 0) { const char* v = getenv("DEP_BWD_BURST"); kb_env = v ? atoi(v) : 4; if (kb_env != 0 && kb_env != 4 && kb_env != 6) kb_env = 4; }
-    const int kb = a.H >= 512 ? 0 : kb_env;           // H = 512: 192 weight registers per compute wave leave no room for a second wave per SIMD
-    const size_t lds = (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
+    static int xhalf_env = -1;
+    if (xhalf_env < 0) { const char* v = getenv("DEP_BWD_XHALF"); xhalf_env = (v && v[0] == '1') ? 1 : 0; }
+    p.xhalf = (xhalf_env && a.H == 256 && a.B <= CH) ? 1 : 0;
+    const int kb = (a.H >= 512 || p.xhalf) ? 0 : kb_env;           // H = 512: 192 weight registers per compute wave leave no room for a second wave per SIMD
+    const size_t lds = p.xhalf ? (size_t)49152 + 2048
+                               : (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
     p.trall_off = (int)((lds - 2048) / 4);
     static bool attr_b = false;
     if (!attr_b) {
@@ -721,7 +731,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
-        dim3 grid(NC * p.nbtp);
+        dim3 grid(NC * p.nbtp * (p.xhalf ? 2 : 1));
         const dim3 block(kb ? CT + SVC_THREADS : CT);
 #define DEP_BWD_LAUNCH(N, S)                                                                                              \
         do { if (kb == 4) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 4>), grid, block, lds, a.stream, p);               \
