@@ -96,7 +96,8 @@ def main():
     ap.add_argument('--workload', default='audio_gru', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-run', action='store_true', help='warm-up + timed steps only (rocprofv3 passes: every launch belongs to a train step)')
-    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (gloo: launch check on CPU)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend (gloo: launch check on CPU, or a dry run of the N-rank bench with the ranks sharing one GPU)')
     ap.add_argument('--launch-check', action='store_true', help='only exercise the N-rank launch + one all-reduce')
     args = ap.parse_args()
 
@@ -112,7 +113,7 @@ def main():
     if world_env > 1:
         # init_from_env builds the C-ABI's own RCCL communicator too (per-layer ranges overlapped with the backward pass); if it
         # cannot be built on EVERY rank all ranks agree to fall back -- visibly, in `config.backend` -- to torch.distributed
-        parallel.init_from_env('nccl')
+        parallel.init_from_env(args.backend)        # 'gloo': dry run of the multi-rank logic with the ranks sharing the visible GPUs
         comm_kind = {'rccl-native': 'rccl via dep_comm_* (layer ranges overlapped with backward)',
                      'torch.distributed': 'rccl via torch.distributed (single bucket after backward): ' + str(parallel._native.get('why'))
                      }.get(parallel.transport(), parallel.transport())
@@ -120,7 +121,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the process group has {world} ranks '
                          f'(WORLD_SIZE={os.environ.get("WORLD_SIZE")}): refusing to report an N={args.gpus} number')
-    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
 
     modname, cls, B, T, F, H = WORKLOADS[args.workload]
@@ -198,6 +199,8 @@ def main():
         e1.record(); torch.cuda.synchronize()
         mine = torch.tensor([e0.elapsed_time(e1) / 10], device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
+        if dist.get_backend() != 'nccl':
+            mine = mine.cpu(); allr = [t.cpu() for t in allr]
         dist.all_gather(allr, mine)
         comm_alone = [round(float(t.item()), 4) for t in allr]
 
