@@ -235,3 +235,42 @@ def device_labels(targets, device, num_classes=None):
             raise IndexError(f'Target {bad} is out of bounds for {num_classes} classes')
         return torch.as_tensor(t, device=device)
     return torch.as_tensor(t.astype(np.float32), device=device)
+
+
+class PairFeeder:
+    """The fusion scripts' list of [audio_i, text_i] pairs (fuse_net_whole.py:27, grown by append in the fold loop) as two
+    HBM-resident fp32 tensors, stacked and uploaded once per (list object, length); rows(a, b) = the (audio, text) tensors of
+    idxs[a:b], which `fusion_net.pretrained_feature` accepts in place of the list slice.  Lists whose items differ in shape keep
+    the per-batch path (rows() then returns the list slice itself)."""
+
+    def __init__(self, pairs, idxs, device):
+        self.pairs = pairs
+        self.idxs = [int(i) for i in idxs]
+        self.device = device
+        self.ok = False
+        n = len(pairs)
+        if n == 0:
+            return
+        hit = _dev_cache.get('fuse_pairs')
+        key = (n, np.asarray(pairs[0][0]).shape, np.asarray(pairs[0][1]).shape, str(device),
+               float(np.asarray(pairs[0][0], dtype=np.float64).sum() + np.asarray(pairs[-1][1], dtype=np.float64).sum()))
+        if hit is not None and hit[0] is pairs and hit[1] == key:
+            self.Xa, self.Xt = hit[2]
+        else:
+            try:
+                xa = np.stack([np.asarray(e[0], dtype=np.float32) for e in pairs])
+                xt = np.stack([np.asarray(e[1], dtype=np.float32) for e in pairs])
+            except ValueError:                            # ragged items: no stacked copy
+                return
+            if (xa.size + xt.size) * 4 > float(os.environ.get('DEP_FEATURES_HBM_GB', '64')) * 2 ** 30:
+                return
+            self.Xa, self.Xt = torch.from_numpy(xa).to(device), torch.from_numpy(xt).to(device)
+            _dev_cache['fuse_pairs'] = (pairs, key, (self.Xa, self.Xt))
+        self.idx_dev = torch.as_tensor(np.asarray(self.idxs, dtype=np.int64), device=device)
+        self.ok = True
+
+    def rows(self, a, b):
+        if not self.ok:
+            return [self.pairs[i] for i in self.idxs[a:b]]
+        sel = self.idx_dev[a:b]
+        return (self.Xa.index_select(0, sel), self.Xt.index_select(0, sel))

@@ -94,18 +94,18 @@ def train(model, epoch):
     total = nn.LossSum(model.device)                 # device-side sum of the step losses, read once per epoch
     preds = []
     idx = list(train_dep_idxs) + list(train_non_idxs)
-    X_train = [fuse_features[i] for i in idx]
     Y_train = [fuse_targets[i] for i in idx]
-    for lo, hi in _common.minibatches(len(X_train), config['batch_size']):
+    feed = _common.PairFeeder(fuse_features, idx, model.device)
+    for lo, hi in _common.minibatches(len(idx), config['batch_size']):
         a, b = _common.rank_slice(lo, hi)
         parallel.set_global_count(hi - lo)
-        x, y = X_train[a:b], Y_train[a:b]
+        y = Y_train[a:b]
         if b <= a:                                  # empty shard of a small mini-batch: zero-contribution step
             total.add(nn.empty_shard_step(model, optimizer))
             preds.append(torch.zeros(hi - lo, device=model.device))
             continue
         optimizer.zero_grad()
-        text_feature, audio_feature = model.pretrained_feature(x)
+        text_feature, audio_feature = model.pretrained_feature(feed.rows(a, b))
         output = model(torch.cat((text_feature, audio_feature), dim=1))
         loss = criterion(text_feature, audio_feature, y, model)
         loss.backward()
@@ -135,11 +135,11 @@ def evaluate(model, fold, train_mae):
     total_loss = 0
     pred = np.array([])
     idx = list(test_dep_idxs) + list(test_non_idxs)
-    X_test = [fuse_features[i] for i in idx]
     Y_test = [fuse_targets[i] for i in idx]
-    for lo, hi in _common.minibatches(len(X_test), config['batch_size']):
-        x, y = X_test[lo:hi], Y_test[lo:hi]
-        text_feature, audio_feature = model.pretrained_feature(x)
+    feed = _common.PairFeeder(fuse_features, idx, model.device)
+    for lo, hi in _common.minibatches(len(idx), config['batch_size']):
+        y = Y_test[lo:hi]
+        text_feature, audio_feature = model.pretrained_feature(feed.rows(lo, hi))
         output = model(torch.cat((text_feature, audio_feature), dim=1))
         loss = criterion(text_feature, audio_feature, y, model)
         pred = np.hstack((pred, output.data.flatten().cpu().numpy()))

@@ -103,16 +103,18 @@ def train(epoch, train_idxs):
     model.train()
     total = nn.LossSum(model.device)                 # device-side sum of the step losses, read once per epoch
     correct_dev = torch.zeros((), dtype=torch.int64, device=model.device)      # counted on the device, read once per epoch
-    X_train = [fuse_features[idx] for idx in train_idxs]
+    n_train = len(train_idxs)
     Y_train = [fuse_targets[idx] for idx in train_idxs]
-    for lo, hi in _common.minibatches(len(X_train), config['batch_size']):
-        x, y = _batch(X_train, Y_train, lo, hi)
+    feed = _common.PairFeeder(fuse_features, train_idxs, model.device)       # the pairs X_train = [fuse_features[i] ...], in HBM
+    for lo, hi in _common.minibatches(n_train, config['batch_size']):
+        a, b = _common.rank_slice(lo, hi)
+        y = Y_train[a:b]
         parallel.set_global_count(hi - lo)
-        if len(x) == 0:                             # empty shard of a small mini-batch (batch_size 2 < world): zero-contribution step
+        if b <= a:                             # empty shard of a small mini-batch (batch_size 2 < world): zero-contribution step
             total.add(nn.empty_shard_step(model, optimizer))
             continue
         optimizer.zero_grad()
-        text_feature, audio_feature = model.pretrained_feature(x)
+        text_feature, audio_feature = model.pretrained_feature(feed.rows(a, b))
         concat_x = torch.cat((text_feature, audio_feature), dim=1)
         output = model(concat_x)
         pred = output.data.max(1, keepdim=True)[1]
@@ -129,8 +131,8 @@ def train(epoch, train_idxs):
     train_acc = correct
     if parallel.rank() == 0:
         print('Train Epoch: {:2d}\t Learning rate: {:.4f}\tLoss: {:.6f}\t Accuracy: {}/{} ({:.0f}%)\n '.format(
-            epoch, config['learning_rate'], total_loss / len(X_train), correct, len(X_train),
-            100. * correct / len(X_train)))
+            epoch, config['learning_rate'], total_loss / n_train, correct, n_train,
+            100. * correct / n_train))
 
 
 def evaluate(model, test_idxs, fold, train_idxs):
@@ -139,18 +141,18 @@ def evaluate(model, test_idxs, fold, train_idxs):
     model.eval()
     total_loss = 0
     preds = []
-    X_test = [fuse_features[idx] for idx in test_idxs]
     Y_test = [fuse_targets[idx] for idx in test_idxs]
-    for lo, hi in _common.minibatches(len(X_test), config['batch_size']):
-        x, y = X_test[lo:hi], Y_test[lo:hi]
-        text_feature, audio_feature = model.pretrained_feature(x)
+    feed = _common.PairFeeder(fuse_features, test_idxs, model.device)
+    for lo, hi in _common.minibatches(len(Y_test), config['batch_size']):
+        y = Y_test[lo:hi]
+        text_feature, audio_feature = model.pretrained_feature(feed.rows(lo, hi))
         output = model(torch.cat((text_feature, audio_feature), dim=1))
         loss = criterion(text_feature, audio_feature, y, model)
         preds.append(output.data.max(1, keepdim=True)[1])
         total_loss += loss.item()
     pred = torch.cat(preds).cpu()
     y_test_pred, conf_matrix = model_performance(Y_test, pred)
-    print('\nTest set: Average loss: {:.4f}'.format(total_loss / len(X_test)))
+    print('\nTest set: Average loss: {:.4f}'.format(total_loss / len(Y_test)))
     print('Calculating additional test metrics...')
     accuracy, precision, recall, f1_score = _common.prf(conf_matrix)
     print("Accuracy: {}".format(accuracy))

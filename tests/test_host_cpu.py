@@ -273,6 +273,8 @@ def _order_worker(rank, world, port, q, modname):
         def _rows(self, x):
             if isinstance(x, list):                         # fusion: list of (audio, text) pairs
                 return torch.tensor([float(np.asarray(p[0]).sum()) for p in x])
+            if isinstance(x, tuple):                        # fusion: (audio, text) tensors from _common.PairFeeder
+                return x[0].reshape(x[0].shape[0], -1).sum(1)
             return x.reshape(x.shape[0], -1).sum(1)
 
         def __call__(self, x):
