@@ -88,6 +88,7 @@ struct Layout {
     bool drop;
     bool cluster;                    // cluster-parallel sweeps (rnn_cluster*.hip)
     bool cluster16;                  // forward with 16-unit members, two workgroups per CU (rnn_cluster16.hip)
+    bool dg4;                        // GRU cluster backward: gate gradients as ONE (B*T, 4H) array [dr | dz | dn | dn*r] (dW_hh is then one contraction)
     bool cluster16_bwd;              // same for the backward (slower than 32-unit members: A/B only, DEP_CLUSTER16_BWD=1)
     bool fused2;                     // 2-layer GRU, H = 256: both layers in one launch (rnn_fused2.hip), split-precision mode only
     size_t wih_img;                  // workspace: packed W_ih of layer 1 for the fused forward
@@ -123,7 +124,7 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     // the generic sweep.  (Sized for the larger; dep_finish_db sums the rows the sweep that ran has written: dbpart_rows.)
     lo.nwg = dep_sweep_num_wg(d->B, d->H, d->impl);
     size_t w = 0;
-    lo.gi = w; w += al(lo.BT * D * G * H);                 // GI (fwd) / dGI (bwd)
+    lo.gi = w; w += al(lo.BT * D * (G + (d->cell == DEP_CELL_GRU && d->training ? 1 : 0)) * H);     // GI (fwd) / dGI (bwd; GRU: room for the 4H-wide [dr|dz|dn|dn*r] rows)
     lo.dghn = w; w += al(lo.BT * H);
     const size_t maxin = D * H > (size_t)d->F ? D * H : (size_t)d->F;
     lo.dx[0] = w; w += al(lo.BT * D * H);
@@ -150,6 +151,7 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     lo.cluster = cok && (d->impl == 0 || d->impl == 3);
     lo.cluster16 = lo.cluster && dep_cluster16_ok(d->cell, d->H, d->B);
     { const char* e = getenv("DEP_CLUSTER16_BWD"); lo.cluster16_bwd = lo.cluster16 && e && e[0] == '1'; }
+    { const char* e = getenv("DEP_DG4"); lo.dg4 = lo.cluster && d->cell == DEP_CELL_GRU && d->dirs == 1 && !lo.cluster16_bwd && !(e && e[0] == '0'); }
     lo.xbuf = w; lo.xbuf_bytes = !lo.cluster ? 0 : (d->cell == DEP_CELL_GRU ? dep_cluster_xbuf_bytes(d->cell, d->H, d->B, d->dirs)
                                                                 : dep_cluster_lstm_xbuf_bytes(d->H, d->B, d->dirs));
     if (lo.cluster) lo.nwg = dep_cdiv(d->B, 16);      // the cluster sweeps write one row per tile whatever the tile-MFMA sweep could do at this H
@@ -526,7 +528,10 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         a.pool_scale = d->pool == DEP_POOL_MEAN ? 1.0f / (float)T : 1.0f;
         a.dh_n = dh_n ? dh_n + (size_t)l * D * B * H : nullptr;
         a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3];
-        a.dgi = dgi; a.dghn = W + lo.dghn; a.dbpart = W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
+        const int ldg = lo.dg4 ? 4 * H : D * G * H;                  // row stride of the gate-gradient array
+        float* dghn = lo.dg4 ? dgi + 3 * H : W + lo.dghn;
+        a.dgi = dgi; a.dghn = dghn; a.lddg = lo.dg4 ? ldg : 0; a.lddghn = lo.dg4 ? ldg : 0;
+        a.dbpart = W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
         rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
@@ -553,7 +558,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         if (dxl) {
             for (int dd = 0; dd < D; ++dd) {
                 const float* const* wl = weights + (size_t)(l * D + dd) * 4;
-                rc = dep_gemm_internal(0, 0, BTr, Kl, G * H, dgi + (size_t)dd * G * H, D * G * H, wl[0], Kl, dxl, Kl, nullptr,
+                rc = dep_gemm_internal(0, 0, BTr, Kl, G * H, dgi + (size_t)dd * G * H, ldg, wl[0], Kl, dxl, Kl, nullptr,
                                        dd == 0 ? 0.f : 1.f, 0, 0, nullptr, 0, s);
                 if (rc) return rc;
             }
@@ -561,17 +566,23 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         for (int dd = 0; dd < D; ++dd) {
             float* const* gl = dweights + (size_t)(l * D + dd) * 4;
             const float* dg = dgi + (size_t)dd * G * H;
-            const int ldg = D * G * H;
             // dW_ih (G*H, Kl) = dG^T * in
             rc = dep_gemm_internal(1, 0, G * H, Kl, BTr, dg, ldg, in, Kl, gl[0], Kl, nullptr, 0.f, 0, 0, gws, gwsb, s);
             if (rc) return rc;
             // dW_hh (G*H, H) = dGH^T * h_prev   (h_prev = layer output shifted by one step along the sweep)
             const float* yl = R + lo.y[l] + (size_t)dd * H;
             const int shift = dd == 0 ? -1 : 1;
-            if (d->cell == DEP_CELL_GRU) {
+            if (d->cell == DEP_CELL_GRU && lo.dg4 && dep_gemm_uses_bf16x3(3 * H, H, BTr, T)) {
+                // ONE contraction over the 4H-wide rows: op(A) columns [dr | dz] and [dn*r] (the dn block in between is skipped by
+                // the loader).  The separate (H x H) call for the n rows cost 100 us for a third of the (2H x H) call's 165 us work.
+                dep_gemm_set_a_colskip(2 * H, H);
+                rc = dep_gemm_internal(1, 0, 3 * H, H, BTr, dg, ldg, yl, D * H, gl[1], H, nullptr, 0.f, T, shift, gws, gwsb, s);
+                dep_gemm_set_a_colskip(0, 0);
+                if (rc) return rc;
+            } else if (d->cell == DEP_CELL_GRU) {
                 rc = dep_gemm_internal(1, 0, 2 * H, H, BTr, dg, ldg, yl, D * H, gl[1], H, nullptr, 0.f, T, shift, gws, gwsb, s);
                 if (rc) return rc;
-                rc = dep_gemm_internal(1, 0, H, H, BTr, W + lo.dghn, H, yl, D * H, gl[1] + (size_t)2 * H * H, H, nullptr,
+                rc = dep_gemm_internal(1, 0, H, H, BTr, dghn, lo.dg4 ? ldg : H, yl, D * H, gl[1] + (size_t)2 * H * H, H, nullptr,
                                        0.f, T, shift, gws, gwsb, s);
                 if (rc) return rc;
             } else {

@@ -88,6 +88,11 @@ enum { DEP_PROF_GRU_FWD = 0, DEP_PROF_GRU_BWD = 1, DEP_PROF_LSTM_FWD = 2, DEP_PR
 // device word is non-zero (the conditional fallback of dep_rnn_forward).  nullptr = unconditional.
 void dep_gemm_set_predicate(const unsigned* only_if);
 const unsigned* dep_gemm_predicate();
+// A-operand column skip of the calling thread's next TN contractions (bf16x3 kernel only): logical column m of op(A) is stored
+// column m + (m >= at ? by : 0).  dW_hh of a GRU reads [dr | dz] and [dn*r] out of [dr | dz | dn | dn*r] with (2H, H).  (0, 0) = off.
+void dep_gemm_set_a_colskip(int at, int by);
+// true when dep_gemm_internal would run the bf16x3 kernel for a contraction of this size (it is the one that honours the skip)
+bool dep_gemm_uses_bf16x3(int M, int N, int K, int seq_T);
 // process-wide: may dep_rnn_forward use kernels that need every CU to themselves (dep_rnn_set_exclusive, include/dep_rnn.h)
 bool dep_exclusive_on();
 bool dep_prof_on();
@@ -139,6 +144,8 @@ struct dep_sweep_bwd_args {
     const float* sv0; const float* sv1; const float* sv2; const float* sv3;
     float* dgi;              // (B,T,dirs*G*H) written: grad of the input projection
     float* dghn;             // GRU: (B,T,H) grad of the n-gate recurrent pre-activation (dn*r)
+    int lddg, lddghn;        // row strides of dgi / dghn (0 = packed: dirs*G*H and H).  The GRU cluster sweep accepts 4H / 4H with
+                             // dghn = dgi + 3H: one (B,T,4H) array [dr | dz | dn | dn*r], so that dW_hh is ONE contraction
     float* dbpart;           // partial bias sums, see dep_sweep_dbpart_floats
     int dbpart_rows;         // number of partial rows provided
     hipStream_t stream;

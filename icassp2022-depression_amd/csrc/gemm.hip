@@ -325,6 +325,12 @@ extern "C" int dep_set_gemm_mode(int mode, long min_macs) {
     return DEP_OK;
 }
 extern "C" int dep_get_gemm_mode(void) { init_split_mode(); return g_split_mode; }
+bool dep_gemm_uses_bf16x3(int M, int N, int K, int seq_T) {
+    init_split_mode();
+    if (naive_forced() || g_force_exact == 1) return false;
+    if (seq_T <= 0 && (long)dep_cdiv(M, BM) * dep_cdiv(N, BN) < 32 && K <= 8192 && (long)M * N * K <= (1L << 27)) return false;    // gemm_small
+    return g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs;
+}
 
 extern "C" size_t dep_gemm_workspace_bytes(int transA, int transB, int M, int N, int K) {
     (void)transA; (void)transB;

@@ -32,6 +32,7 @@ struct GemmP {
     int ablate;             // debug (DEP_GEMM_ABLATE): 1 no epilogue stores, 2 no MFMA, 4 no tile reloads, 8 no LDS staging
     const unsigned* only_if;    // run only if this device word is non-zero (dep_gemm_set_predicate), or nullptr
     int xcd_lo, xcd_n;          // experiment (dep_gemm_set_xcds): only the workgroups of XCDs [xcd_lo, xcd_lo + xcd_n) work; 0, 8 = all
+    int skip_at, skip_by;       // A stored MN-contiguous (transA): logical column m lives at m + (m >= skip_at ? skip_by : 0); 0, 0 = off
 };
 
 // Operand tile of ROWS (128 or 256) rows x 32 k, 256 threads: a = tid&7, bq = tid>>3.
@@ -39,7 +40,7 @@ struct GemmP {
 //    TR (MN-contiguous)    : r[4jj + i] = k row (k0 + a*4 + i),           mn = mn0 + (bq + 32 jj)*4 + 0..3
 template <bool TR, bool VEC, int ROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int Kend,
-                                          int tid, float (&r)[ROWS / 32][4], int seqT, int shift) {
+                                          int tid, float (&r)[ROWS / 32][4], int seqT, int shift, int skip_at = 0, int skip_by = 0) {
     const int a = tid & 7, bq = tid >> 3;
     if (!TR) {
 #pragma unroll
@@ -63,7 +64,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
                 const int k = k0 + a * 4 + i, mn = mn0 + (bq + 32 * jj) * 4;
                 bool ok = k < Kend;
                 if (seqT > 0) { const int tt = k % seqT + shift; ok = ok && tt >= 0 && tt < seqT; }
-                const float* src = P + ((long)k + shift) * ld + mn;
+                // column skip: skip_at is a multiple of the tile's 4-column pieces, so a piece never straddles it
+                const float* src = P + ((long)k + shift) * ld + mn + ((skip_by && mn >= skip_at) ? skip_by : 0);
                 float (&rr)[4] = r[jj * 4 + i];
                 if (VEC) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
 
     f32x16 acc[MI][2];
     float ra[BMT / 32][4], rb[BN / 32][4];
-    load_tile<A_TR, VEC, BMT>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra, 0, 0);
+    load_tile<A_TR, VEC, BMT>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra, 0, 0, p.skip_at, p.skip_by);
     load_tile<B_TR, VEC, BN>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb, p.seqT, p.shiftB);
 
     while (true) {
@@ -207,10 +209,10 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
             __syncthreads();
             if (!(p.ablate & 4)) {
                 if (k0 + BK < kend) {
-                    load_tile<A_TR, VEC, BMT>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0);
+                    load_tile<A_TR, VEC, BMT>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0, p.skip_at, p.skip_by);
                     load_tile<B_TR, VEC, BN>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb, p.seqT, p.shiftB);
                 } else if (has_next) {       // first k-tile of the NEXT output tile
-                    load_tile<A_TR, VEC, BMT>(p.A, p.lda, nm0, p.M, nkb, nke, tid, ra, 0, 0);
+                    load_tile<A_TR, VEC, BMT>(p.A, p.lda, nm0, p.M, nkb, nke, tid, ra, 0, 0, p.skip_at, p.skip_by);
                     load_tile<B_TR, VEC, BN>(p.B, p.ldb, nn0, p.N, nkb, nke, tid, rb, p.seqT, p.shiftB);
                 }
             }
@@ -651,6 +653,8 @@ __global__ void splitk_reduce2(const unsigned* only_if, const float* __restrict_
 
 // experiment hook: confine the persistent kernel's working workgroups to a range of XCDs (per calling thread)
 static thread_local int g_xcd_lo = 0, g_xcd_n = 8;
+static thread_local int g_skip_at = 0, g_skip_by = 0;
+void dep_gemm_set_a_colskip(int at, int by) { g_skip_at = at; g_skip_by = by; }
 extern "C" int dep_gemm_set_xcds(int lo, int n) { if (lo < 0 || n < 1 || lo + n > 8) return DEP_ERR_ARG; g_xcd_lo = lo; g_xcd_n = n; return DEP_OK; }
 
 // Same contract as dep_gemm_internal (gemm.hip); `splits` is decided by the caller's shared heuristic.
@@ -662,9 +666,9 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     if (wsd == -2) { const char* e = getenv("DEP_GEMM_WS"); wsd = e ? atoi(e) : 0; if (wsd < 0 || wsd > 4) wsd = 0; }
     // (32-bit lane offsets: every operand must span less than 4 GB)
     const size_t spanA = (size_t)(transA ? K : M) * lda * 4, spanB = (size_t)(transB ? N : K) * ldb * 4;
-    if (wsd > 0 && terms == 3 && M >= 256 && spanA < (1ull << 32) && spanB < (1ull << 32)) {
+    if (wsd > 0 && terms == 3 && M >= 256 && !(transA && g_skip_by) && spanA < (1ull << 32) && spanB < (1ull << 32)) {
         // wave-specialised kernel: one 8-wave workgroup per CU, 256 x 128 tiles, `wsd` register sets of prefetch
-        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl, dep_gemm_predicate(), 0, 8};
+        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl, dep_gemm_predicate(), 0, 8, 0, 0};
         const int ntiles = p.gx * p.gy * splits;
         int ncu = 256;
         { static int cus = -1; if (cus < 0) { hipDeviceProp_t pr; int dv = 0; cus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; } ncu = cus / 8 * 8; if (ncu < 8) ncu = 8; }
@@ -698,7 +702,7 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     // measured at cfg2: 256-row tiles win 8-10 % on the NN (dX) and TN (dW) forms, lose 6 % on the short-K NT projection
     const bool big = bm256 && M >= 512 && !(!transA && transB);
     const int BMT = big ? 256 : 128;
-    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl, dep_gemm_predicate(), g_xcd_lo, g_xcd_n};
+    GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl, dep_gemm_predicate(), g_xcd_lo, g_xcd_n, transA ? g_skip_at : 0, transA ? g_skip_by : 0};
     // persistent launch: at most `persist` workgroups (a multiple of 8: one share per XCD), each walks a list of tiles
     const int ntiles = p.gx * p.gy * splits;
     const int cap = big ? persist * 2 / 3 : persist;              // 2 resident workgroups per CU with 256-row tiles, 3 otherwise

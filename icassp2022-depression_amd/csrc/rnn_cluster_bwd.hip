@@ -27,7 +27,7 @@ struct P2 {
     const float* dh_n;
     const float* sv0; const float* sv1; const float* sv2; const float* sv3;
     float* dgi; int lddg;
-    float* dghn;
+    float* dghn; int lddghn;
     float* dbpart;
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
     int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
             const float* o = obuf + (k % (KBX + 1)) * 4 * SARR + sr * SROW + sp * 4;
             // arrays sarr0 (dr / dz) and 2 + sarr0 (dn / dn*r)
             *reinterpret_cast<f32x4*>(p.dgi + row * p.lddg + (sodd ? H : 0) + scol) = ld4(o + (sodd ? SARR : 0));
-            float* g1 = sodd ? p.dghn + row * H + scol : p.dgi + row * p.lddg + 2 * H + scol;
+            float* g1 = sodd ? p.dghn + row * p.lddghn + scol : p.dgi + row * p.lddg + 2 * H + scol;
             *reinterpret_cast<f32x4*>(g1) = ld4(o + (sodd ? 3 * SARR : 2 * SARR));
         }
     };
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
         } else if (valid) {
             float* g = p.dgi + row * p.lddg;
             st2(g + col, dr); st2(g + H + col, dz); st2(g + 2 * H + col, dn);
-            st2(p.dghn + row * H + col, dnr);
+            st2(p.dghn + row * p.lddghn + col, dnr);
         }
         dbr.x += dr.x; dbr.y += dr.y; dbz.x += dz.x; dbz.y += dz.y; dbn.x += dn.x; dbn.y += dn.y; dbh.x += dnr.x; dbh.y += dnr.y;
         bar_lds();                                   // LDS only: the dgi/dghn stores above stay in flight
@@ -697,7 +697,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.seed = a.seed; p.site = a.site;
     p.dpooled = a.dpooled; p.pool_scale = a.pool_scale; p.dh_n = a.dh_n;
     p.sv0 = a.sv0; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
-    p.dgi = a.dgi; p.lddg = 3 * a.H; p.dghn = a.dghn; p.dbpart = a.dbpart;
+    p.dgi = a.dgi; p.lddg = a.lddg ? a.lddg : 3 * a.H; p.dghn = a.dghn; p.lddghn = a.lddghn ? a.lddghn : a.H; p.dbpart = a.dbpart;
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
     const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 256);
