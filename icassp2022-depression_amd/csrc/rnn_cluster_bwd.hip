@@ -33,6 +33,7 @@ struct P2 {
     int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
     long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
     int trall_off;           // debug: LDS offset (32-bit words) of the per-step stamp array
+    int wflags;              // DEP_BWD_WFLAGS: every compute wave raises its OWN epoch flag once its own payload stores are acknowledged (no workgroup barrier in front of the flag; the pollers watch 4 NC words)
     int xhalf;               // experiment (DEP_BWD_XHALF=1): the sweep's workgroups on XCDs 0-3 only, two per CU; the launch has twice the blocks and those of XCDs 4-7 leave at once
 };
 
@@ -117,8 +118,10 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     const size_t pstride = (size_t)p.nbtp * NC * BT * H;                   // floats per parity buffer
     const size_t tile_base = (size_t)bt * NC * BT * H;                     // this tile's [NC][NTT][64][4] block
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
-    unsigned* myflag = p.flags + bt * NC + c;
-    unsigned* tflags = p.flags + bt * NC;
+    const bool wf = p.wflags != 0;                    // uniform
+    unsigned* tflags = wf ? p.flags + bt * NC * 4 : p.flags + bt * NC;
+    unsigned* myflag = wf ? tflags + c * 4 + (w & 3) : tflags + c;
+    const int nflags = wf ? NC * 4 : NC;
     const int ml = lane & 15, mq = lane >> 4;
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * NC, NC, c, p.status);
     if (sx < 0) return;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                     else svc_put(KBX, phi);
                 }
                 if (k == T - 1) break;
-                bar_lds();                           // #2 (the compute waves' drain barrier)
+                if (!p.wflags) bar_lds();            // #2 (the compute waves' drain barrier; absent with per-wave flags)
             }
             const int jl2 = (T - 1 + KBX - phi) % KBX;
             svc_flush(T - 1 - jl2, T);                // the gate gradients since the last dirty step
@@ -335,14 +338,21 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
         BSTAMP(3);
-        __builtin_amdgcn_s_barrier();                // every wave drained its payload stores (vmcnt(0) above)
-        if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        if (wf) {
+            // per-wave flags: this wave's partials are acknowledged -> say so; nobody waits for the sibling waves here (their
+            // flags are among the 4 NC words every wave polls below, which also orders this step's LDS reads before the next
+            // step's LDS writes: a sibling raises its flag only after its MFMAs have read the gate-gradient planes)
+            if (lane == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        } else {
+            __builtin_amdgcn_s_barrier();            // every wave drained its payload stores (vmcnt(0) above)
+            if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        }
         if (masked) mk = draw(t - 1);                // next step's mask, in the shadow of the wait below
         BSTAMP(4);
         // wait for every member's flag (one wave polls, relaxed; flags are monotonic)
         // every wave polls the flags itself (no verdict-broadcast barrier); a wave that gives up leaves, the hardware
         // barrier only counts live waves and the others give up too (status word raised)
-        if (!wait_flags(tflags, NC, epoch, p.status, 3)) return;
+        if (!wait_flags(tflags, nflags, epoch, p.status, 3)) return;
         BSTAMP(5);
         // gather this thread's two columns from the NC partials, sum in member order
         float2 s = f2(0.f, 0.f);
@@ -708,6 +718,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
     static int kb_env = -1;                           // DEP_BWD_BURST=0: the round-1 kernel (every wave streams for itself, every step); 4 (default) or 6: burst length
     if (kb_env < 0) { const char* v = getenv("DEP_BWD_BURST"); kb_env = v ? atoi(v) : 4; if (kb_env != 0 && kb_env != 4 && kb_env != 6) kb_env = 4; }
+    { static int wf_env = -1; if (wf_env < 0) { const char* v = getenv("DEP_BWD_WFLAGS"); wf_env = (v && v[0] == '0') ? 0 : 1; } p.wflags = wf_env; }     // default on; DEP_BWD_WFLAGS=0: one flag per member behind a workgroup barrier
     static int xhalf_env = -1;
     if (xhalf_env < 0) { const char* v = getenv("DEP_BWD_XHALF"); xhalf_env = (v && v[0] == '1') ? 1 : 0; }
     p.xhalf = (xhalf_env && a.H == 256 && a.B <= CH) ? 1 : 0;

@@ -10,12 +10,12 @@ constexpr int LPAD = 4;                     // LDS row padding (floats)
 constexpr int CT = 256;                     // compute threads per workgroup
 constexpr unsigned SPIN_LIMIT = 1u << 20;   // bounded spins: ~1 s, then the status word is raised and the kernel leaves
 constexpr unsigned HELLO_LIMIT_SOFT = 1u << 13;    // hello of a kernel that has a fallback: a few ms (a normal hello takes ~20 us)
-// exchange buffer header: word [0] status, word [1] "soft" flag (both cleared by dep_rnn_forward) | flags (<= 512 words) |
+// exchange buffer header: word [0] status, word [1] "soft" flag (both cleared by dep_rnn_forward) | flags (<= 1024 words) |
 // hello (<= 512 words) | trace (zeroed before every launch)
 //   soft flag: a forward kernel that needs every CU to itself (rnn_fused2.hip) could not assemble its clusters -- a foreign
 //   workgroup sat in the dispatcher.  It leaves WITHOUT raising the status; the co-schedule-tolerant per-layer kernels
 //   enqueued behind it run only when this word is set (dep_rnn_forward, api.hip) and redo the forward.
-constexpr size_t FLAG_OFF = 256, HELLO_OFF = 3328, TRACE_OFF = 6144, PAYLOAD_OFF = 8192;
+constexpr size_t FLAG_OFF = 256, HELLO_OFF = 4352, TRACE_OFF = 6400, PAYLOAD_OFF = 8192;     // flags: 1024 words (per-wave flags of the GRU backward), hello: 512 words
 
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

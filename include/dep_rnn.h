@@ -80,7 +80,7 @@ size_t dep_rnn_reserve_ydrop_offset(const dep_rnn_desc* d, int layer);
  * the single-workgroup kernels. */
 int dep_rnn_status(const dep_rnn_desc* d, void* workspace, void* stream);
 /* Debug tooling: byte offset of the cluster exchange buffer inside the workspace ((size_t)-1 if unused).
- * With DEP_TRACE=1 workgroup 0 of the GRU sweeps leaves shader-clock stamps of its phases at +6144
+ * With DEP_TRACE=1 workgroup 0 of the GRU sweeps leaves shader-clock stamps of its phases at +6400
  * (tools/trace_fwd.py, tools/trace_bwd.py). */
 size_t dep_rnn_workspace_xbuf_offset(const dep_rnn_desc* d);
 /* Kernels that need every CU to themselves.  The default GRU forward at H = 256 (both layers fused into one launch of twelve

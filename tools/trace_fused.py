@@ -27,7 +27,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 rnn.check()
 off = L.load().dep_rnn_workspace_xbuf_offset(C.byref(rnn.desc))
-tr = rnn.workspace[(off + 6144) // 4:(off + 6144) // 4 + 128].view(torch.int64).cpu().numpy().reshape(2, 4, 8)
+tr = rnn.workspace[(off + 6400) // 4:(off + 6400) // 4 + 128].view(torch.int64).cpu().numpy().reshape(2, 4, 8)
 n0 = ['frags+MFMA+red', 'barrier#1', 'gates+publish+deposit+mask draw', 'drain vmcnt', 'barrier#2+flag', 'poll', 'gather->LDS']
 for s in range(4):
     a = tr[0, s]

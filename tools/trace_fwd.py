@@ -24,7 +24,7 @@ for _ in range(2):
     rnn.forward(x, W, pooled=pooled)
 torch.cuda.synchronize()
 off = L.load().dep_rnn_workspace_xbuf_offset(C.byref(rnn.desc))
-TOFF = int(os.environ.get('TRACE_OFF', 6144))
+TOFF = int(os.environ.get('TRACE_OFF', 6400))
 tr = rnn.workspace[(off + TOFF) // 4:(off + TOFF) // 4 + 64].view(torch.int64).cpu().numpy().reshape(4, 8)
 names = ['top->matvec done', 'pair-exch barrier', 'elementwise', 'payload store+drain', 'barrier+flag+y/sv stores+poll', 'poll barrier', 'load h + LDS + barrier']
 for s in range(4):
