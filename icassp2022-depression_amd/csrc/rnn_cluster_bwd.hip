@@ -33,6 +33,7 @@ struct P2 {
     int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
     long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
     int trall_off;           // debug: LDS offset (32-bit words) of the per-step stamp array
+    int ntstream;            // DEP_BWD_NT=1: non-temporal hint on the service waves' HBM streams
     int wflags;              // DEP_BWD_WFLAGS: every compute wave raises its OWN epoch flag once its own payload stores are acknowledged (no workgroup barrier in front of the flag; the pollers watch 4 NC words)
     int xhalf;               // experiment (DEP_BWD_XHALF=1): the sweep's workgroups on XCDs 0-3 only, two per CU; the launch has twice the blocks and those of XCDs 4-7 leave at once
 };
@@ -155,14 +156,19 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     const float* sbase1 = sodd ? p.sv3 : p.sv2;
     const float* sbase2 = sodd ? p.dy : p.y;
     const int sld2 = sodd ? p.lddy : p.ldy;
+    // DEP_BWD_NT=1: the service waves' one-touch streams carry the non-temporal hint, so that they do not displace the
+    // exchange payload (rewritten every other step) from this XCD's L2 and turn it into HBM write-backs
+    const bool snt = p.ntstream != 0;
+    auto ldnt = [&](const float* q) -> f32x4 { return snt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : ld4(q); };
+    auto stnt = [&](float* q, f32x4 v) { if (snt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q)); else *reinterpret_cast<f32x4*>(q) = v; };
     auto svc_load1 = [&](int k, int i) -> f32x4 {     // input array a = sarr0 + 2 i of step k
         const int t = T - 1 - k;
         if (!svalid || t < 0) return zero4();
         const size_t row = (size_t)sb * T + t;
-        if (i == 0) return ld4(sbase0 + row * H + scol);
-        if (i == 1) return ld4(sbase1 + row * H + scol);
-        if (sodd) return sbase2 ? ld4(sbase2 + row * sld2 + scol) : zero4();
-        return t > 0 ? ld4(sbase2 + (row - 1) * sld2 + scol) : zero4();
+        if (i == 0) return ldnt(sbase0 + row * H + scol);
+        if (i == 1) return ldnt(sbase1 + row * H + scol);
+        if (sodd) return sbase2 ? ldnt(sbase2 + row * sld2 + scol) : zero4();
+        return t > 0 ? ldnt(sbase2 + (row - 1) * sld2 + scol) : zero4();
     };
     auto svc_issue = [&](int k0, int n) {             // inputs of steps k0 .. k0+n-1 -> registers
 #pragma unroll
@@ -187,9 +193,9 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
             const size_t row = (size_t)sb * T + (T - 1 - k);
             const float* o = obuf + (k % (KBX + 1)) * 4 * SARR + sr * SROW + sp * 4;
             // arrays sarr0 (dr / dz) and 2 + sarr0 (dn / dn*r)
-            *reinterpret_cast<f32x4*>(p.dgi + row * p.lddg + (sodd ? H : 0) + scol) = ld4(o + (sodd ? SARR : 0));
+            stnt(p.dgi + row * p.lddg + (sodd ? H : 0) + scol, ld4(o + (sodd ? SARR : 0)));
             float* g1 = sodd ? p.dghn + row * p.lddghn + scol : p.dgi + row * p.lddg + 2 * H + scol;
-            *reinterpret_cast<f32x4*>(g1) = ld4(o + (sodd ? 3 * SARR : 2 * SARR));
+            stnt(g1, ld4(o + (sodd ? 3 * SARR : 2 * SARR)));
         }
     };
     if constexpr (BURST) {
@@ -719,6 +725,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     static int kb_env = -1;                           // DEP_BWD_BURST=0: the round-1 kernel (every wave streams for itself, every step); 4 (default) or 6: burst length
     if (kb_env < 0) { const char* v = getenv("DEP_BWD_BURST"); kb_env = v ? atoi(v) : 4; if (kb_env != 0 && kb_env != 4 && kb_env != 6) kb_env = 4; }
     { static int wf_env = -1; if (wf_env < 0) { const char* v = getenv("DEP_BWD_WFLAGS"); wf_env = (v && v[0] == '0') ? 0 : 1; } p.wflags = wf_env; }     // default on; DEP_BWD_WFLAGS=0: one flag per member behind a workgroup barrier
+    { static int nt_env = -1; if (nt_env < 0) { const char* v = getenv("DEP_BWD_NT"); nt_env = (v && v[0] == '1') ? 1 : 0; } p.ntstream = nt_env; }
     static int xhalf_env = -1;
     if (xhalf_env < 0) { const char* v = getenv("DEP_BWD_XHALF"); xhalf_env = (v && v[0] == '1') ? 1 : 0; }
     p.xhalf = (xhalf_env && a.H == 256 && a.B <= CH) ? 1 : 0;
