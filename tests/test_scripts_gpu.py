@@ -302,3 +302,36 @@ def test_models_built_without_a_seed_differ_and_follow_the_global_seed():
     torch.manual_seed(123)
     a2 = audio_gru_whole.AudioBiLSTM(cfg).state_dict()['fc_audio.1.weight'].clone()
     assert not torch.equal(a, b) and torch.equal(a, a2)
+
+
+def test_streamed_feature_feeder_equals_resident_mode(monkeypatch):
+    """_common.FeatureFeeder: arrays beyond DEP_FEATURES_HBM_GB are fed from a pinned fp32 host copy by a copy stream, one
+    mini-batch ahead of the step that consumes it.  Forced here with a zero budget: two epochs of audio_gru_whole.train() must leave
+    bit-identical parameters and the same accuracy count as the HBM-resident mode (same kernels, same inputs)."""
+    g = load_golden('audio_clf_train_eval')
+    N, T, F, H = [int(v) for v in g['shape']]
+    m = audio_gru_whole
+    saved_cfg = dict(m.config)
+    saved = (m.audio_features, m.audio_targets, m.model, m.optimizer, m.criterion)
+    res = {}
+    try:
+        for mode, budget in (('resident', '64'), ('streamed', '0')):
+            monkeypatch.setenv('DEP_FEATURES_HBM_GB', budget)
+            _common.invalidate_device_features()
+            m.config.update(embedding_size=F, hidden_dims=H, dropout=0.0, batch_size=4, learning_rate=float(g['lr']))
+            m.audio_features = g['feats']; m.audio_targets = g['targs']
+            m.model = m.AudioBiLSTM(m.config, seed=0)
+            m.model.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()})
+            m.optimizer = nn.AdamW(m.get_param_group(m.model), lr=m.config['learning_rate']); m.criterion = nn.CrossEntropyLoss()
+            idx = [5, 0, 3, 11, 7, 2, 9, 1, 14, 6, 4]                     # not a run: the resident mode gathers, the streamed one copies slices
+            feed = _common.FeatureFeeder(m.audio_features, idx, m.model.device, role='audio_features')
+            assert (feed.Xd is None) == (mode == 'streamed')
+            capture(m.train, 1, idx); capture(m.train, 2, idx)
+            res[mode] = ({k: v.cpu().numpy().copy() for k, v in m.model.state_dict().items()}, int(m.train_acc))
+        assert res['resident'][1] == res['streamed'][1]
+        for k, v in res['resident'][0].items():
+            assert np.array_equal(v, res['streamed'][0][k]), k
+    finally:
+        _common.invalidate_device_features()
+        m.config.clear(); m.config.update(saved_cfg)
+        m.audio_features, m.audio_targets, m.model, m.optimizer, m.criterion = saved
