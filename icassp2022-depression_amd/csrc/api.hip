@@ -82,6 +82,7 @@ struct Layout {
     size_t reserve_floats;
     // workspace (float offsets)
     size_t gi, dghn, dx[2], dbpart, biastmp, gemm, xbuf;
+    size_t wstack[MAXL], bstack[MAXL], dwstack;   // bidirectional: both directions' W_ih / (b_ih + b_hh) stacked (2 G H x in), one dW_ih scratch
     size_t gi2, dghn2, dbpart2;      // second set of gate-gradient buffers: the fused backward keeps both layers' dgi / dghn
     size_t gemm_bytes, xbuf_bytes, ws_floats;
     int nwg;
@@ -118,6 +119,17 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
             lo.wpT[l][dd] = off; off += al(G * H * H);
         }
     }
+    // bidirectional stacks: the two directions share their input, so their input projections, dX and dW_ih are ONE contraction
+    // each over stacked weights [W_ih(fwd); W_ih(bwd)] (2 G H x in) -- the input (629 MB at cfg3's layer 0) is read once, and
+    // dX needs no read-modify-write.  The stacked copies live in the reserve (the backward's dX reads them again).
+    for (int l = 0; l < d->L; ++l) {
+        lo.wstack[l] = lo.bstack[l] = 0;
+        if (d->dirs == 2) {
+            const size_t in = l == 0 ? (size_t)d->F : D * H;
+            lo.wstack[l] = off; off += al(D * G * H * in);
+            lo.bstack[l] = off; off += al(D * G * H);
+        }
+    }
     lo.reserve_floats = off;
     // workspace
     // rows of bias-gradient partials: one per 16-utterance tile for the tile-MFMA and the cluster sweeps, one per utterance for
@@ -132,13 +144,14 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     (void)maxin;
     lo.dbpart = w; w += al((size_t)D * lo.nwg * 4 * H);
     lo.biastmp = w; w += al(G * H);
+    lo.dwstack = w; if (d->dirs == 2 && d->training) { const size_t mx = D * H > (size_t)d->F ? D * H : (size_t)d->F; w += al(D * G * H * mx); }
     // split-K scratch: the largest weight-gradient contraction
     size_t gb = 0;
     {   // every (rows, cols) block dep_rnn_backward contracts over B*T: dW_ih (G H x F | D H), dW_hh whole or as the GRU's
         // (2H x H) + (H x H) pair -- the split count depends on the block shape, so take the maximum over all of them
-        const int Ms[3] = {(int)(G * H), (int)(2 * H), (int)H};
+        const int Ms[4] = {(int)(D * G * H), (int)(G * H), (int)(2 * H), (int)H};      // (D G H: the direction-stacked dW_ih of a bidirectional stack)
         const int Ns[3] = {d->F, (int)(D * H), (int)H};
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 4; ++i)
             for (int j = 0; j < 3; ++j) {
                 const size_t b1 = dep_gemm_workspace_bytes(1, 0, Ms[i], Ns[j], (int)lo.BT);
                 if (b1 > gb) gb = b1;
@@ -355,6 +368,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
         const int Kl = l == 0 ? d->F : D * H;
         float* gi = W + lo.gi;
+        const bool stacked = D == 2;                   // both directions' projections as one GEMM over stacked weights
         for (int dd = 0; dd < D; ++dd) {
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             DEP_CHECK_ARG(wl[0] && wl[1] && wl[2] && wl[3]);
@@ -377,6 +391,14 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
                 }
             }
             const float* bias = wl[2];
+            if (stacked) {
+                // stack this direction's W_ih and (b_ih + b_hh) behind the other's; the GEMM follows the loop
+                float* ws_ = R + lo.wstack[l] + (size_t)dd * G * H * Kl; float* bs_ = R + lo.bstack[l] + (size_t)dd * G * H;
+                rc = dep_axpby(wl[0], ws_, (long)G * H * Kl, 1.f, 0.f, s); if (rc) return rc;
+                rc = dep_axpby(wl[2], bs_, (long)G * H, 1.f, 0.f, s); if (rc) return rc;
+                if (d->cell == DEP_CELL_LSTM) { rc = dep_axpby(wl[3], bs_, (long)G * H, 1.f, 1.f, s); if (rc) return rc; }
+                continue;
+            }
             if (d->cell == DEP_CELL_LSTM) {          // both biases fold into the projection
                 float* tb = W + lo.biastmp;
                 rc = dep_axpby(wl[2], tb, (long)G * H, 1.f, 0.f, s); if (rc) return rc;
@@ -387,6 +409,11 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
                                    0.f, 0, 0, nullptr, 0, s);
             if (rc) return rc;
             // the bias scratch is reused by the next direction: stream order keeps this safe
+        }
+        if (stacked) {
+            rc = dep_gemm_internal(0, 1, BTr, D * G * H, Kl, in, Kl, R + lo.wstack[l], Kl, gi, D * G * H, R + lo.bstack[l],
+                                   0.f, 0, 0, nullptr, 0, s);
+            if (rc) return rc;
         }
         dep_sweep_args a{};
         a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.training = d->training; a.impl = d->impl;
@@ -555,7 +582,13 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         if (rc) return rc;
         float* dxl = l == 0 ? dx : W + lo.dx[l & 1];
         // dX (B*T, Kl) (+)= dG * W_ih first: it is the only product the next layer's sweep waits for
-        if (dxl) {
+        const bool stacked = D == 2 && lo.wstack[l] != 0;
+        if (dxl && stacked) {
+            // dX = [dG_fwd | dG_bwd] [W_ih(fwd); W_ih(bwd)]: one contraction over K = 2 G H (the forward left the stacked copy in
+            // the reserve) instead of two with a read-modify-write of dX in between
+            rc = dep_gemm_internal(0, 0, BTr, Kl, D * G * H, dgi, ldg, R + lo.wstack[l], Kl, dxl, Kl, nullptr, 0.f, 0, 0, nullptr, 0, s);
+            if (rc) return rc;
+        } else if (dxl) {
             for (int dd = 0; dd < D; ++dd) {
                 const float* const* wl = weights + (size_t)(l * D + dd) * 4;
                 rc = dep_gemm_internal(0, 0, BTr, Kl, G * H, dgi + (size_t)dd * G * H, ldg, wl[0], Kl, dxl, Kl, nullptr,
@@ -563,12 +596,24 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
                 if (rc) return rc;
             }
         }
+        if (stacked) {
+            // dW_ih of both directions: (2 G H x Kl) = dG^T in, the input read once; rows [0, G H) / [G H, 2 G H) are the two tensors
+            float* dws = W + lo.dwstack;
+            rc = dep_gemm_internal(1, 0, D * G * H, Kl, BTr, dgi, ldg, in, Kl, dws, Kl, nullptr, 0.f, 0, 0, gws, gwsb, s);
+            if (rc) return rc;
+            for (int dd = 0; dd < D; ++dd) {
+                float* const* gl = dweights + (size_t)(l * D + dd) * 4;
+                rc = dep_axpby(dws + (size_t)dd * G * H * Kl, gl[0], (long)G * H * Kl, 1.f, 0.f, s); if (rc) return rc;
+            }
+        }
         for (int dd = 0; dd < D; ++dd) {
             float* const* gl = dweights + (size_t)(l * D + dd) * 4;
             const float* dg = dgi + (size_t)dd * G * H;
             // dW_ih (G*H, Kl) = dG^T * in
-            rc = dep_gemm_internal(1, 0, G * H, Kl, BTr, dg, ldg, in, Kl, gl[0], Kl, nullptr, 0.f, 0, 0, gws, gwsb, s);
-            if (rc) return rc;
+            if (!stacked) {
+                rc = dep_gemm_internal(1, 0, G * H, Kl, BTr, dg, ldg, in, Kl, gl[0], Kl, nullptr, 0.f, 0, 0, gws, gwsb, s);
+                if (rc) return rc;
+            }
             // dW_hh (G*H, H) = dGH^T * h_prev   (h_prev = layer output shifted by one step along the sweep)
             const float* yl = R + lo.y[l] + (size_t)dd * H;
             const int shift = dd == 0 ? -1 : 1;
