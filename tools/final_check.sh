@@ -1,11 +1,22 @@
+#!/bin/bash
+# Last session of a round (run on the GPU box): PMC passes at the final kernel digest, the whole GPU suite, smoke, the three bench lines.
 set -u
 export TMPDIR=/tmp
-tag=r03c; out=$PWD/gpurun_out/$tag; mkdir -p $out
+tag=${1:-final}; out=$PWD/gpurun_out/$tag; mkdir -p $out
 for wl in audio_gru text_bilstm fusion; do
   bash tools/prof_pmc.sh $tag/pmc_$wl python $PWD/bench.py --steps 3 --warmup 1 --profile-run --workload $wl > $out/pmc_$wl.txt 2>&1
 done
 grep -h "launches=" $out/pmc_audio_gru.txt | head -4
-python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3
+python tools/update_pmc_traffic.py $out 4 > $out/pmc_traffic_update.txt 2>&1     # so that the bench lines below carry the traffic record
+cp profiles/pmc_traffic.json $out/pmc_traffic.json
+python -m pytest tests/ -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_cfg2.json 2> $out/bench.err
-tail -c 700 $out/bench_cfg2.json
+python bench.py --steps 20 --warmup 5 --workload text_bilstm > $out/bench_cfg3.json 2>> $out/bench.err
+python bench.py --steps 20 --warmup 5 --workload fusion > $out/bench_cfg4_fusion.json 2>> $out/bench.err
+python - "$out" <<'PY'
+import json, sys
+for f in ('bench_cfg2', 'bench_cfg3', 'bench_cfg4_fusion'):
+    d = json.loads(open(f'{sys.argv[1]}/{f}.json').read().strip().splitlines()[-1])
+    print(f, d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['traffic'], d['roofline']['step_traffic']['pmc_bytes_per_step'])
+PY
