@@ -202,3 +202,23 @@ def test_data_parallel_with_dropout_is_deterministic_per_rank_and_keeps_replicas
         assert np.array_equal(a[k], b[k]), k
     c, _ = _spawn('text_clf', 1, 0.5, 27800)                  # other mask partition (rank-keyed streams): close, not equal
     assert any(not np.array_equal(a[k], c[k]) for k in a) and max(np.abs(a[k] - c[k]).max() for k in a) < 0.1
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
+def test_bench_two_rank_dry_run_on_one_gpu():
+    """The N-rank code path of bench.py end to end -- self re-exec under torch.distributed.run, process group, sharded step with the
+    gradient exchange, max-over-ranks timing, per-rank communication probe, teardown on every rank -- with the two ranks sharing
+    this box's GPU through gloo (`--backend gloo`; RCCL refuses two ranks on one device).  What the driver's 8-GPU run executes differs
+    only in the transport."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['config']['ranks'] == 2 and d['config']['global_batch'] == 1024 and d['scaling'] == 'weak'
+    assert d['config']['backend'].startswith('rccl via torch.distributed') or d['config']['backend'] == 'torch.distributed'
+    assert len(d['extra']['comm_alone_ms_per_step_by_rank']) == 2 and d['value'] > 0
+    assert d['extra']['f32_exact'] is None and d['extra']['train_e2e'] is None and 'cpu_baseline' not in d       # rank-0-at-N=1 legs only
