@@ -305,16 +305,14 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         // h0_t (no layer-1 input-projection GEMM, no GI round trip through HBM for it)
         const float* const* w0 = weights; const float* const* w1 = weights + 4;
         for (int k = 0; k < 4; ++k) DEP_CHECK_ARG(w0[k] && w1[k]);
-        rc = dep_pack_cluster_fwd_split(w0[1], R + lo.wp[0][0], H, s); if (rc) return rc;
-        rc = dep_pack_cluster_fwd_split(w1[1], R + lo.wp[1][0], H, s); if (rc) return rc;
-        rc = dep_pack_cluster_fwd_split(w1[0], W + lo.wih_img, H, s); if (rc) return rc;
-        if (d->training) {
-            // same choice as the per-layer path below: the 16-unit-member backward (DEP_CLUSTER16_BWD=1) reads its own image
-            for (int l = 0; l < 2; ++l) {
-                const float* whh = l == 0 ? w0[1] : w1[1];
-                rc = lo.cluster16_bwd ? dep_pack_cluster16_bwd(whh, R + lo.wpT[l][0], H, s)
-                                      : dep_pack_cluster_bwd_split(whh, R + lo.wpT[l][0], H, s);
-                if (rc) return rc;
+        {   // every weight image of the step in one launch: W_hh(l0), W_hh(l1), W_ih(l1) forward images; the backward's two
+            const float* srcs[5] = {w0[1], w1[1], w1[0], w0[1], w1[1]};
+            float* dsts[5] = {R + lo.wp[0][0], R + lo.wp[1][0], W + lo.wih_img, R + lo.wpT[0][0], R + lo.wpT[1][0]};
+            const int kinds[5] = {0, 0, 0, 1, 1};
+            const bool bwd_multi = d->training && !lo.cluster16_bwd;
+            rc = dep_pack_cluster_split_multi(bwd_multi ? 5 : 3, srcs, dsts, kinds, H, s); if (rc) return rc;
+            if (d->training && lo.cluster16_bwd) {       // the 16-unit-member backward (DEP_CLUSTER16_BWD=1) reads its own image
+                for (int l = 0; l < 2; ++l) { rc = dep_pack_cluster16_bwd(l == 0 ? w0[1] : w1[1], R + lo.wpT[l][0], H, s); if (rc) return rc; }
             }
         }
         float* gi = W + lo.gi;

@@ -210,6 +210,7 @@ int dep_cluster_reset_status(void* xbuf, hipStream_t s);
 int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster16_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s);
+int dep_pack_cluster_split_multi(int n, const float* const* src, float* const* dst, const int* bwd, int H, hipStream_t s);
 int dep_pack_cluster_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_lstm_split(const float* w_hh, float* wp, float* wpT, int H, hipStream_t s);
 int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);

@@ -633,7 +633,55 @@ __global__ void pack_cluster_fwd_split_kernel(const float* __restrict__ W, u32x4
     out[(idx - lane) * 2 + 64 + lane] = lo;
 }
 
+// all split-precision images of a step in ONE launch (blockIdx.y = job): five ~4.5 us launches per training step otherwise
+struct PackJobs { const float* src[8]; u32x4* dst[8]; int bwd[8]; int n; };
+__global__ void pack_cluster_split_multi_kernel(PackJobs j, int H) {
+    const int k = blockIdx.y;
+    if (k >= j.n) return;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float* W = j.src[k]; u32x4* out = j.dst[k];
+    if (j.bwd[k]) {
+        const long n = (long)(H / 32) * (H / 16) * 3 * 64;
+        if (idx >= n) return;
+        const int lane = idx & 63; long r = idx >> 6;
+        const int ks = r % 3; r /= 3;
+        const int jt = r % (H / 16); const int c = r / (H / 16);
+        const float* src = W + (size_t)(ks * H + 32 * c + 8 * (lane >> 4)) * H + jt * 16 + (lane & 15);
+        u32x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsigned h, l; split_pair(src[(size_t)(2 * e) * H], src[(size_t)(2 * e + 1) * H], h, l); hi[e] = h; lo[e] = l; }
+        out[(idx - lane) * 2 + lane] = hi;
+        out[(idx - lane) * 2 + 64 + lane] = lo;
+    } else {
+        const int KS2 = H / 64;
+        const long n = (long)(H / 16) * 3 * 2 * KS2 * 64;
+        if (idx >= n) return;
+        const int lane = idx & 63; long r = idx >> 6;
+        const int ks = r % KS2; r /= KS2;
+        const int kh = r % 2; r /= 2;
+        const int g = r % 3; const int jt = r / 3;
+        const float* src = W + (size_t)(g * H + jt * 16 + (lane & 15)) * H + kh * (H / 2) + 32 * ks + 8 * (lane >> 4);
+        u32x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsigned h, l; split_pair(src[2 * e], src[2 * e + 1], h, l); hi[e] = h; lo[e] = l; }
+        out[(idx - lane) * 2 + lane] = hi;
+        out[(idx - lane) * 2 + 64 + lane] = lo;
+    }
+}
+
 }  // namespace
+
+// (H x 3H recurrent / input weight) -> forward (bwd[k] = 0) or backward (1) split image, up to 8 jobs in one launch
+int dep_pack_cluster_split_multi(int n, const float* const* src, float* const* dst, const int* bwd, int H, hipStream_t s) {
+    DEP_CHECK_ARG(n > 0 && n <= 8 && src && dst && bwd);
+    PackJobs j{};
+    j.n = n;
+    for (int k = 0; k < n; ++k) { DEP_CHECK_ARG(src[k] && dst[k]); j.src[k] = src[k]; j.dst[k] = (u32x4*)dst[k]; j.bwd[k] = bwd[k]; }
+    const long nf = (long)(H / 16) * 3 * 2 * (H / 64) * 64, nb = (long)(H / 32) * (H / 16) * 3 * 64;
+    hipLaunchKernelGGL(pack_cluster_split_multi_kernel, dim3(dep_cdiv(nf > nb ? nf : nb, 256), n), dim3(256), 0, s, j, H);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
 
 int dep_pack_cluster_fwd_split(const float* w_hh, float* out, int H, hipStream_t s) {
     const long n = (long)(H / 16) * 3 * 2 * (H / 64) * 64;
