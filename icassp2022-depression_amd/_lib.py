@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, 'libdep_rnn.so')
 CELL_GRU, CELL_LSTM = 0, 1
 POOL_NONE, POOL_MEAN, POOL_SUM = 0, 1, 2
 LOSS_CE_ON_SOFTMAX, LOSS_L1_RELU, LOSS_SMOOTHL1_RELU, LOSS_CE_LOGITS, LOSS_SMOOTHL1 = 0, 1, 2, 3, 4
+LOSS_LABELS_I64 = 0x100                     # OR into a CE kind: int64 labels read in place
 SITE_FC0, SITE_FC1, SITE_FC2, SITE_FC3 = 1, 2, 3, 4
 
 
@@ -82,6 +83,9 @@ _SIGS = {
     'dep_colsum': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     'dep_head_loss': (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     'dep_reduce_loss': (C.c_int, [_P, C.c_int, C.c_float, _P, C.c_int, _P]),
+    'dep_head_mlp_supported': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'dep_head_mlp_fwd': (C.c_int, [_P] * 9 + [C.c_int] * 4 + [C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P]),
+    'dep_head_mlp_bwd': (C.c_int, [_P] * 12 + [C.c_int] * 4 + [C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P]),
     'dep_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int, C.c_int, _P]),
     'dep_frame_window': (C.c_int, [_P, C.c_long, C.c_int, C.c_int, C.c_int, _P, _P]),
@@ -240,6 +244,28 @@ def head_loss(kind, z, target, out, loss_rows, dz, norm):
     B, Cc = z.shape
     check(load().dep_head_loss(kind, _ptr(z), _ptr(target), _ptr(out), _ptr(loss_rows), _ptr(dz), B, Cc, float(norm),
                                stream()), 'dep_head_loss')
+
+
+def head_mlp_supported(Hin, H1, Cc):
+    """Widths the fused head kernels cover (DEP_HEAD_FUSED=0 keeps the composed launches: A/B switch)."""
+    return os.environ.get('DEP_HEAD_FUSED', '1') != '0' and bool(load().dep_head_mlp_supported(Hin, H1, Cc))
+
+
+def head_mlp_fwd(x, W1, b1, W2, b2, a0, z1, a1, z2, p, seed, sites, first):
+    B, Hin = x.shape
+    H1 = W1.shape[0]
+    Cc = 0 if W2 is None else W2.shape[0]
+    check(load().dep_head_mlp_fwd(_ptr(x), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(a0), _ptr(z1), _ptr(a1), _ptr(z2),
+                                  B, Hin, H1, Cc, float(p), int(seed), int(sites[0]), int(sites[1]), int(first), stream()),
+          'dep_head_mlp_fwd')
+
+
+def head_mlp_bwd(dz2, a0, z1, a1, W1, W2, dW1, db1, dW2, db2, dx, dz1, p, seed, sites, first):
+    B, Hin = a0.shape
+    H1, Cc = W1.shape[0], W2.shape[0]
+    check(load().dep_head_mlp_bwd(_ptr(dz2), _ptr(a0), _ptr(z1), _ptr(a1), _ptr(W1), _ptr(W2), _ptr(dW1), _ptr(db1), _ptr(dW2),
+                                  _ptr(db2), _ptr(dx), _ptr(dz1), B, Hin, H1, Cc, float(p), int(seed), int(sites[0]),
+                                  int(sites[1]), int(first), stream()), 'dep_head_mlp_bwd')
 
 
 def reduce_loss(loss_rows, norm, loss_out, accumulate=False):

@@ -110,20 +110,22 @@ __global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const float* __restric
 }
 // backward: given P = dL/dWf (J,F) and q = dL/dbf (J):
 //     dW[j,f] = P[j,f] gamma[f] + q[j] beta[f] ,  db = q ,  dgamma[f] = sum_j P[j,f] W[j,f] ,  dbeta[f] = sum_j W[j,f] q[j]
-// block = 64 columns x 16 row groups (1024 threads): coalesced row segments, 16 partial sums per column reduced in LDS
+// block = 16 columns x 64 row groups (1024 threads): 64-byte row segments, 64 partial sums per column reduced in LDS.  (With
+// 64 columns x 16 row groups only F / 64 = 4 CUs moved the 2.3 MB of the cfg2 fold: 14 us, CU-bandwidth bound.)
+constexpr int LFC = 16, LFR = 64;
 __global__ __launch_bounds__(1024) void ln_fold_bwd_kernel(const float* __restrict__ W, const float* __restrict__ P,
                                                            const float* __restrict__ q, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ dW,
                                                            float* __restrict__ db, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int J, int F) {
-    __shared__ float red[2][16][64];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int f = blockIdx.x * 64 + c;
+    __shared__ float red[2][LFR][LFC];
+    const int c = threadIdx.x % LFC, rg = threadIdx.x / LFC;
+    const int f = blockIdx.x * LFC + c;
     float dg = 0.f, dbt = 0.f;
     if (f < F) {
         const float g = gamma[f], bt = beta[f];
 #pragma unroll 4
-        for (int j = rg; j < J; j += 16) {
+        for (int j = rg; j < J; j += LFR) {
             const float w = W[(size_t)j * F + f], pj = P[(size_t)j * F + f], qj = q[j];
             dW[(size_t)j * F + f] = fmaf(pj, g, qj * bt);
             dg = fmaf(pj, w, dg);
@@ -132,11 +134,11 @@ __global__ __launch_bounds__(1024) void ln_fold_bwd_kernel(const float* __restri
     }
     red[0][rg][c] = dg; red[1][rg][c] = dbt;
     __syncthreads();
-    if (rg == 0 && f < F) {
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { a += red[0][r][c]; b += red[1][r][c]; }
-        dgamma[f] = a; dbeta[f] = b;
+    if (rg < 2 && f < F) {                                         // row group 0 sums dgamma, row group 1 dbeta
+        float a = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < LFR; ++r) a += red[rg][r][c];
+        (rg == 0 ? dgamma : dbeta)[f] = a;
     }
     if (blockIdx.x == 0) for (int j = threadIdx.x; j < J; j += 1024) db[j] = q[j];
 }
@@ -236,6 +238,8 @@ __global__ void head_loss_kernel(int kind, const float* __restrict__ z, const vo
                                  int B, int C, float inv_norm) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const bool wide = (kind & DEP_LOSS_LABELS_I64) != 0;       // class labels as torch.long, read in place
+    kind &= ~DEP_LOSS_LABELS_I64;
     const float* zr = z + (size_t)b * C;
     float v[MAXC];
     if (kind == DEP_LOSS_CE_ON_SOFTMAX || kind == DEP_LOSS_CE_LOGITS) {
@@ -245,7 +249,7 @@ __global__ void head_loss_kernel(int kind, const float* __restrict__ z, const vo
         for (int c = 0; c < C; ++c) { v[c] = expf(zr[c] - mx); s += v[c]; }
         for (int c = 0; c < C; ++c) { v[c] /= s; if (out) out[(size_t)b * C + c] = v[c]; }   // softmax(z)
         if (!target) return;
-        const int y = ((const int32_t*)target)[b];
+        const int y = wide ? (int)((const int64_t*)target)[b] : ((const int32_t*)target)[b];
         if (kind == DEP_LOSS_CE_LOGITS) {
             if (loss_rows) loss_rows[b] = -((zr[y] - mx) - logf(s));
             if (dz) for (int c = 0; c < C; ++c) dz[(size_t)b * C + c] = (v[c] - (c == y ? 1.f : 0.f)) * inv_norm;
@@ -444,7 +448,7 @@ extern "C" int dep_ln_fold_fwd(const float* W, const float* b, const float* gamm
 extern "C" int dep_ln_fold_bwd(const float* W, const float* dWf, const float* dbf, const float* gamma, const float* beta,
                                float* dW, float* db, float* dgamma, float* dbeta, int J, int F, void* stream) {
     DEP_CHECK_ARG(W && dWf && dbf && gamma && beta && dW && db && dgamma && dbeta && J > 0 && F > 0);
-    hipLaunchKernelGGL(ln_fold_bwd_kernel, dim3(dep_cdiv(F, 64)), dim3(1024), 0, S_, W, dWf, dbf, gamma, beta, dW, db, dgamma, dbeta, J, F);
+    hipLaunchKernelGGL(ln_fold_bwd_kernel, dim3(dep_cdiv(F, LFC)), dim3(1024), 0, S_, W, dWf, dbf, gamma, beta, dW, db, dgamma, dbeta, J, F);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -514,7 +518,8 @@ extern "C" int dep_colsum(const float* x, int M, int N, int ld, float* out, void
 }
 extern "C" int dep_head_loss(int kind, const float* z, const void* target, float* out, float* loss_rows, float* dz,
                              int B, int C, float norm, void* stream) {
-    DEP_CHECK_ARG(z && B > 0 && C > 0 && C <= MAXC && kind >= 0 && kind <= 4 && norm > 0.f);
+    DEP_CHECK_ARG(z && B > 0 && C > 0 && C <= MAXC && (kind & ~DEP_LOSS_LABELS_I64) >= 0 && (kind & ~DEP_LOSS_LABELS_I64) <= 4 && norm > 0.f);
+    DEP_CHECK_ARG(!(kind & DEP_LOSS_LABELS_I64) || (kind & ~DEP_LOSS_LABELS_I64) == DEP_LOSS_CE_ON_SOFTMAX || (kind & ~DEP_LOSS_LABELS_I64) == DEP_LOSS_CE_LOGITS);
     DEP_CHECK_ARG(target || (!dz && !loss_rows));
     hipLaunchKernelGGL(head_loss_kernel, dim3(nblk(B, 128)), dim3(128), 0, S_, kind, z, target, out, loss_rows, dz, B, C, 1.0f / norm);
     DEP_CHECK_LAUNCH();

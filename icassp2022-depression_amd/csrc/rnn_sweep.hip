@@ -605,7 +605,15 @@ __global__ void finish_db_kernel(const float* __restrict__ part, int nrows, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4 * H) return;
     float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += part[(size_t)r * 4 * H + i];
+    int r = 0;
+    for (; r + 8 <= nrows; r += 8) {                          // eight loads in flight, added in row order (same sum as a plain loop)
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(r + k) * 4 * H + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; r < nrows; ++r) s += part[(size_t)r * 4 * H + i];
     const int g = i / H, c = i % H;
     if (cell == DEP_CELL_GRU) {
         if (g < 2) { db_ih[g * H + c] = s; db_hh[g * H + c] = s; }

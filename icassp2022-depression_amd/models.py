@@ -71,16 +71,29 @@ class _MLPHead:
     def forward(self, x, seed, training):
         o = self.o; P = o._params
         p = self.p if training else 0.0
+        W1, b1 = P[self.n1 + '.weight'].data, P[self.n1 + '.bias'].data
+        W2 = P[self.n2 + '.weight'].data if self.n2 is not None else None
+        if x.is_contiguous() and W1.is_contiguous() and L.head_mlp_supported(W1.shape[1], W1.shape[0], 0 if W2 is None else W2.shape[0]):
+            # one launch (csrc/head.hip): both dropouts, both Linears, the ReLU
+            B, H1 = x.shape[0], W1.shape[0]
+            first = bool(self.first and p > 0)
+            a0 = torch.empty_like(x) if first else x
+            z1 = torch.empty(B, H1, dtype=torch.float32, device=x.device); a1 = torch.empty_like(z1)
+            z2 = torch.empty(B, W2.shape[0], dtype=torch.float32, device=x.device) if W2 is not None else None
+            L.head_mlp_fwd(x, W1, b1, W2, P[self.n2 + '.bias'].data if W2 is not None else None, a0 if first else None,
+                           z1, a1, z2, p, seed, self.sites, first)
+            self.saved = (a0, z1, a1, p, seed)
+            return z2 if W2 is not None else a1
         if self.first and p > 0:
             a0 = torch.empty_like(x); L.dropout(x, a0, p, seed, self.sites[0])
         else:
             a0 = x
-        z1 = L.linear_fwd(a0, P[self.n1 + '.weight'].data, P[self.n1 + '.bias'].data)
+        z1 = L.linear_fwd(a0, W1, b1)
         a1 = torch.empty_like(z1)
         L.relu_dropout_fwd(z1, a1, p, seed, self.sites[1])
         z2 = None
         if self.n2 is not None:
-            z2 = L.linear_fwd(a1, P[self.n2 + '.weight'].data, P[self.n2 + '.bias'].data)
+            z2 = L.linear_fwd(a1, W2, P[self.n2 + '.bias'].data)
         self.saved = (a0, z1, a1, p, seed)
         return z2 if self.n2 is not None else a1
 
@@ -90,6 +103,12 @@ class _MLPHead:
         a0, z1, a1, p, seed = self.saved
         W1, W2 = P[self.n1 + '.weight'], P[self.n2 + '.weight']
         B, Cc = dz2.shape; H = a1.shape[1]
+        if (dz2.is_contiguous() and a0.is_contiguous() and W1.data.is_contiguous() and W1._grad.is_contiguous()
+                and L.head_mlp_supported(a0.shape[1], H, Cc)):
+            dx = torch.empty_like(a0); dz1 = torch.empty_like(z1)
+            L.head_mlp_bwd(dz2, a0, z1, a1, W1.data, W2.data, W1._grad, P[self.n1 + '.bias']._grad, W2._grad,
+                           P[self.n2 + '.bias']._grad, dx, dz1, p, seed, self.sites, bool(self.first and p > 0))
+            return dx
         L.gemm(1, 0, Cc, H, B, dz2, Cc, a1, H, W2._grad, H)                       # dW2 = dz2^T a1
         L.colsum(dz2, P[self.n2 + '.bias']._grad)
         da1 = torch.empty_like(a1)
@@ -463,15 +482,18 @@ class MyLoss:
         if self.variant == 'clf':
             t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target)
             nn._check_labels(t, Cc)
-            t = t.to(device=dev, dtype=torch.int32).view(-1)
             kind = L.LOSS_CE_LOGITS; norm_local = B
+            if t.dtype == torch.int64:
+                t = t.to(device=dev).contiguous().view(-1); kind |= L.LOSS_LABELS_I64
+            else:
+                t = t.to(device=dev, dtype=torch.int32).contiguous().view(-1)
         else:
             t = torch.as_tensor(np.asarray(target, dtype=np.float32) if not torch.is_tensor(target) else target)
             t = t.to(device=dev, dtype=torch.float32).contiguous().view(B, Cc)
             kind = L.LOSS_SMOOTHL1; norm_local = B * Cc
         norm = parallel.global_count(norm_local) if train else norm_local
         rows = torch.empty(B, dtype=torch.float32, device=dev)
-        val = torch.zeros(1, dtype=torch.float32, device=dev)
+        val = torch.empty(1, dtype=torch.float32, device=dev)                       # overwritten by the first dep_reduce_loss
         dzt = torch.empty_like(zt) if train else None
         dza = torch.empty_like(za) if train else None
         L.head_loss(kind, zt, t, None, rows, dzt, norm); L.reduce_loss(rows, norm, val)

@@ -278,10 +278,14 @@ class _HeadLoss:
         z = output._z
         B, Cc = z.shape
         dev = z.device
+        kind = self.kind
         if self.target_dtype == 'int':
             t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target)
             _check_labels(t, Cc)
-            t = t.to(device=dev, dtype=torch.int32).contiguous().view(-1)
+            if t.dtype == torch.int64:                       # torch.long as the reference's loops make them: read in place
+                t = t.to(device=dev).contiguous().view(-1); kind = self.kind | L.LOSS_LABELS_I64
+            else:
+                t = t.to(device=dev, dtype=torch.int32).contiguous().view(-1)
         else:
             t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target)
             t = t.to(device=dev, dtype=torch.float32).contiguous().view(B, Cc)
@@ -292,8 +296,8 @@ class _HeadLoss:
         norm = parallel.global_count(norm_local) if train else norm_local
         rows = torch.empty(B, dtype=torch.float32, device=dev)
         dz = torch.empty_like(z) if train else None
-        L.head_loss(self.kind, z, t, None, rows, dz, norm)
-        val = torch.zeros(1, dtype=torch.float32, device=dev)
+        L.head_loss(kind, z, t, None, rows, dz, norm)
+        val = torch.empty(1, dtype=torch.float32, device=dev)         # dep_reduce_loss overwrites it
         L.reduce_loss(rows, norm, val)
         return Loss(val, (lambda: owner.backward(dz)) if train else None, reduce=train and parallel.world_size() > 1,
                     health=getattr(owner, 'check_health', None))

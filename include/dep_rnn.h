@@ -266,10 +266,12 @@ int dep_relu_dropout_bwd(const float* da, const float* z, float* dz, long n, flo
 int dep_colsum(const float* x, int M, int N, int ld, float* out, void* stream);
 
 enum { DEP_LOSS_CE_ON_SOFTMAX = 0, DEP_LOSS_L1_RELU = 1, DEP_LOSS_SMOOTHL1_RELU = 2, DEP_LOSS_CE_LOGITS = 3,
-       DEP_LOSS_SMOOTHL1 = 4 };
+       DEP_LOSS_SMOOTHL1 = 4,
+       DEP_LOSS_LABELS_I64 = 0x100 /* OR into a CE kind: target holds int64 labels (torch.long, as the reference's loops make
+                                      them: audio_gru_whole.py:178) instead of int32 -- no cast kernel per mini-batch */ };
 /* Output nonlinearity + loss + its gradient w.r.t. the pre-activation z (B,C), one kernel:
  *   CE_ON_SOFTMAX : out = softmax(z) ; loss = CrossEntropyLoss(out, y)  (double softmax,
- *                   audio_gru_whole.py:72,188,308)              target = int32 labels
+ *                   audio_gru_whole.py:72,188,308)              target = int32 labels (int64 with DEP_LOSS_LABELS_I64)
  *   L1_RELU       : out = relu(z) ; L1Loss(out, y)   (audio_bilstm_perm.py:91,251)  target = float
  *   SMOOTHL1_RELU : out = relu(z) ; SmoothL1Loss(out, y) (text_bilstm_perm.py:247)   target = float
  *   CE_LOGITS / SMOOTHL1 : plain losses on z (MyLoss halves, fuse_net_whole.py:384-395)
@@ -280,6 +282,26 @@ int dep_head_loss(int kind, const float* z, const void* target, float* out, floa
                   float* dz, int B, int C, float norm, void* stream);
 /* loss = sum(loss_rows[0..B)) / norm, deterministic single-block tree; result on device. */
 int dep_reduce_loss(const float* loss_rows, int B, float norm, float* loss_out, int accumulate, void* stream);
+
+/* The models' MLP head as three launches (one forward, two backward) instead of fifteen:
+ *     [Dropout(p)] -> Linear(Hin,H1) -> ReLU -> Dropout(p) -> [Linear(H1,C)]
+ * (fc_audio: Classification/audio_gru_whole.py:66-73, Regression/audio_bilstm_perm.py:60-67 -- first_dropout = 1;
+ *  fc_out: Classification/text_bilstm_whole.py:60-66 -- first_dropout = 0).  Exact fp32, fixed summation order; the masks are the
+ * draws dep_dropout / dep_relu_dropout_* make at (seed, site0) / (seed, site1).  W1 (H1,Hin), W2 (C,H1) row-major as
+ * torch.nn.Linear holds them; W1 16-byte aligned.  dep_head_mlp_supported says which widths are covered (Hin, H1 <= 256,
+ * Hin % 32 == 0, H1 % 4 == 0, C <= 16); other shapes are composed from dep_gemm_f32 / dep_relu_dropout_* / dep_colsum.
+ *   fwd : a0 (B,Hin) = dropout(x) (written only if first_dropout && p > 0; otherwise x itself is the saved input),
+ *         z1, a1 (B,H1) saved for the backward, z2 (B,C) the pre-activation dep_head_loss takes (C = 0: stop at a1).
+ *   bwd : dz2 (B,C) from dep_head_loss; a0 = what the forward saved (x when no first dropout ran); dW1, db1, dW2, db2
+ *         OVERWRITTEN; dx (B,Hin) or NULL; dz1 (B,H1) scratch. */
+int dep_head_mlp_supported(int Hin, int H1, int C);
+int dep_head_mlp_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* a0,
+                     float* z1, float* a1, float* z2, int B, int Hin, int H1, int C, float p, uint64_t seed,
+                     uint32_t site0, uint32_t site1, int first_dropout, void* stream);
+int dep_head_mlp_bwd(const float* dz2, const float* a0, const float* z1, const float* a1, const float* W1,
+                     const float* W2, float* dW1, float* db1, float* dW2, float* db2, float* dx, float* dz1, int B,
+                     int Hin, int H1, int C, float p, uint64_t seed, uint32_t site0, uint32_t site1, int first_dropout,
+                     void* stream);
 
 /* ------------------------------------------------------------------ optimizer ------ */
 /* torch.optim.Adam / AdamW update on a contiguous parameter range (audio_gru_whole.py:307 AdamW

@@ -390,6 +390,13 @@ def test_head_loss_kinds():
     assert np.abs(host(out) - p).max() < 1e-6
     assert abs(host(loss)[0] - lr_) < 1e-6
     assert relerr(host(dz), R.softmax_bwd(p, dp)) < 1e-5
+    # the same with torch.long labels read in place (DEP_LOSS_LABELS_I64): bit-identical
+    y64 = torch.from_numpy(y.astype(np.int64)).to(DEV)
+    dz64 = torch.empty_like(dz); rows64 = torch.empty_like(rows)
+    L.head_loss(L.LOSS_CE_ON_SOFTMAX | L.LOSS_LABELS_I64, zd, y64, out, rows64, dz64, B)
+    assert torch.equal(dz64, dz) and torch.equal(rows64, rows)
+    with pytest.raises(L.DepError):
+        L.head_loss(L.LOSS_L1_RELU | L.LOSS_LABELS_I64, zd, y64, out, rows64, dz64, B)
     # CE on logits
     L.head_loss(L.LOSS_CE_LOGITS, zd, yd, out, rows, dz, B)
     L.reduce_loss(rows, B, loss)
@@ -437,6 +444,61 @@ def test_relu_dropout_colsum_adam():
             L.adam_step(pd, dev(g), md, vd, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, step)
             p, m, v = R.adam_step(p, g, m, v, step, 1e-3, wd=wd, decoupled=decoupled)
         assert np.abs(host(pd) - p).max() < 1e-6
+
+
+@pytest.mark.parametrize('B,Hin,H1,C', [(5, 32, 8, 2), (512, 256, 256, 2), (77, 128, 128, 1), (64, 256, 64, 0), (3, 64, 256, 16)])
+@pytest.mark.parametrize('p,first', [(0.0, 0), (0.5, 1), (0.3, 0)])
+def test_fused_mlp_head_against_float64_with_the_same_masks(B, Hin, H1, C, p, first):
+    """csrc/head.hip: [Dropout] -> Linear -> ReLU -> Dropout -> [Linear] in one launch, its backward in two; the masks are
+    the draws of the stand-alone dropout kernels (dep_dropout_mask at the same seed / site)."""
+    assert L.head_mlp_supported(Hin, H1, C)
+    rng = np.random.default_rng(B * 7 + Hin + C)
+    x = rng.standard_normal((B, Hin)).astype(np.float32)
+    W1 = (rng.standard_normal((H1, Hin)) * 0.1).astype(np.float32); b1 = rng.standard_normal(H1).astype(np.float32)
+    W2 = (rng.standard_normal((max(C, 1), H1)) * 0.1).astype(np.float32); b2 = rng.standard_normal(max(C, 1)).astype(np.float32)
+    seed, sites = 1234, (L.SITE_FC0, L.SITE_FC1)
+    m0 = host(L.dropout_mask(B * Hin, p, seed, sites[0], DEV)).reshape(B, Hin) if (first and p > 0) else np.ones((B, Hin))
+    m1 = host(L.dropout_mask(B * H1, p, seed, sites[1], DEV)).reshape(B, H1) if p > 0 else np.ones((B, H1))
+    a0r = x.astype(np.float64) * m0
+    z1r = a0r @ W1.T.astype(np.float64) + b1
+    a1r = np.maximum(z1r, 0) * m1
+    xd, W1d, b1d = dev(x), dev(W1), dev(b1)
+    W2d, b2d = (dev(W2), dev(b2)) if C else (None, None)
+    use0 = bool(first and p > 0)
+    a0 = torch.empty_like(xd) if use0 else xd
+    z1 = torch.empty(B, H1, device=DEV); a1 = torch.empty_like(z1)
+    z2 = torch.empty(B, C, device=DEV) if C else None
+    L.head_mlp_fwd(xd, W1d, b1d, W2d, b2d, a0 if use0 else None, z1, a1, z2, p, seed, sites, use0)
+    assert np.abs(host(a0) - a0r).max() < 1e-6
+    assert relerr(host(z1), z1r) < 2e-6 and relerr(host(a1), a1r) < 2e-6
+    assert ((host(a1) == 0) == (a1r == 0)).all()                      # same mask, same ReLU pattern
+    if not C:
+        return
+    z2r = a1r @ W2.T.astype(np.float64) + b2
+    assert relerr(host(z2), z2r) < 2e-6
+    dz2 = rng.standard_normal((B, C)).astype(np.float32)
+    dW1 = torch.full((H1, Hin), 7.0, device=DEV); db1 = torch.full((H1,), 7.0, device=DEV)      # must be overwritten
+    dW2 = torch.full((C, H1), 7.0, device=DEV); db2 = torch.full((C,), 7.0, device=DEV)
+    dx = torch.empty_like(xd); dz1 = torch.empty_like(z1)
+    L.head_mlp_bwd(dev(dz2), a0, z1, a1, W1d, W2d, dW1, db1, dW2, db2, dx, dz1, p, seed, sites, use0)
+    da1 = dz2.astype(np.float64) @ W2
+    dz1r = da1 * (host(z1) > 0) * m1
+    assert relerr(host(dz1), dz1r) < 2e-6
+    assert relerr(host(dW2), dz2.astype(np.float64).T @ a1r) < 5e-6 and relerr(host(db2), dz2.astype(np.float64).sum(0)) < 5e-6
+    assert relerr(host(dW1), dz1r.T @ a0r) < 5e-6 and relerr(host(db1), dz1r.sum(0)) < 5e-6
+    assert relerr(host(dx), (dz1r @ W1) * m0) < 5e-6
+    # the composed launches (DEP_HEAD_FUSED=0 path of models._MLPHead) agree
+    zc = L.linear_fwd(a0, W1d, b1d)
+    assert relerr(host(zc), host(z1)) < 2e-6
+
+
+def test_fused_mlp_head_refuses_shapes_it_does_not_cover():
+    assert not L.load().dep_head_mlp_supported(300, 256, 2) and not L.load().dep_head_mlp_supported(40, 256, 2)
+    assert not L.load().dep_head_mlp_supported(256, 256, 17)
+    x = torch.zeros(4, 40, device=DEV); W1 = torch.zeros(8, 40, device=DEV); b1 = torch.zeros(8, device=DEV)
+    z1 = torch.zeros(4, 8, device=DEV)
+    with pytest.raises(L.DepError):
+        L.head_mlp_fwd(x, W1, b1, None, None, None, z1, torch.empty_like(z1), None, 0.0, 0, (L.SITE_FC0, L.SITE_FC1), False)
 
 
 def test_bad_arguments_fail_loudly():
