@@ -83,6 +83,7 @@ _SIGS = {
     'dep_colsum': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     'dep_head_loss': (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     'dep_reduce_loss': (C.c_int, [_P, C.c_int, C.c_float, _P, C.c_int, _P]),
+    'dep_gemm_set_xcds': (C.c_int, [C.c_int, C.c_int]),
     'dep_head_mlp_supported': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'dep_head_mlp_fwd': (C.c_int, [_P] * 9 + [C.c_int] * 4 + [C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P]),
     'dep_head_mlp_bwd': (C.c_int, [_P] * 12 + [C.c_int] * 4 + [C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _P]),

@@ -206,6 +206,9 @@ int dep_gemm_bf16x3(int transA, int transB, int M, int N, int K,
                     const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     const float* bias, float beta, int seq_T, int shiftB,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* Experiment hook (tools/exp_overlap2.py): confine the working workgroups of the calling thread's next
+ * split-precision GEMMs to XCDs [lo, lo + n) -- block index % 8 is the XCD.  (0, 8) = whole chip, the default. */
+int dep_gemm_set_xcds(int lo, int n);
 /* mode 2 (DEP_GEMM_MODE=bf16) is the THROUGHPUT mode BASELINE configs[1] calls "bf16": the large contractions form a_hi * b_hi only
  * (plain bf16 products, fp32 accumulation; a third of the MFMAs).  Relative error per product ~4e-3: it cannot meet the path's
  * 1e-4 parity bar, is never the default and is benchmarked on its own labelled line (bench.py extra.bf16_products). */
