@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdep_rnn.so')
-SOURCES = ['api.hip', 'gemm.hip', 'gemm_bf16x3.hip', 'rnn_sweep.hip', 'rnn_cluster.hip', 'rnn_cluster_bwd.hip', 'rnn_cluster16.hip', 'rnn_cluster_lstm.hip', 'rnn_fused2.hip', 'rnn_fused2_bwd.hip', 'elementwise.hip', 'head.hip', 'frontend.hip', 'comm.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'gemm_bf16x3.hip', 'rnn_sweep.hip', 'rnn_cluster.hip', 'rnn_cluster_bwd.hip', 'rnn_cluster16.hip', 'rnn_cluster_lstm.hip', 'rnn_fused2.hip', 'rnn_fused2_bwd.hip', 'elementwise.hip', 'head.hip', 'attention.hip', 'frontend.hip', 'comm.hip']
 HEADERS = ['dep_common.h', 'rnn_cluster_common.h', os.path.join('..', '..', 'include', 'dep_rnn.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result',
          '-Wno-pass-failed']

@@ -362,6 +362,21 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         if (y) { rc = dep_axpby(R + lo.y[1], y, (long)lo.BT * H, 1.f, 0.f, s); if (rc) return rc; }
         return DEP_OK;
     }
+    if (D == 2) {
+        // gather every layer's direction-stacked W_ih and folded bias (b_ih [+ b_hh]) in one launch (16 jobs at a time)
+        const float* src[16]; const float* add[16]; float* dst[16]; long cnt[16]; int nj = 0;
+        for (int l = 0; l < L; ++l) {
+            const int Kl = l == 0 ? d->F : D * H;
+            for (int dd = 0; dd < D; ++dd) {
+                const float* const* wl = weights + (size_t)(l * D + dd) * 4;
+                DEP_CHECK_ARG(wl[0] && wl[1] && wl[2] && wl[3]);
+                src[nj] = wl[0]; add[nj] = nullptr; dst[nj] = R + lo.wstack[l] + (size_t)dd * G * H * Kl; cnt[nj++] = (long)G * H * Kl;
+                src[nj] = wl[2]; add[nj] = d->cell == DEP_CELL_LSTM ? wl[3] : nullptr; dst[nj] = R + lo.bstack[l] + (size_t)dd * G * H; cnt[nj++] = (long)G * H;
+                if (nj == 16) { rc = dep_multi_copy(nj, src, add, dst, cnt, s); if (rc) return rc; nj = 0; }
+            }
+        }
+        if (nj) { rc = dep_multi_copy(nj, src, add, dst, cnt, s); if (rc) return rc; }
+    }
     for (int l = 0; l < L; ++l) {
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
         const int Kl = l == 0 ? d->F : D * H;
@@ -389,14 +404,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
                 }
             }
             const float* bias = wl[2];
-            if (stacked) {
-                // stack this direction's W_ih and (b_ih + b_hh) behind the other's; the GEMM follows the loop
-                float* ws_ = R + lo.wstack[l] + (size_t)dd * G * H * Kl; float* bs_ = R + lo.bstack[l] + (size_t)dd * G * H;
-                rc = dep_axpby(wl[0], ws_, (long)G * H * Kl, 1.f, 0.f, s); if (rc) return rc;
-                rc = dep_axpby(wl[2], bs_, (long)G * H, 1.f, 0.f, s); if (rc) return rc;
-                if (d->cell == DEP_CELL_LSTM) { rc = dep_axpby(wl[3], bs_, (long)G * H, 1.f, 1.f, s); if (rc) return rc; }
-                continue;
-            }
+            if (stacked) continue;                     // weights and biases were stacked above; the GEMM follows the loop
             if (d->cell == DEP_CELL_LSTM) {          // both biases fold into the projection
                 float* tb = W + lo.biastmp;
                 rc = dep_axpby(wl[2], tb, (long)G * H, 1.f, 0.f, s); if (rc) return rc;
@@ -599,10 +607,11 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
             float* dws = W + lo.dwstack;
             rc = dep_gemm_internal(1, 0, D * G * H, Kl, BTr, dgi, ldg, in, Kl, dws, Kl, nullptr, 0.f, 0, 0, gws, gwsb, s);
             if (rc) return rc;
+            const float* src[2]; float* dst[2]; long cnt[2];
             for (int dd = 0; dd < D; ++dd) {
-                float* const* gl = dweights + (size_t)(l * D + dd) * 4;
-                rc = dep_axpby(dws + (size_t)dd * G * H * Kl, gl[0], (long)G * H * Kl, 1.f, 0.f, s); if (rc) return rc;
+                src[dd] = dws + (size_t)dd * G * H * Kl; dst[dd] = (dweights + (size_t)(l * D + dd) * 4)[0]; cnt[dd] = (long)G * H * Kl;
             }
+            rc = dep_multi_copy(D, src, nullptr, dst, cnt, s); if (rc) return rc;
         }
         for (int dd = 0; dd < D; ++dd) {
             float* const* gl = dweights + (size_t)(l * D + dd) * 4;

@@ -211,6 +211,11 @@ int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster16_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_split_multi(int n, const float* const* src, float* const* dst, const int* bwd, int H, hipStream_t s);
+int dep_multi_copy(int count, const float* const* src, const float* const* add, float* const* dst, const long* n, hipStream_t s);
+// attention.hip: the loads-in-flight attention kernels (H in {64,128,256}); 1 = launched, 0 = shape left to elementwise.hip's
+int dep_attn2_fwd(const float* out, const float* pre, float* ctx, float* alpha, int B, int T, int H, hipStream_t s);
+int dep_attn2_bwd(const float* dctx, const float* out, const float* alpha, const float* pre, float* dout, float* dpre, int B,
+                  int T, int H, hipStream_t s);
 int dep_pack_cluster_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_lstm_split(const float* w_hh, float* wp, float* wpT, int H, hipStream_t s);
 int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);

@@ -320,6 +320,16 @@ __global__ void axpby_kernel(const float* x, float* y, long n, float a, float b)
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
 }
+// several small copies (optionally sums of two sources) in ONE launch: blockIdx.y = job.  The bidirectional stacks gather
+// their direction-stacked weights / folded biases with it: twelve 5 us launches per forward otherwise.
+struct CopyJobs { const float* src[16]; const float* add[16]; float* dst[16]; long n[16]; int count; };
+__global__ void multi_copy_kernel(CopyJobs j) {
+    const int k = blockIdx.y;
+    if (k >= j.count) return;
+    const float* __restrict__ s = j.src[k]; const float* __restrict__ a = j.add[k]; float* __restrict__ d = j.dst[k];
+    const long n = j.n[k], stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = a ? s[i] + a[i] : s[i];
+}
 __global__ void sigmoid_gate_kernel(const float* g, const float* x, float* y, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = dep_sigmoid(g[i]) * x[i];
@@ -549,6 +559,23 @@ extern "C" int dep_fill(float* p, long n, float value, void* stream) {
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
+// dst[k][i] = src[k][i] (+ add[k][i] when add[k] != NULL), k < count <= 16, one launch
+int dep_multi_copy(int count, const float* const* src, const float* const* add, float* const* dst, const long* n, hipStream_t s) {
+    DEP_CHECK_ARG(count > 0 && count <= 16 && src && dst && n);
+    CopyJobs j{};
+    long mx = 0;
+    for (int k = 0; k < count; ++k) {
+        DEP_CHECK_ARG(src[k] && dst[k] && n[k] > 0);
+        j.src[k] = src[k]; j.add[k] = add ? add[k] : nullptr; j.dst[k] = dst[k]; j.n[k] = n[k];
+        if (n[k] > mx) mx = n[k];
+    }
+    j.count = count;
+    int gx = dep_cdiv(mx, 256 * 4); if (gx > 512) gx = 512; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(gx, count), dim3(256), 0, s, j);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
+
 extern "C" int dep_axpby(const float* x, float* y, long n, float a, float b, void* stream) {
     DEP_CHECK_ARG(x && y && n > 0);
     hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n)), dim3(256), 0, S_, x, y, n, a, b);
@@ -570,8 +597,10 @@ extern "C" int dep_attn_fwd(const float* out, const float* h_n, int K, const flo
     DEP_CHECK_LAUNCH();
     int rc = dep_gemm_internal(0, 1, B, H, H, hsum, H, Wa, H, pre, H, ba, 0.f, 0, 0, nullptr, 0, S_);
     if (rc) return rc;
-    const size_t lds = (size_t)(H + T + 16) * sizeof(float);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), lds, S_, out, pre, ctx, alpha, T, H);
+    if (!dep_attn2_fwd(out, pre, ctx, alpha, B, T, H, S_)) {
+        const size_t lds = (size_t)(H + T + 16) * sizeof(float);
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), lds, S_, out, pre, ctx, alpha, T, H);
+    }
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -592,8 +621,10 @@ extern "C" int dep_attn_bwd(const float* dctx, const float* out, const float* Wa
     float* dhs = dpre + (size_t)B * H;
     char* gws = (char*)workspace + dep_align((size_t)2 * B * H * sizeof(float));
     const size_t gws_bytes = workspace_bytes - dep_align((size_t)2 * B * H * sizeof(float));
-    const size_t lds = (size_t)(2 * H + 2 * T + 16) * sizeof(float);
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(256), lds, S_, dctx, out, alpha, pre, dout, dpre, T, H);
+    if (!dep_attn2_bwd(dctx, out, alpha, pre, dout, dpre, B, T, H, S_)) {
+        const size_t lds = (size_t)(2 * H + 2 * T + 16) * sizeof(float);
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(256), lds, S_, dctx, out, alpha, pre, dout, dpre, T, H);
+    }
     DEP_CHECK_LAUNCH();
     // dWa (H,H) = dpre^T (H,B) * hsum (B,H) ; dba = colsum(dpre) ; dhsum = dpre * Wa
     int rc = dep_gemm_internal(1, 0, H, H, B, dpre, H, hsum, H, dWa, H, nullptr, 0.f, 0, 0, gws, gws_bytes, S_);

@@ -62,6 +62,22 @@ class _RnnCache:
         return self.last.fallback_word() if getattr(self, 'last', None) is not None else None
 
 
+def _mlp_feature(x, W1, b1, p, seed, sites):
+    """Dropout(p) -> Linear -> ReLU -> Dropout(p), forward only (the frozen encoders' heads in fusion_net.pretrained_feature):
+    one launch when csrc/head.hip covers the widths, the three composed launches otherwise."""
+    if x.is_contiguous() and W1.is_contiguous() and L.head_mlp_supported(W1.shape[1], W1.shape[0], 0):
+        first = p > 0
+        z1 = torch.empty(x.shape[0], W1.shape[0], dtype=torch.float32, device=x.device); a1 = torch.empty_like(z1)
+        L.head_mlp_fwd(x, W1, b1, None, None, torch.empty_like(x) if first else None, z1, a1, None, p, seed, sites, first)
+        return a1
+    a0 = x
+    if p > 0:
+        a0 = torch.empty_like(x); L.dropout(x, a0, p, seed, sites[0])
+    z = L.linear_fwd(a0, W1, b1)
+    a1 = torch.empty_like(z); L.relu_dropout_fwd(z, a1, p, seed, sites[1])
+    return a1
+
+
 class _MLPHead:
     """[Dropout] -> Linear(H,H) -> ReLU -> Dropout -> [Linear(H,C)]   (fc_audio / fc_out Sequentials)."""
 
@@ -420,11 +436,7 @@ class FusionNet(nn.Module):
         h_n = torch.empty(2 * self.rnn_layers, B, self.text_hidden_dims, dtype=torch.float32, device=self.device)
         rnn.forward(xt, self._wt, seed=seed, h_n=h_n)
         ctx, _ = L.attn_fwd(rnn.layer_output(), h_n, P['attention_layer.0.weight'].data, P['attention_layer.0.bias'].data)
-        a0 = ctx
-        if p > 0:
-            a0 = torch.empty_like(ctx); L.dropout(ctx, a0, p, seed, L.SITE_FC0)
-        z = L.linear_fwd(a0, P['fc_out.1.weight'].data, P['fc_out.1.bias'].data)
-        tf = torch.empty_like(z); L.relu_dropout_fwd(z, tf, p, seed, L.SITE_FC1)
+        tf = _mlp_feature(ctx, P['fc_out.1.weight'].data, P['fc_out.1.bias'].data, p, seed, (L.SITE_FC0, L.SITE_FC1))
         # audio encoder
         Ba, Ta, Fa = xa.shape
         if self.variant == 'clf':
@@ -434,11 +446,7 @@ class FusionNet(nn.Module):
         rna = self._rnn_a.get(Ba, Ta, training)
         pooled = torch.empty(Ba, self.audio_hidden_dims, dtype=torch.float32, device=self.device)
         rna.forward(xn, self._wa, seed=seed + 1, pooled=pooled)
-        a0 = pooled
-        if p > 0:
-            a0 = torch.empty_like(pooled); L.dropout(pooled, a0, p, seed, L.SITE_FC2)
-        z = L.linear_fwd(a0, P['fc_audio.1.weight'].data, P['fc_audio.1.bias'].data)
-        af = torch.empty_like(z); L.relu_dropout_fwd(z, af, p, seed, L.SITE_FC3)
+        af = _mlp_feature(pooled, P['fc_audio.1.weight'].data, P['fc_audio.1.bias'].data, p, seed, (L.SITE_FC2, L.SITE_FC3))
         return tf, af
 
     def forward(self, x):

@@ -353,7 +353,10 @@ def test_rnn_generic_and_mfma_agree_on_cfg1_shape():
 
 
 # ----------------------------------------------------------------------------- attention
-@pytest.mark.parametrize('B,T,H', [(3, 6, 8), (7, 50, 128), (2, 300, 16)])
+# H in {64,128,256}: attention.hip (rows cached in LDS up to T H ~ 39 K floats, re-read beyond: T = 330 at H = 128, 170 at 256);
+# other widths: the first-generation kernels
+@pytest.mark.parametrize('B,T,H', [(3, 6, 8), (7, 50, 128), (2, 300, 16), (5, 300, 128), (3, 330, 128), (4, 33, 64), (5, 60, 256), (6, 90, 256),
+                                   (2, 170, 256), (2, 1, 128), (3, 17, 128)])
 def test_attention(B, T, H):
     rng = np.random.default_rng(B + T + H)
     out = rng.standard_normal((B, T, 2 * H)).astype(np.float32).astype(np.float64)
