@@ -330,6 +330,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         for (int l = 0; l < 2; ++l) for (int k = 0; k < 4; ++k) f.sv[l][k] = d->training ? R + lo.sv[l][k] : nullptr;
         f.stream = s;
         f.soft_fallback = 1;
+        f.hdr_clean = 1;                                   // dep_cluster_reset_status above zeroed every header slot
         rc = dep_launch_fused2_fwd(f, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
         // Fallback, decided ON THE DEVICE (no host synchronisation, identical on every data-parallel rank): the launch above
         // needs every CU to itself; if a foreign workgroup kept its clusters from assembling it has set the workspace's soft
@@ -357,6 +358,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             a.h_n = h_n ? h_n + (size_t)l * B * H : nullptr;
             if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
             a.only_if = soft; a.stream = s;
+            a.hdr_slot = 1 + l; a.hdr_clean = 1;             // own header slots: still zero from the call's one memset
             rc = dep_launch_cluster_fwd(a, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
         }
         if (y) { rc = dep_axpby(R + lo.y[1], y, (long)lo.BT * H, 1.f, 0.f, s); if (rc) return rc; }
@@ -438,6 +440,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         a.h_n = h_n ? h_n + (size_t)l * D * B * H : nullptr;
         if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
         a.stream = s;
+        a.hdr_slot = l < DEP_HDR_SLOTS ? l : 0; a.hdr_clean = l < DEP_HDR_SLOTS;      // one header slot per layer, zeroed once per call
         rc = use16 ? dep_launch_cluster16_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : lo.cluster ? dep_launch_cluster_fwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_fwd(a);
@@ -540,6 +543,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         return DEP_OK;
     }
     float* pending_ptr = nullptr; long pending_n = 0;      // data parallel: a finished layer's gradient range waiting for the next sweep to be enqueued
+    if (lo.cluster && !lo.cluster16_bwd) { rc = dep_cluster_reset_flags(W + lo.xbuf, s); if (rc) return rc; }      // every layer's header slot in one memset (the status words stay)
     for (int l = L - 1; l >= 0; --l) {
         const bool top = l == L - 1;
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
@@ -565,6 +569,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         float* dghn = lo.dg4 ? dgi + 3 * H : W + lo.dghn;
         a.dgi = dgi; a.dghn = dghn; a.lddg = lo.dg4 ? ldg : 0; a.lddghn = lo.dg4 ? ldg : 0;
         a.dbpart = W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
+        a.hdr_slot = l < DEP_HDR_SLOTS ? l : 0; a.hdr_clean = l < DEP_HDR_SLOTS;
         rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);

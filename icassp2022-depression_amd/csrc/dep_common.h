@@ -125,6 +125,7 @@ struct dep_sweep_args {
     // reserve (training): GRU r,z,n,hn each (B,T,H) ; LSTM gates (B,T,dirs*4H) + c (B,T,dirs*H)
     float* sv0; float* sv1; float* sv2; float* sv3;
     const unsigned* only_if;  // cluster forward: run only when this device word is non-zero (fallback behind an exclusive kernel), or NULL
+    int hdr_slot, hdr_clean;  // cluster sweeps: exchange-header slot of this launch; clean = the caller zeroed it (rnn_cluster_common.h)
     hipStream_t stream;
 };
 int dep_launch_sweep_fwd(const dep_sweep_args& a);
@@ -148,6 +149,7 @@ struct dep_sweep_bwd_args {
                              // dghn = dgi + 3H: one (B,T,4H) array [dr | dz | dn | dn*r], so that dW_hh is ONE contraction
     float* dbpart;           // partial bias sums, see dep_sweep_dbpart_floats
     int dbpart_rows;         // number of partial rows provided
+    int hdr_slot, hdr_clean; // cluster sweeps: exchange-header slot of this launch; clean = the caller zeroed it
     hipStream_t stream;
 };
 int dep_launch_sweep_bwd(const dep_sweep_bwd_args& a);
@@ -186,6 +188,7 @@ struct dep_fused2_args {
     float* pooled; float pool_scale; float* hn0; float* hn1;
     float* sv[2][4];
     int soft_fallback;                                        // 1: a failed hello sets the workspace's soft flag instead of the status word
+    int hdr_clean;                                            // slot 0 was zeroed by the caller (dep_cluster_reset_status)
     hipStream_t stream;
 };
 bool dep_fused2_ok(int cell, int H, int L, int dirs);
@@ -206,7 +209,9 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
 // comm.hip: all-reduce of [buf, buf+n) on comm_stream after everything enqueued so far on `compute`
 int dep_comm_enqueue_after(dep_comm* c, float* buf, long n, hipStream_t compute, hipStream_t comm_stream);
 // clears the sticky status word of a cluster exchange buffer (once per dep_rnn_forward; the sweeps themselves never clear it)
-int dep_cluster_reset_status(void* xbuf, hipStream_t s);
+constexpr int DEP_HDR_SLOTS = 4;                              // exchange-header slots at the head of the buffer (rnn_cluster_common.h)
+int dep_cluster_reset_status(void* xbuf, hipStream_t s);      // status, soft flag and EVERY header slot
+int dep_cluster_reset_flags(void* xbuf, hipStream_t s);       // every header slot, status words kept (dep_rnn_backward)
 int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster16_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s);

@@ -177,6 +177,13 @@ __global__ void splitk_reduce(const unsigned* only_if, const float* __restrict__
     const size_t MN = (size_t)M * N;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int z = 0;
+    for (; z + 15 < splits; z += 16) {                      // sixteen loads in flight; the same four interleaved sums as below
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = part[(size_t)(z + k) * MN + idx];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) { s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; s3 += v[k + 3]; }
+    }
     for (; z + 3 < splits; z += 4) {
         s0 += part[(size_t)z * MN + idx]; s1 += part[(size_t)(z + 1) * MN + idx];
         s2 += part[(size_t)(z + 2) * MN + idx]; s3 += part[(size_t)(z + 3) * MN + idx];

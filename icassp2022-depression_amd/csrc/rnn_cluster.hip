@@ -13,11 +13,11 @@
 // bounds it to 256 (one per CU) or 512 (two per CU) workgroups; larger batches run as consecutive chunks of the batch.
 // (The first version of the exchange, 8-byte {epoch, value} granules polled by the consumers, was 2-3x slower than the
 // flag-published payload for the 4096-value reduce-scatter and is no longer kept.)
-#include "dep_common.h"
+#include "rnn_cluster_common.h"
+
+using depc::BT; using depc::FLAG_OFF; using depc::PAYLOAD_OFF;
 
 namespace {
-
-constexpr int BT = 16;
 
 // cluster-backward weight image: wpc[((c*(H/16) + jt)*KCB + kc)*256 + l*4 + e] = W[(g*H + 32c + u)*H + jt*16 + (l&15)]
 // with k = kc*16 + (l>>4)*4 + e, g = k/32, u = k%32   (G*32 = KS rows of the member, all H columns)
@@ -72,14 +72,18 @@ size_t dep_cluster_xbuf_bytes(int cell, int H, int B, int dirs) {
     if (!dep_cluster_ok(cell, H, B, dirs)) return 0;
     const int NC = H / 32, CH = dep_cluster_chunk(NC, 1, 256);
     const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
-    return 16384 + (size_t)2 * nbtp * NC * BT * H * sizeof(float) * 2;
+    return PAYLOAD_OFF + 8192 + (size_t)2 * nbtp * NC * BT * H * sizeof(float) * 2;
 }
 
 // The status word (first 256 bytes of the exchange buffer header, see rnn_cluster_common.h) is raised by any sweep whose
 // bounded spin gave up and is STICKY: later sweeps of the same step see it at kernel entry and leave at once, so a failure
 // in the layer-0 forward is still there when the host reads dep_rnn_status after the whole step.
 int dep_cluster_reset_status(void* xbuf, hipStream_t s) {
-    if (hipMemsetAsync(xbuf, 0, 256, s) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+    if (hipMemsetAsync(xbuf, 0, PAYLOAD_OFF, s) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+    return DEP_OK;
+}
+int dep_cluster_reset_flags(void* xbuf, hipStream_t s) {
+    if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, s) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
     return DEP_OK;
 }
 

@@ -498,16 +498,16 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
     p.sv0 = a.training ? a.sv0 : nullptr; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
     const size_t pay = (size_t)2 * nbtp_max * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 512);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
-    p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
+    p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
     const size_t lds = (size_t)(BT * (a.H + 8) + 4 * 3 * RED_BLK + 2 * 768 + 2 * 1280 + 64) * sizeof(float);
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
-        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
         if (a.split) hipLaunchKernelGGL((gru_fwd_cluster16<4, true>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
         else hipLaunchKernelGGL((gru_fwd_cluster16<4, false>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
         DEP_CHECK_LAUNCH();
@@ -530,7 +530,7 @@ int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbu
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
     const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 512);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
     const size_t lds = (size_t)(BT * (48 + LPAD) + 64) * sizeof(float);
@@ -538,7 +538,7 @@ int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbu
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
-        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
         hipLaunchKernelGGL(gru_bwd_cluster16<4>, dim3(NC * p.nbtp), dim3(CT), lds, a.stream, p);
         DEP_CHECK_LAUNCH();
     }

@@ -711,10 +711,10 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
     p.sv0 = a.training ? a.sv0 : nullptr; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
     const size_t pay = (size_t)2 * nbtp_max * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 256);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + HELLO_OFF);
     p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
-    p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
+    p.trace = trace_env() ? (long long*)(hdr_base(xbuf, a.hdr_slot) + TRACE_OFF) : nullptr;
     p.only_if = a.only_if;
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream, a.only_if == nullptr);      // a conditional fallback launch is not a sweep of the step
     // Ask for more than half of the CU's 160 KiB LDS: the dispatcher can then never co-locate two members on one
@@ -732,7 +732,7 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
-        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         dim3 grid(NC * p.nbtp);
 #define DEP_FWD_LAUNCH(K)                                                                                                 \
         do { if (a.split) hipLaunchKernelGGL((gru_fwd_cluster_r1<K, true>), grid, dim3(CT), lds, a.stream, p);            \
@@ -765,10 +765,10 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
     const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 256);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + HELLO_OFF);
     p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
-    p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
+    p.trace = trace_env() ? (long long*)(hdr_base(xbuf, a.hdr_slot) + TRACE_OFF) : nullptr;
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
     static int kb_env = -1;                           // DEP_BWD_BURST=0: the round-1 kernel (every wave streams for itself, every step); 4 (default) or 6: burst length
     if (kb_env < 0) { const char* v = getenv("DEP_BWD_BURST"); kb_env = v ? atoi(v) : 4; if (kb_env != 0 && kb_env != 4 && kb_env != 6) kb_env = 4; }
@@ -796,7 +796,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
-        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         dim3 grid(NC * p.nbtp * (p.xhalf ? 2 : 1));
         const dim3 block(kb ? CT + SVC_THREADS : CT);
 #define DEP_BWD_LAUNCH(N, S)                                                                                              \

@@ -15,7 +15,21 @@ constexpr unsigned HELLO_LIMIT_SOFT = 1u << 13;    // hello of a kernel that has
 //   soft flag: a forward kernel that needs every CU to itself (rnn_fused2.hip) could not assemble its clusters -- a foreign
 //   workgroup sat in the dispatcher.  It leaves WITHOUT raising the status; the co-schedule-tolerant per-layer kernels
 //   enqueued behind it run only when this word is set (dep_rnn_forward, api.hip) and redo the forward.
-constexpr size_t FLAG_OFF = 256, HELLO_OFF = 4352, TRACE_OFF = 6400, PAYLOAD_OFF = 8192;     // flags: 1024 words (per-wave flags of the GRU backward), hello: 512 words
+constexpr size_t FLAG_OFF = 256, HELLO_OFF = 4352, TRACE_OFF = 6400;     // inside a header slot; flags: 1024 words (per-wave flags of the GRU backward), hello: 512 words
+// The buffer starts with HDR_SLOTS such headers of HDR_SLOT bytes; the payload follows.  A launch uses slot `hdr_slot` (status
+// and soft flag are always slot 0's words [0], [1]).  Round 3: every sweep of a forward (or backward) call takes its own slot, so
+// that ONE memset per call clears them all -- six 4.5 us fill launches per training step were four too many.
+constexpr size_t HDR_SLOT = 8192;
+constexpr int HDR_SLOTS = DEP_HDR_SLOTS;
+constexpr size_t PAYLOAD_OFF = HDR_SLOT * HDR_SLOTS;
+inline char* hdr_base(void* xbuf, int slot) { return (char*)xbuf + (size_t)(slot > 0 && slot < HDR_SLOTS ? slot : 0) * HDR_SLOT; }
+// flags / hello / trace words of a slot are zero at launch: either the call's single memset did it (`clean`, first chunk only)
+// or the launcher does it here
+inline int hdr_prepare(void* xbuf, int slot, bool clean, hipStream_t s) {
+    if (clean) return DEP_OK;
+    if (hipMemsetAsync(hdr_base(xbuf, slot) + FLAG_OFF, 0, HDR_SLOT - FLAG_OFF, s) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+    return DEP_OK;
+}
 
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

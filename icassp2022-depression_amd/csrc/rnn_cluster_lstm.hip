@@ -649,7 +649,7 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
     p.svg = a.training ? a.sv0 : nullptr; p.svc = a.sv1;
     const size_t pay = (size_t)2 * a.dirs * nbtp_max * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp_max * NC <= 256);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     DepProfScope prof(DEP_PROF_LSTM_FWD, a.stream);
     static int kb_env = -1;                           // DEP_LSTM_BURST=0: every wave streams for itself, every step (round-1 schedule)
@@ -666,7 +666,7 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
-        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
         if (kb) { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4>), grid, block, lds, a.stream, p);
                   else hipLaunchKernelGGL((lstm_fwd_cluster<4, false, 4>), grid, block, lds, a.stream, p); }
@@ -691,7 +691,7 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
     DEP_CHECK_ARG(a.dbpart_rows >= nbt * a.dirs);
     const size_t pay = (size_t)2 * a.dirs * nbtp_max * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp_max * NC <= 256);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     DepProfScope prof(DEP_PROF_LSTM_BWD, a.stream);
     static int kb_env = -1;                           // DEP_LSTM_BURST=0: round-1 schedule
@@ -708,7 +708,7 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
-        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
         if (kb) { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4>), grid, block, lds, a.stream, p);
                   else hipLaunchKernelGGL((lstm_bwd_cluster<2, false, 4>), grid, block, lds, a.stream, p); }

@@ -388,9 +388,9 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     const size_t pay = (size_t)2 * nbtp_max * 3 * F_REGION * sizeof(float);
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * FNC <= 256);
     DEP_CHECK_ARG(!drop || a.y0d);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
-    p.trace = trace_env() ? (long long*)((char*)xbuf + TRACE_OFF) : nullptr;
+    p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
     p.soft = a.soft_fallback ? (unsigned*)xbuf + 1 : nullptr;
     { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] == '1') ? 1 : 0; } p.force_soft = fs; }
     static bool attr = false;
@@ -406,7 +406,7 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
-        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        { const int rc_h = hdr_prepare(xbuf, 0, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(FNC * p.nbtp), blk(FTHREADS);
         if (p.trace) {                                    // DEP_TRACE=1: the stamped variant (tools/trace_fused.py)
             if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, true>), grid, blk, F_LDS_BYTES, a.stream, p);

@@ -333,7 +333,7 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
     DEP_CHECK_ARG(a.dbpart_rows >= nbt && a.wh1 && a.wi1 && a.wh0 && a.dgi1 && a.dgi0 && a.dghn1 && a.dghn0);
     const size_t pay = (size_t)2 * nbtp_max * 3 * B_BLOCK * sizeof(float);
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * BNC <= 256 && pay < (1ull << 32));
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)((char*)xbuf + FLAG_OFF); p.hello = (unsigned*)((char*)xbuf + HELLO_OFF);
+    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     static bool attr = false;
     if (!attr) {
@@ -348,7 +348,7 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
-        if (hipMemsetAsync((char*)xbuf + FLAG_OFF, 0, PAYLOAD_OFF - FLAG_OFF, a.stream) != hipSuccess) { dep_set_error("hipMemsetAsync failed"); return DEP_ERR_HIP; }
+        { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(BNC * p.nbtp), blk(BTHREADS);
         if (drop) { if (a.dy) hipLaunchKernelGGL((gru2_bwd_fused<true, true>), grid, blk, B_LDS_BYTES, a.stream, p);
                     else hipLaunchKernelGGL((gru2_bwd_fused<true, false>), grid, blk, B_LDS_BYTES, a.stream, p); }
