@@ -291,8 +291,8 @@ int dep_reduce_loss(const float* loss_rows, int B, float norm, float* loss_out, 
  * (fc_audio: Classification/audio_gru_whole.py:66-73, Regression/audio_bilstm_perm.py:60-67 -- first_dropout = 1;
  *  fc_out: Classification/text_bilstm_whole.py:60-66 -- first_dropout = 0).  Exact fp32, fixed summation order; the masks are the
  * draws dep_dropout / dep_relu_dropout_* make at (seed, site0) / (seed, site1).  W1 (H1,Hin), W2 (C,H1) row-major as
- * torch.nn.Linear holds them; W1 16-byte aligned.  dep_head_mlp_supported says which widths are covered (Hin, H1 <= 256,
- * Hin % 32 == 0, H1 % 4 == 0, C <= 16); other shapes are composed from dep_gemm_f32 / dep_relu_dropout_* / dep_colsum.
+ * torch.nn.Linear holds them; W1 16-byte aligned.  dep_head_mlp_supported says which widths are covered (Hin and H1 powers of
+ * two in [8, 256], C <= 16); other shapes are composed from dep_gemm_f32 / dep_relu_dropout_* / dep_colsum.
  *   fwd : a0 (B,Hin) = dropout(x) (written only if first_dropout && p > 0; otherwise x itself is the saved input),
  *         z1, a1 (B,H1) saved for the backward, z2 (B,C) the pre-activation dep_head_loss takes (C = 0: stop at a1).
  *   bwd : dz2 (B,C) from dep_head_loss; a0 = what the forward saved (x when no first dropout ran); dW1, db1, dW2, db2
