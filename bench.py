@@ -88,6 +88,111 @@ def launch_check(args):
         print(json.dumps({'launch_check': True, 'world': world, 'sum': float(t.item()), 'backend': args.backend}))
 
 
+def build_workload(name, dev, rank, world):
+    """Model, optimizer, synthetic HBM-resident batch and the train-step closure of one WORKLOADS entry."""
+    import importlib
+    from icassp2022_depression_amd import nn, parallel
+    modname, cls, B, T, F, H = WORKLOADS[name]
+    mod = importlib.import_module('icassp2022_depression_amd.' + modname)
+    torch.manual_seed(0)
+    g = torch.Generator(device='cpu'); g.manual_seed(1234 + rank)
+    y = torch.randint(0, 2, (B,), generator=g).to(dev)
+    out = {'mod': mod, 'B': B, 'T': T, 'F': F, 'H': H}
+    if name == 'fusion':
+        cfg = dict(mod.config); cfg.update(audio_embed_size=F, audio_hidden_dims=H, text_embed_size=1024, text_hidden_dims=128)
+        model = mod.fusion_net(cfg['text_embed_size'], cfg['text_hidden_dims'], cfg['rnn_layers'], cfg['dropout'],
+                               cfg['num_classes'], cfg['audio_hidden_dims'], cfg['audio_embed_size'], seed=0)
+        parallel.broadcast_params(model)
+        optimizer = nn.Adam(model.parameters(), lr=cfg['learning_rate'])
+        criterion = mod.MyLoss()
+        xa = torch.randn(B, T, F, generator=g).to(dev)       # synthetic paired features, resident in HBM
+        xt = torch.randn(B, T, 1024, generator=g).to(dev)
+        model.train()
+
+        def step():
+            parallel.set_global_count(B * world)
+            optimizer.zero_grad()
+            tf, af = model.pretrained_feature((xa, xt))
+            model(torch.cat((tf, af), dim=1))
+            loss = criterion(tf, af, y, model)
+            loss.backward()
+            optimizer.step()
+            return loss
+        out.update(xa=xa, xt=xt, eval_fn=lambda: model.pretrained_feature((xa, xt)))
+    else:
+        cfg = dict(mod.config); cfg.update(embedding_size=F, hidden_dims=H)
+        model = getattr(mod, cls)(cfg, seed=0)
+        parallel.broadcast_params(model)
+        optimizer = nn.AdamW(mod.get_param_group(model), lr=cfg['learning_rate'])
+        criterion = nn.CrossEntropyLoss()
+        x = torch.randn(B, T, F, generator=g).to(dev)        # synthetic features, resident in HBM
+        model.train()
+
+        def step():
+            parallel.set_global_count(B * world)
+            optimizer.zero_grad()
+            o = model(x)
+            loss = criterion(o, y)
+            loss.backward()                                   # includes the RCCL all-reduce of the grad bucket
+            optimizer.step()
+            return loss
+        out.update(x=x, eval_fn=lambda: model(x))
+    out.update(model=model, optimizer=optimizer, criterion=criterion, cfg=cfg, step=step)
+    return out
+
+
+def dominant_sweep(prof, steps, name, B, T, H):
+    """The recurrent sweep category with the largest total time and SURVEY 8(d)'s algorithmic flops of one of its launches."""
+    cats = {k: v for k, v in prof.items() if v[1] > 0}
+    sweeps = {k: v for k, v in cats.items() if 'sweep' in k}
+    dom = max(sweeps, key=lambda k: sweeps[k][0])
+    dom_ms = sweeps[dom][0] / sweeps[dom][1]
+    if dom.startswith('lstm'):
+        G, dirs, Hs = 4, 2, 128                               # the text encoder's hidden size in every workload
+    else:
+        G, dirs, Hs = 3, 1, H
+    launches_per_step = sweeps[dom][1] / steps               # 2 for per-layer sweeps, 1 for a launch that carries both layers
+    layers_per_launch = 2.0 / launches_per_step
+    sweep_flops = 2.0 * B * T * (G * Hs) * Hs * dirs * layers_per_launch
+    return {'cats': cats, 'dom': dom, 'dom_ms': dom_ms, 'G': G, 'dirs': dirs, 'H': Hs, 'launches_per_step': launches_per_step,
+            'layers_per_launch': layers_per_launch, 'sweep_flops': sweep_flops}
+
+
+def time_other_workload(name, dev, L, steps=8, warmup=3):
+    """BASELINE configs[2] / [3] in the same invocation: a few train steps after the headline region, so that
+    the driver's own `bench.py --gpus 1` run times all three per-GPU workloads."""
+    wl = build_workload(name, dev, 0, 1)
+    step, model = wl['step'], wl['model']
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    L.profile_enable(True); L.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = L.profile_read(); L.profile_enable(False)
+    B, T, H = wl['B'], wl['T'], wl['H']
+    d = dominant_sweep(prof, steps, name, B, T, H)
+    split = L.get_gemm_mode() == 1
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+    tfl = d['sweep_flops'] / (d['dom_ms'] * 1e-3) / 1e12
+    fb = [int(w.item()) for w in (model.fallback_words() if hasattr(model, 'fallback_words') else [])]
+    ms = dt / steps * 1e3
+    res = {'ms_per_step': round(ms, 3), 'value': round(B / (ms * 1e-3), 1), 'unit': 'utterances/s', 'steps': steps, 'warmup': warmup,
+           'final_loss': round(loss.item(), 6),
+           'dominant_kernel': {'kernel': d['dom'], 'avg_launch_ms': round(d['dom_ms'], 4), 'tflops': round(tfl, 2),
+                               'frac_of_mfma_peak': round(tfl / peak, 4), 'peak_tflops': round(peak, 1)},
+           'gru_forward_path': (None if not fb else ('fallback (co-schedule-tolerant sweeps redid the forward)' if any(fb) else
+                                                     'exclusive fused two-layer launch' if L.load().dep_rnn_get_exclusive() else 'tolerant sweeps (dep_rnn_set_exclusive(0))')),
+           'kernels_ms_per_step': {k: round(v[0] / steps, 4) for k, v in d['cats'].items()},
+           'workload': '%s.%s train step, B=%d T=%d F=%d H=%d' % (WORKLOADS[name][0], WORKLOADS[name][1], B, T, wl['F'], H)}
+    del wl, step, model
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -95,6 +200,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='audio_gru', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-workloads', action='store_true', help='skip extra.other_workloads (the other two BASELINE per-GPU workloads, a few steps each)')
     ap.add_argument('--profile-run', action='store_true', help='warm-up + timed steps only (rocprofv3 passes: every launch belongs to a train step)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='process-group backend (gloo: launch check on CPU, or a dry run of the N-rank bench with the ranks sharing one GPU)')
@@ -125,47 +231,9 @@ def main():
     torch.cuda.set_device(dev)
 
     modname, cls, B, T, F, H = WORKLOADS[args.workload]
-    mod = importlib.import_module('icassp2022_depression_amd.' + modname)
-    torch.manual_seed(0)
-    g = torch.Generator(device='cpu'); g.manual_seed(1234 + rank)
-    y = torch.randint(0, 2, (B,), generator=g).to(dev)
-    if args.workload == 'fusion':
-        cfg = dict(mod.config); cfg.update(audio_embed_size=F, audio_hidden_dims=H, text_embed_size=1024, text_hidden_dims=128)
-        model = mod.fusion_net(cfg['text_embed_size'], cfg['text_hidden_dims'], cfg['rnn_layers'], cfg['dropout'],
-                               cfg['num_classes'], cfg['audio_hidden_dims'], cfg['audio_embed_size'], seed=0)
-        parallel.broadcast_params(model)
-        optimizer = nn.Adam(model.parameters(), lr=cfg['learning_rate'])
-        criterion = mod.MyLoss()
-        xa = torch.randn(B, T, F, generator=g).to(dev)       # synthetic paired features, resident in HBM
-        xt = torch.randn(B, T, 1024, generator=g).to(dev)
-        model.train()
-
-        def step():
-            parallel.set_global_count(B * world)
-            optimizer.zero_grad()
-            tf, af = model.pretrained_feature((xa, xt))
-            model(torch.cat((tf, af), dim=1))
-            loss = criterion(tf, af, y, model)
-            loss.backward()
-            optimizer.step()
-            return loss
-    else:
-        cfg = dict(mod.config); cfg.update(embedding_size=F, hidden_dims=H)
-        model = getattr(mod, cls)(cfg, seed=0)
-        parallel.broadcast_params(model)
-        optimizer = nn.AdamW(mod.get_param_group(model), lr=cfg['learning_rate'])
-        criterion = nn.CrossEntropyLoss()
-        x = torch.randn(B, T, F, generator=g).to(dev)        # synthetic features, resident in HBM
-        model.train()
-
-        def step():
-            parallel.set_global_count(B * world)
-            optimizer.zero_grad()
-            out = model(x)
-            loss = criterion(out, y)
-            loss.backward()                                   # includes the RCCL all-reduce of the grad bucket
-            optimizer.step()
-            return loss
+    wl = build_workload(args.workload, dev, rank, world)
+    mod, model, optimizer, criterion, cfg, step = wl['mod'], wl['model'], wl['optimizer'], wl['criterion'], wl['cfg'], wl['step']
+    x, xa, xt = wl.get('x'), wl.get('xa'), wl.get('xt')
 
     for _ in range(args.warmup):
         step()
@@ -183,6 +251,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     final_loss = loss.item()
+    # which GRU forward produced the headline: the exclusive fused launch, or -- on a shared GPU -- its on-device fallback
+    fbw = [int(w.item()) for w in (model.fallback_words() if hasattr(model, 'fallback_words') else [])]
+    fwd_path = None if not fbw else ('fallback (co-schedule-tolerant sweeps redid the forward)' if any(fbw) else
+                                     'exclusive fused two-layer launch' if L.load().dep_rnn_get_exclusive() else 'tolerant sweeps (dep_rnn_set_exclusive(0))')
 
     extras = not args.profile_run
     # gradient exchange alone (every rank; gathered on rank 0): the same ranges the step reduces, nothing beside them
@@ -290,6 +362,14 @@ def main():
         from icassp2022_depression_amd import _common
         _common.invalidate_device_features()
 
+    # BASELINE configs[2] (text BiLSTM) and [3] (late fusion) at their per-GPU shapes, driver-timed in this same invocation
+    other = None
+    if extras and rank == 0 and world == 1 and not args.no_other_workloads:
+        other = {}
+        for name in sorted(WORKLOADS):
+            if name != args.workload:
+                other[name] = time_other_workload(name, dev, L)
+
     if world > 1:
         parallel.barrier()
         parallel.destroy_native_comm()                          # every rank tears its communicator down
@@ -393,11 +473,13 @@ def main():
                       'global_batch': B * world, 'parallelism': f'dp{world}', 'ranks': world,
                       'backend': comm_kind},
            'final_loss': round(final_loss, 6),
+           'gru_forward_path': fwd_path,
            'roofline': roofline}
     if eval_ms is not None:
         out['eval_forward'] = {'value': round(B / (eval_ms * 1e-3), 1), 'unit': 'utterances/s', 'ms_per_batch': round(eval_ms, 3),
                                'note': 'forward only (evaluate), rank 0, outside the headline region'}
     out['extra'] = {'f32_exact': f32_exact, 'bf16_products': bf16_products, 'train_e2e': train_e2e, 'comm_alone_ms_per_step_by_rank': comm_alone,
+                    'other_workloads': other,
                     'precision_note': 'storage, state, accumulation and elementwise math fp32; products of the large contractions '
                                       'and of the recurrent sweeps: 3-term bf16 split on the bf16 matrix cores (DEP_GEMM_MODE=f32 = exact)'}
 

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from . import parallel
+from . import _lib as L
 
 
 def save(model, filename):
@@ -107,6 +108,67 @@ def prf(conf_matrix):
         recall = np.float64(tp) / np.float64(tp + fn)
         f1 = 2 * (precision * recall) / (precision + recall)
     return accuracy, float(precision), float(recall), float(f1)
+
+
+# The helpers below are HIP launches on device tensors.  Host tensors only ever reach them from the CPU stand-in model of
+# tests/test_host_cpu.py (the real models cannot be built without a GPU: nn._device raises); those take plain host indexing.
+def _gather(X, sel):
+    return L.gather_rows(X, sel) if X.is_cuda else X[sel]
+
+
+def predict(output, out=None):
+    """`output.data.max(1, keepdim=True)[1]` of the reference loops (audio_gru_whole.py:185) as one HIP launch: (B, 1) int64 first
+    arg-max per row, on the device.  `out`: a (B, 1) int64 device view to write into (epoch-level prediction buffers)."""
+    probs = output.data if hasattr(output, 'data') else output
+    if not probs.is_cuda:
+        p = probs.max(1, keepdim=True)[1]
+        if out is not None:
+            out.copy_(p); return out
+        return p
+    if out is not None:
+        assert out.is_contiguous() and out.dtype == torch.int64 and out.numel() == probs.shape[0]
+        if probs.shape[0]:
+            L.check(L.load().dep_argmax_count(probs.data_ptr(), None, 0, probs.shape[0], probs.shape[1], None, out.data_ptr(),
+                                              L.stream()), 'dep_argmax_count')
+        return out
+    return L.argmax_count(probs, want_pred=True)
+
+
+def count_correct(output, y_dev, counter):
+    """`correct += pred.eq(y.view_as(pred)).sum()` (audio_gru_whole.py:186-187): arg-max, comparison with the device labels and
+    the running count in ONE launch (dep_argmax_count); `counter` is a 0-dim int64 device tensor read once per epoch."""
+    probs = output.data if hasattr(output, 'data') else output
+    if not probs.is_cuda:
+        pred = probs.max(1, keepdim=True)[1]
+        counter += pred.eq(y_dev.view_as(pred)).sum()
+        return
+    L.argmax_count(probs, labels=y_dev, count=counter)
+
+
+def concat_features(text_feature, audio_feature):
+    """torch.cat((text_feature, audio_feature), dim=1) (fuse_net_whole.py:434) as two strided copies (dep_copy2d)."""
+    if not text_feature.is_cuda:
+        return torch.cat((text_feature, audio_feature), dim=1)
+    return L.concat2(text_feature, audio_feature)
+
+
+def prediction_buffer(n, device):
+    """(n,) fp32 zeros on the device: the regression loops' predictions of one epoch (audio_bilstm_perm.py:150-160)."""
+    if torch.device(device).type != 'cuda':
+        return torch.zeros(n, dtype=torch.float32)
+    buf = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+    L.fill(buf, 0.0)
+    return buf[:n]
+
+
+def store_predictions(buf, at, output):
+    """buf[at : at + B] = output.flatten() for a (B, 1) head output (dep_copy2d)."""
+    o = output.data if hasattr(output, 'data') else output
+    n = o.numel()
+    if n and not o.is_cuda:
+        buf[at:at + n] = o.reshape(-1)
+    elif n:
+        L.check(L.load().dep_copy2d(o.data_ptr(), 1, buf.data_ptr() + 4 * at, 1, n, 1, L.stream()), 'dep_copy2d')
 
 
 def minibatches(n, batch_size):
@@ -213,7 +275,7 @@ class FeatureFeeder:
         if self.Xd is not None:
             if self.contiguous:                    # idxs is a run i, i+1, ...: a view, no gather
                 return self.Xd[int(self.idxs[0]) + a:int(self.idxs[0]) + b]
-            return self.Xd.index_select(0, self.idx_dev[a:b])
+            return _gather(self.Xd, self.idx_dev[a:b])                       # dep_gather_rows: the mini-batch out of the HBM-resident corpus
         self._start(a, b)
         t, ev = self.inflight.pop((a, b))
         torch.cuda.current_stream().wait_event(ev)
@@ -273,4 +335,4 @@ class PairFeeder:
         if not self.ok:
             return [self.pairs[i] for i in self.idxs[a:b]]
         sel = self.idx_dev[a:b]
-        return (self.Xa.index_select(0, sel), self.Xt.index_select(0, sel))
+        return (_gather(self.Xa, sel), _gather(self.Xt, sel))

@@ -99,6 +99,9 @@ _SIGS = {
     'dep_fill': (C.c_int, [_P, C.c_long, C.c_float, _P]),
     'dep_axpby': (C.c_int, [_P, _P, C.c_long, C.c_float, C.c_float, _P]),
     'dep_sigmoid_gate': (C.c_int, [_P, _P, _P, C.c_long, _P]),
+    'dep_gather_rows': (C.c_int, [_P, _P, _P, C.c_long, C.c_long, _P]),
+    'dep_copy2d': (C.c_int, [_P, C.c_long, _P, C.c_long, C.c_long, C.c_long, _P]),
+    'dep_argmax_count': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -289,6 +292,49 @@ def axpby(x, y, a, b):
 
 def sigmoid_gate(g, x, y):
     check(load().dep_sigmoid_gate(_ptr(g), _ptr(x), _ptr(y), x.numel(), stream()), 'dep_sigmoid_gate')
+
+
+def gather_rows(src, idx, out=None):
+    """src (N, ...) fp32 contiguous, idx (n,) int64 on the device -> (n, ...) rows (dep_gather_rows)."""
+    n = idx.numel()
+    row = src[0].numel()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    if n:
+        assert src.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+        for r0 in range(0, n, 65535):
+            r1 = min(n, r0 + 65535)
+            check(load().dep_gather_rows(_ptr(src), idx.data_ptr() + 8 * r0, out.data_ptr() + 4 * row * r0, r1 - r0, row, stream()),
+                  'dep_gather_rows')
+    return out
+
+
+def concat2(a, b):
+    """torch.cat((a, b), dim=1) of two (B, .) fp32 matrices as two strided copies (dep_copy2d)."""
+    B, na = a.shape
+    nb = b.shape[1]
+    out = torch.empty(B, na + nb, dtype=torch.float32, device=a.device)
+    if B:
+        lib = load()
+        check(lib.dep_copy2d(_ptr(a), a.stride(0), _ptr(out), na + nb, B, na, stream()), 'dep_copy2d')
+        check(lib.dep_copy2d(_ptr(b), b.stride(0), out.data_ptr() + 4 * na, na + nb, B, nb, stream()), 'dep_copy2d')
+    return out
+
+
+def argmax_count(probs, labels=None, count=None, want_pred=False):
+    """First arg-max per row of `probs` (B, C) -> int64 (B, 1) when want_pred; `count` (0-dim int64 device tensor) += the
+    number of rows whose arg-max equals `labels` (int32 / int64 device tensor).  One launch (dep_argmax_count)."""
+    B, Cc = probs.shape
+    pred = torch.empty(B, 1, dtype=torch.int64, device=probs.device) if want_pred else None
+    if B:
+        assert probs.is_contiguous()
+        i64 = 0
+        if labels is not None:
+            assert labels.is_cuda and labels.is_contiguous() and labels.dtype in (torch.int64, torch.int32)
+            i64 = int(labels.dtype == torch.int64)
+        check(load().dep_argmax_count(_ptr(probs), _ptr(labels), i64, B, Cc, _ptr(count) if labels is not None else None,
+                                      _ptr(pred), stream()), 'dep_argmax_count')
+    return pred
 
 
 def attn_fwd(out, h_n, Wa, ba):

@@ -65,8 +65,8 @@ def train(epoch):
     """Reference lines 134-172."""
     model.train()
     total = nn.LossSum(model.device)                 # device-side sum of the step losses, read once per epoch
-    preds = []
     idx = list(train_dep_idxs) + list(train_non_idxs)
+    pred_dev = _common.prediction_buffer(len(idx), model.device)       # zero-filled; every rank writes its own rows
     Y_train = audio_targets[idx]
     Y_dev = _common.device_labels(Y_train, model.device)
     feed = _common.FeatureFeeder(audio_features, idx, model.device, role='audio_features')       # rows of X_train = audio_features[idx], in HBM
@@ -75,7 +75,6 @@ def train(epoch):
         parallel.set_global_count(hi - lo)
         if b <= a:                                  # empty shard of a small (ragged) mini-batch: zero-contribution step
             total.add(nn.empty_shard_step(model, optimizer))
-            preds.append(torch.zeros(hi - lo, device=model.device))
             continue
         x = feed.rows(a, b, then=batches[bi + 1][1] if bi + 1 < len(batches) else None)
         y = Y_dev[a:b]
@@ -84,17 +83,13 @@ def train(epoch):
         loss = criterion(output, y.view(-1, 1))
         loss.backward()
         optimizer.step()
-        out_all = output.data.flatten()
-        if parallel.world_size() > 1:               # this rank's rows of the global mini-batch; the others' stay zero until the epoch-end SUM
-            full = torch.zeros(hi - lo, device=out_all.device); full[a - lo:b - lo] = out_all
-            out_all = full
-        preds.append(out_all)
+        _common.store_predictions(pred_dev, a, output)     # this rank's rows; the others' stay zero until the epoch-end SUM
         total.add(loss, model)
     parallel.set_global_count(None)
     total_loss = total.item()                        # the epoch's only host synchronisation on the loss (raises if a sweep gave up)
     # per step every rank issues: the gradient exchange, then the loss scalar (nn.Loss.item); the predictions of the whole epoch
     # are assembled by ONE all-reduce here -- same sequence on working and empty-shard ranks, no per-step host copy
-    pred = parallel.all_reduce_sum(torch.cat(preds)).cpu().numpy().astype(np.float64) if preds else np.array([])
+    pred = parallel.all_reduce_sum(pred_dev).cpu().numpy().astype(np.float64) if len(idx) else np.array([])
     train_mae, train_rmse = _mae_rmse(Y_train, pred)
     if parallel.rank() == 0:
         print('Train Epoch: {:2d}\t Learning rate: {:.4f}\t Loss: {:.4f}\t MAE: {:.4f}\t RMSE: {:.4f}\n '

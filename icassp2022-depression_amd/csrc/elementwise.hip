@@ -335,6 +335,51 @@ __global__ void sigmoid_gate_kernel(const float* g, const float* x, float* y, lo
     if (i < n) y[i] = dep_sigmoid(g[i]) * x[i];
 }
 
+// ------------------------------------------------------------------------------ host-loop helpers (round 4)
+// The training loops' bookkeeping that used to run as ATen kernels (index_select, cat, max / eq / sum): row gather of a
+// mini-batch out of the HBM-resident corpus, a strided 2-D copy (feature concat), and arg-max + correct count of the head output.
+__global__ void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx, float* __restrict__ dst,
+                                   long row_floats, int vec) {
+    const long r = blockIdx.y;
+    const float* sr = src + (size_t)idx[r] * row_floats;
+    float* dr = dst + (size_t)r * row_floats;
+    const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {                                       // rows are 16-byte aligned multiples of four floats
+        const f32x4* s = reinterpret_cast<const f32x4*>(sr); f32x4* d = reinterpret_cast<f32x4*>(dr);
+        for (long i = i0; i < (row_floats >> 2); i += stride) d[i] = s[i];
+    } else {
+        for (long i = i0; i < row_floats; i += stride) dr[i] = sr[i];
+    }
+}
+__global__ void copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, long rows, long cols) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols, c = i - r * cols;
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+// first maximum per row (torch.max(1) on the reference's CPU path returns the first index among equals)
+__global__ void argmax_count_kernel(const float* __restrict__ p, const void* __restrict__ labels, int i64, int B, int C,
+                                    long long* __restrict__ count, long long* __restrict__ pred) {
+    __shared__ int wsum[4];
+    int ok = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* row = p + (size_t)b * C;
+        int best = 0; float bv = row[0];
+        for (int c = 1; c < C; ++c) { const float v = row[c]; if (v > bv) { bv = v; best = c; } }
+        if (pred) pred[b] = best;
+        if (labels) {
+            const long long y = i64 ? reinterpret_cast<const long long*>(labels)[b] : (long long)reinterpret_cast<const int*>(labels)[b];
+            ok += (y == best) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ok += __shfl_xor(ok, m, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ok;
+    __syncthreads();
+    if (threadIdx.x == 0 && count) *count += (long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
 // ------------------------------------------------------------------------------ attention
 __global__ void attn_hsum_kernel(const float* __restrict__ hn, int K, long BH, float* __restrict__ hsum) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -585,6 +630,29 @@ extern "C" int dep_axpby(const float* x, float* y, long n, float a, float b, voi
 extern "C" int dep_sigmoid_gate(const float* g, const float* x, float* y, long n, void* stream) {
     DEP_CHECK_ARG(g && x && y && n > 0);
     hipLaunchKernelGGL(sigmoid_gate_kernel, dim3(nblk(n)), dim3(256), 0, S_, g, x, y, n);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
+
+extern "C" int dep_gather_rows(const float* src, const long long* idx, float* dst, long nrows, long row_floats, void* stream) {
+    DEP_CHECK_ARG(src && idx && dst && nrows > 0 && row_floats > 0 && nrows <= 65535);
+    const int vec = (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (row_floats & 3) == 0) ? 1 : 0;
+    int gx = dep_cdiv(vec ? row_floats >> 2 : row_floats, 256); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, (unsigned)nrows), dim3(256), 0, S_, src, idx, dst, row_floats, vec);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
+extern "C" int dep_copy2d(const float* src, long lds, float* dst, long ldd, long rows, long cols, void* stream) {
+    DEP_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols);
+    int gx = nblk(rows * cols); if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(gx), dim3(256), 0, S_, src, lds, dst, ldd, rows, cols);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
+extern "C" int dep_argmax_count(const float* p, const void* labels, int labels_i64, int B, int C, long long* count,
+                                long long* pred, void* stream) {
+    DEP_CHECK_ARG(p && B > 0 && C > 0 && (count || pred) && (!count || labels));
+    hipLaunchKernelGGL(argmax_count_kernel, dim3(1), dim3(256), 0, S_, p, labels, labels_i64, B, C, count, pred);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

@@ -775,11 +775,14 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     { static int wf_env = -1; if (wf_env < 0) { const char* v = getenv("DEP_BWD_WFLAGS"); wf_env = (v && v[0] == '0') ? 0 : 1; } p.wflags = wf_env; }     // default on; DEP_BWD_WFLAGS=0: one flag per member behind a workgroup barrier
     { static int nt_env = -1; if (nt_env < 0) { const char* v = getenv("DEP_BWD_NT"); nt_env = (v && v[0] == '1') ? 1 : 0; } p.ntstream = nt_env; }
     static int xhalf_env = -1;
-    if (xhalf_env < 0) { const char* v = getenv("DEP_BWD_XHALF"); xhalf_env = (v && v[0] == '1') ? 1 : 0; }
-    p.xhalf = (xhalf_env && a.H == 256 && a.B <= CH) ? 1 : 0;
-    const int kb = (a.H >= 512 || p.xhalf) ? 0 : kb_env;           // H = 512: 192 weight registers per compute wave leave no room for a second wave per SIMD
-    const size_t lds = p.xhalf ? (size_t)49152 + 2048
-                               : (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
+    if (xhalf_env < 0) { const char* v = getenv("DEP_BWD_XHALF"); xhalf_env = (v && v[0] == '1') ? 1 : (v && v[0] == '2') ? 2 : 0; }
+    // 1: the whole batch's workgroups on XCDs 0-3, two per CU (round-1 schedule, 48 KB of LDS each); 2 (round 4, tools/exp_corun.py):
+    // placement only -- a batch of at most half a chunk on XCDs 0-3 with ONE burst-stream workgroup per CU, XCDs 4-7 left to another stream
+    const bool xpack = xhalf_env == 1 && a.H == 256 && a.B <= CH;
+    p.xhalf = (xpack || (xhalf_env == 2 && a.H == 256 && a.B <= CH / 2)) ? 1 : 0;
+    const int kb = (a.H >= 512 || xpack) ? 0 : kb_env;             // H = 512: 192 weight registers per compute wave leave no room for a second wave per SIMD
+    const size_t lds = xpack ? (size_t)49152 + 2048
+                             : (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
     p.trall_off = (int)((lds - 2048) / 4);
     static bool attr_b = false;
     if (!attr_b) {

@@ -92,8 +92,8 @@ def train(model, epoch):
     """Reference lines 373-412."""
     model.train()
     total = nn.LossSum(model.device)                 # device-side sum of the step losses, read once per epoch
-    preds = []
     idx = list(train_dep_idxs) + list(train_non_idxs)
+    pred_dev = _common.prediction_buffer(len(idx), model.device)       # zero-filled; every rank writes its own rows
     Y_train = [fuse_targets[i] for i in idx]
     feed = _common.PairFeeder(fuse_features, idx, model.device)
     for lo, hi in _common.minibatches(len(idx), config['batch_size']):
@@ -102,25 +102,20 @@ def train(model, epoch):
         y = Y_train[a:b]
         if b <= a:                                  # empty shard of a small mini-batch: zero-contribution step
             total.add(nn.empty_shard_step(model, optimizer))
-            preds.append(torch.zeros(hi - lo, device=model.device))
             continue
         optimizer.zero_grad()
         text_feature, audio_feature = model.pretrained_feature(feed.rows(a, b))
-        output = model(torch.cat((text_feature, audio_feature), dim=1))
+        output = model(_common.concat_features(text_feature, audio_feature))
         loss = criterion(text_feature, audio_feature, y, model)
         loss.backward()
         optimizer.step()
-        out_all = output.data.flatten()
-        if parallel.world_size() > 1:               # this rank's rows of the global mini-batch; the others' stay zero until the epoch-end SUM
-            full = torch.zeros(hi - lo, device=out_all.device); full[a - lo:b - lo] = out_all
-            out_all = full
-        preds.append(out_all)
+        _common.store_predictions(pred_dev, a, output)     # this rank's rows; the others' stay zero until the epoch-end SUM
         total.add(loss, model)
     parallel.set_global_count(None)
     total_loss = total.item()                        # the epoch's only host synchronisation on the loss (raises if a sweep gave up)
     # per step every rank issues: the gradient exchange, then the loss scalar (nn.Loss.item); the predictions of the whole epoch
     # are assembled by ONE all-reduce here -- same sequence on working and empty-shard ranks, no per-step host copy
-    pred = parallel.all_reduce_sum(torch.cat(preds)).cpu().numpy().astype(np.float64) if preds else np.array([])
+    pred = parallel.all_reduce_sum(pred_dev).cpu().numpy().astype(np.float64) if len(idx) else np.array([])
     train_mae, train_rmse = _mae_rmse(Y_train, pred)
     if parallel.rank() == 0:
         print('Train Epoch: {:2d}\t Learning rate: {:.4f}\t Loss: {:.4f}\t MAE: {:.4f}\t RMSE: {:.4f}\n '
@@ -140,7 +135,7 @@ def evaluate(model, fold, train_mae):
     for lo, hi in _common.minibatches(len(idx), config['batch_size']):
         y = Y_test[lo:hi]
         text_feature, audio_feature = model.pretrained_feature(feed.rows(lo, hi))
-        output = model(torch.cat((text_feature, audio_feature), dim=1))
+        output = model(_common.concat_features(text_feature, audio_feature))
         loss = criterion(text_feature, audio_feature, y, model)
         pred = np.hstack((pred, output.data.flatten().cpu().numpy()))
         total_loss += loss.item()

@@ -105,6 +105,7 @@ def train(epoch, train_idxs):
     correct_dev = torch.zeros((), dtype=torch.int64, device=model.device)      # counted on the device, read once per epoch
     n_train = len(train_idxs)
     Y_train = [fuse_targets[idx] for idx in train_idxs]
+    Y_dev = _common.device_labels(np.asarray(Y_train), model.device, config['num_classes'])
     feed = _common.PairFeeder(fuse_features, train_idxs, model.device)       # the pairs X_train = [fuse_features[i] ...], in HBM
     for lo, hi in _common.minibatches(n_train, config['batch_size']):
         a, b = _common.rank_slice(lo, hi)
@@ -115,15 +116,13 @@ def train(epoch, train_idxs):
             continue
         optimizer.zero_grad()
         text_feature, audio_feature = model.pretrained_feature(feed.rows(a, b))
-        concat_x = torch.cat((text_feature, audio_feature), dim=1)
+        concat_x = _common.concat_features(text_feature, audio_feature)
         output = model(concat_x)
-        pred = output.data.max(1, keepdim=True)[1]
-        n_ok = pred.eq(torch.as_tensor(np.asarray(y)).to(pred.device).view_as(pred)).sum()
+        _common.count_correct(output, Y_dev[a:b], correct_dev)
         loss = criterion(text_feature, audio_feature, y, model)
         loss.backward()
         optimizer.step()
         total.add(loss, model)
-        correct_dev += n_ok
     parallel.set_global_count(None)
     total_loss = total.item()                        # the epoch's only host synchronisation on the loss (raises if a sweep gave up)
     correct = int(parallel.all_reduce_sum(correct_dev).item())                  # one collective per epoch, on every rank
@@ -140,17 +139,17 @@ def evaluate(model, test_idxs, fold, train_idxs):
     global max_train_acc, max_acc, max_f1
     model.eval()
     total_loss = 0
-    preds = []
     Y_test = [fuse_targets[idx] for idx in test_idxs]
+    pred_dev = torch.empty(len(Y_test), 1, dtype=torch.int64, device=model.device)      # every mini-batch's arg-max lands here
     feed = _common.PairFeeder(fuse_features, test_idxs, model.device)
     for lo, hi in _common.minibatches(len(Y_test), config['batch_size']):
         y = Y_test[lo:hi]
         text_feature, audio_feature = model.pretrained_feature(feed.rows(lo, hi))
-        output = model(torch.cat((text_feature, audio_feature), dim=1))
+        output = model(_common.concat_features(text_feature, audio_feature))
         loss = criterion(text_feature, audio_feature, y, model)
-        preds.append(output.data.max(1, keepdim=True)[1])
+        _common.predict(output, out=pred_dev[lo:hi])
         total_loss += loss.item()
-    pred = torch.cat(preds).cpu()
+    pred = pred_dev.cpu()
     y_test_pred, conf_matrix = model_performance(Y_test, pred)
     print('\nTest set: Average loss: {:.4f}'.format(total_loss / len(Y_test)))
     print('Calculating additional test metrics...')

@@ -44,8 +44,8 @@ def evaluate_classifier(model, features, targets, test_idxs, batch_size):
     preds = []
     for lo, hi in _common.minibatches(X_test.shape[0], batch_size):
         out = model(np.ascontiguousarray(X_test[lo:hi], dtype=np.float32))
-        preds.append(out.data.max(1, keepdim=True)[1].cpu())
-    pred = torch.cat(preds).numpy()
+        preds.append(_common.predict(out).cpu().numpy())
+    pred = np.concatenate(preds) if preds else np.zeros((0, 1), np.int64)
     conf_matrix = _common.standard_confusion_matrix(Y_test, pred)
     print("Confusion Matrix:"); print(conf_matrix)
     return _report(conf_matrix)
@@ -58,8 +58,8 @@ def evaluate_fusion(model, fuse_features, fuse_targets, test_idxs, batch_size):
     preds = []
     for lo, hi in _common.minibatches(len(X), batch_size):
         tf, af = model.pretrained_feature(X[lo:hi])
-        preds.append(model(torch.cat((tf, af), dim=1)).data.max(1, keepdim=True)[1].cpu())
-    conf_matrix = _common.standard_confusion_matrix(np.asarray(Y), torch.cat(preds).numpy())
+        preds.append(_common.predict(model(_common.concat_features(tf, af))).cpu().numpy())
+    conf_matrix = _common.standard_confusion_matrix(np.asarray(Y), np.concatenate(preds) if preds else np.zeros((0, 1), np.int64))
     print("Confusion Matrix:"); print(conf_matrix)
     return _report(conf_matrix)
 

@@ -242,14 +242,15 @@ class AudioGRU(nn.Module):
         return nn.Output(out, self, z)
 
     def sync_plan(self):
-        """Flat layout [l0 | l1 | .. | fc_audio | ln]: the top layer's range ends with the head (final before the stack's
-        backward starts); layer 0 of the classifier is final only after dep_ln_fold_bwd, with the LayerNorm pair."""
+        """Flat layout [ln | l0 | l1 | .. | fc_audio]: the top layer's range ends with the head (final before the stack's
+        backward starts); layer 0 of the classifier is final only after dep_ln_fold_bwd, together with the LayerNorm pair that
+        sits right in front of it -- ONE contiguous range, so a 2-layer step is two all-reduces."""
         Lyr, px = self.rnn_layers, 'lstm_net_audio'
         in_call, post = {}, []
         for l in range(Lyr):
             first, last = f'{px}.weight_ih_l{l}', ('fc_audio.4.bias' if l == Lyr - 1 else f'{px}.bias_hh_l{l}')
             if l == 0 and self.variant == 'clf':
-                post.append(self._span(first, last)); post.append(self._span('ln.weight', 'ln.bias'))
+                post.append(self._span('ln.weight', last))
             else:
                 in_call[l] = self._span(first, last)
         return in_call, post

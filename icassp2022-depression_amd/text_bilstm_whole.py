@@ -55,7 +55,7 @@ class TextBiLSTM(models.TextBiLSTM):
 
 
 def model_performance(y_test, y_test_pred_proba):
-    y_test_pred = y_test_pred_proba.data.max(1, keepdim=True)[1]
+    y_test_pred = _common.predict(y_test_pred_proba)
     conf_matrix = standard_confusion_matrix(y_test, y_test_pred)
     print("Confusion Matrix:")
     print(conf_matrix)
@@ -81,13 +81,11 @@ def train(epoch, train_idxs):
         y = Y_dev[a:b]
         optimizer.zero_grad()
         output = model(x)
-        pred = output.data.max(1, keepdim=True)[1]
-        n_ok = pred.eq(y.view_as(pred)).sum()
+        _common.count_correct(output, y, correct_dev)          # arg-max, comparison and running count: one launch
         loss = criterion(output, y)
         loss.backward()
         optimizer.step()
         total.add(loss, model)
-        correct_dev += n_ok
     parallel.set_global_count(None)
     total_loss = total.item()                        # the epoch's only host synchronisation on the loss (raises if a sweep gave up)
     correct = int(parallel.all_reduce_sum(correct_dev).item())                  # one collective per epoch, on every rank

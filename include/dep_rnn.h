@@ -344,6 +344,16 @@ int dep_fill(float* p, long n, float value, void* stream);
 int dep_axpby(const float* x, float* y, long n, float a, float b, void* stream);
 /* sigmoid gating of the regression fusion head: y = sigmoid(g) * x (Regression/fuse_net.py:345-351) */
 int dep_sigmoid_gate(const float* g, const float* x, float* y, long n, void* stream);
+/* Host-loop bookkeeping of train() / evaluate() as HIP kernels (round 4), so that the tensors really are storage only:
+ *   dep_gather_rows  : dst[r] = src[idx[r]] for nrows <= 65535 rows of row_floats floats -- the mini-batch
+ *                      X_train[lo:hi] of Classification/audio_gru_whole.py:170-172 out of the HBM-resident corpus
+ *   dep_copy2d       : dst[r*ldd + c] = src[r*lds + c] -- torch.cat((text_feature, audio_feature), dim=1), fuse_net_whole.py:434
+ *   dep_argmax_count : pred[b] = first arg-max of row b (output.data.max(1)[1]); *count += #(pred == label)
+ *                      (pred.eq(y).sum(), audio_gru_whole.py:185-187); labels int32 or (labels_i64) int64; pred / count may be NULL */
+int dep_gather_rows(const float* src, const long long* idx, float* dst, long nrows, long row_floats, void* stream);
+int dep_copy2d(const float* src, long lds, float* dst, long ldd, long rows, long cols, void* stream);
+int dep_argmax_count(const float* p, const void* labels, int labels_i64, int B, int C, long long* count, long long* pred,
+                     void* stream);
 
 #ifdef __cplusplus
 }

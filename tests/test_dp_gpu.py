@@ -14,12 +14,18 @@ torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
 
 
-def _run(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+def _run(rank, world, port, q, backend='gloo'):
+    # backend 'nccl': one rank per GPU over the C-ABI's RCCL communicator (dep_comm_*); 'gloo': the ranks share cuda:0
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank) if backend == 'nccl' else '0', HSA_ENABLE_IPC_MODE_LEGACY='0')
     sys.path.insert(0, ROOT)
     from icassp2022_depression_amd import audio_gru_whole as m, nn, parallel
+    if backend == 'nccl':
+        torch.cuda.set_device(rank)
     if world > 1:
-        parallel.init_from_env('gloo')
+        parallel.init_from_env(backend)
+        if backend == 'nccl':
+            assert parallel.transport() == 'rccl-native', parallel._native.get('why')
     g = load_golden('audio_clf_train_eval')
     N, T, F, H = [int(v) for v in g['shape']]
     m.config.update(embedding_size=F, hidden_dims=H, dropout=0.0, batch_size=5, learning_rate=float(g['lr']))
@@ -35,6 +41,7 @@ def _run(rank, world, port, q):
         q.put(({k: v.cpu().numpy() for k, v in m.model.state_dict().items()}, int(m.train_acc)))
     if world > 1:
         parallel.barrier()
+        parallel.destroy_native_comm()
         import torch.distributed as dist
         dist.destroy_process_group()
 
@@ -56,6 +63,33 @@ def test_two_rank_training_equals_single_process():
             assert p.exitcode == 0
     sd1, acc1 = res[1]
     for world in (2, 3):
+        sdw, accw = res[world]
+        assert acc1 == accw
+        for k in sd1:
+            assert np.abs(sd1[k] - sdw[k]).max() < 2e-6, (world, k)
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason='needs two GPUs (a multi-GPU driver box)')
+def test_native_rccl_multi_gpu_training_equals_single_process():
+    """RCCL with N > 1 ranks: one process per GPU, backend nccl, the gradient ranges reduced through the
+    C-ABI's own communicator (dep_comm_* over xGMI, the top layer's range overlapped with layer 0's backward) -- two epochs of
+    audio_gru_whole.train() must leave the parameters of the single-process run.  Runs by itself wherever >= 2 GPUs are visible."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    res = {}
+    worlds = (1, 2) if torch.cuda.device_count() < 4 else (1, 2, 4)
+    for world in worlds:
+        q = ctx.Queue()
+        port = 28300 + os.getpid() % 1000 + world
+        procs = [ctx.Process(target=_run, args=(r, world, port, q, 'nccl' if world > 1 else 'gloo')) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[world] = q.get(timeout=300)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    sd1, acc1 = res[1]
+    for world in worlds[1:]:
         sdw, accw = res[world]
         assert acc1 == accw
         for k in sd1:

@@ -553,3 +553,47 @@ def test_sweep_status_is_sticky_over_a_step():
     rnn.forward(x, Wd)                                          # the next step starts clean
     rnn.backward(x, Wd, Gd, dy=dy)
     rnn.check()
+
+
+# ----------------------------------------------------------------------------- host-loop helpers (round 4): bit-exact integer / copy work
+@pytest.mark.parametrize('N,n,shape', [(40, 17, (5, 8)), (9, 9, (3, 7)), (300, 64, (30, 256)), (6, 1, (1,))])
+def test_gather_rows_is_an_exact_index_select(N, n, shape):
+    rng = np.random.default_rng(N + n)
+    X = rng.standard_normal((N,) + shape).astype(np.float32)
+    idx = rng.integers(0, N, n)
+    got = L.gather_rows(dev(X), torch.as_tensor(idx, dtype=torch.int64, device=DEV))
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), X[idx])
+    # the feeder built on it: rows(a, b) == features[idxs][a:b], runs and scattered index lists
+    from icassp2022_depression_amd import _common
+    for idxs in (list(idx), list(range(2, min(N, 7)))):
+        _common.invalidate_device_features()
+        fd = _common.FeatureFeeder(X, idxs, DEV, role='t')
+        assert np.array_equal(fd.rows(0, len(idxs)).cpu().numpy(), X[idxs])
+    _common.invalidate_device_features()
+
+
+def test_concat_and_argmax_count_equal_torch_bit_for_bit():
+    from icassp2022_depression_amd import _common
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((37, 128)).astype(np.float32); b = rng.standard_normal((37, 256)).astype(np.float32)
+    big = dev(np.concatenate([b, b], 1))
+    cat = _common.concat_features(dev(a), big[:, 256:])              # a strided second operand
+    assert np.array_equal(cat.cpu().numpy(), np.concatenate([a, b], 1))
+    for B, C in ((37, 2), (512, 2), (5, 7), (1, 3)):
+        p = rng.random((B, C)).astype(np.float32)
+        p[B // 2] = p[B // 2, 0]                                       # a tie: the first index wins, like torch.max on the reference's CPU path
+        y = rng.integers(0, C, B)
+        ref_pred = torch.from_numpy(p).max(1, keepdim=True)[1].numpy()
+        pd = dev(p)
+        assert np.array_equal(_common.predict(pd).cpu().numpy(), ref_pred)
+        for dt in (torch.int64, torch.int32):
+            cnt = torch.full((), 5, dtype=torch.int64, device=DEV)
+            _common.count_correct(pd, torch.as_tensor(y, dtype=dt, device=DEV), cnt)
+            assert int(cnt.item()) == 5 + int((ref_pred[:, 0] == y).sum())
+        out = torch.empty(B + 3, 1, dtype=torch.int64, device=DEV)
+        _common.predict(pd, out=out[2:2 + B])
+        assert np.array_equal(out[2:2 + B].cpu().numpy(), ref_pred)
+    buf = _common.prediction_buffer(11, DEV)
+    _common.store_predictions(buf, 4, dev(np.arange(3, dtype=np.float32).reshape(3, 1) + 1))
+    assert np.array_equal(buf.cpu().numpy(), np.array([0, 0, 0, 0, 1, 2, 3, 0, 0, 0, 0], np.float32))
