@@ -223,11 +223,26 @@ def invalidate_device_features():
 
 
 def _fingerprint(arr):
-    """Cheap content check of a cached array: a strided sample (<= 64k elements) -- catches in-place edits of the usual kinds
-    (whole-array scaling, appended / shuffled rows); the scripts never edit their feature arrays in place."""
+    """Content check of a cached array.  Default: a strided sample (<= 64k elements) PLUS one probe element of EVERY row (at a
+    row-dependent column) -- catches whole-array edits and the replacement / edit of any single row at the probed position;
+    an in-place edit that misses every probe is NOT seen: call invalidate_device_features() after editing a feature array in
+    place (the scripts never do: their fold loops build new arrays).  DEP_FEATURES_HASH=1 hashes the whole array instead
+    (xxh3, ~0.15 s per GB on the host)."""
+    if os.environ.get('DEP_FEATURES_HASH', '0') == '1':
+        try:
+            import xxhash
+            return ('xxh3', xxhash.xxh3_64_intdigest(memoryview(np.ascontiguousarray(arr)).cast('B')))
+        except Exception:                                   # noqa: BLE001 -- no xxhash: the sampled check below
+            pass
     flat = arr.reshape(-1)
     step = max(1, flat.size // 65536)
-    return float(np.asarray(flat[::step], dtype=np.float64).sum())
+    s = float(np.asarray(flat[::step], dtype=np.float64).sum())
+    if arr.ndim >= 2 and arr.shape[0] > 0:
+        rows = arr.reshape(arr.shape[0], -1)
+        cols = (np.arange(rows.shape[0], dtype=np.int64) * 2654435761) % rows.shape[1]
+        s2 = float(np.asarray(rows[np.arange(rows.shape[0]), cols], dtype=np.float64).sum())
+        return (s, s2)
+    return (s, 0.0)
 
 
 def device_features(arr, device, role='x'):
@@ -314,8 +329,14 @@ class PairFeeder:
         if n == 0:
             return
         hit = _dev_cache.get('fuse_pairs')
+        # every pair contributes two probe elements per modality (first / middle), the first and last pairs their full sums: replacing
+        # or editing a middle pair in place is seen unless it misses all probes (then: invalidate_device_features())
+        def probe(e):
+            a, t = np.asarray(e[0]).reshape(-1), np.asarray(e[1]).reshape(-1)
+            return float(a[0]) + float(a[a.size // 2]) + float(t[0]) + float(t[t.size // 2])
         key = (n, np.asarray(pairs[0][0]).shape, np.asarray(pairs[0][1]).shape, str(device),
-               float(np.asarray(pairs[0][0], dtype=np.float64).sum() + np.asarray(pairs[-1][1], dtype=np.float64).sum()))
+               float(np.asarray(pairs[0][0], dtype=np.float64).sum() + np.asarray(pairs[-1][1], dtype=np.float64).sum()),
+               float(sum(probe(e) for e in pairs)))
         if hit is not None and hit[0] is pairs and hit[1] == key:
             self.Xa, self.Xt = hit[2]
         else:

@@ -99,6 +99,7 @@ _SIGS = {
     'dep_fill': (C.c_int, [_P, C.c_long, C.c_float, _P]),
     'dep_axpby': (C.c_int, [_P, _P, C.c_long, C.c_float, C.c_float, _P]),
     'dep_sigmoid_gate': (C.c_int, [_P, _P, _P, C.c_long, _P]),
+    'dep_loss_accumulate': (C.c_int, [_P, _P, _P, _P, _P]),
     'dep_gather_rows': (C.c_int, [_P, _P, _P, C.c_long, C.c_long, _P]),
     'dep_copy2d': (C.c_int, [_P, C.c_long, _P, C.c_long, C.c_long, C.c_long, _P]),
     'dep_argmax_count': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
@@ -292,6 +293,11 @@ def axpby(x, y, a, b):
 
 def sigmoid_gate(g, x, y):
     check(load().dep_sigmoid_gate(_ptr(g), _ptr(x), _ptr(y), x.numel(), stream()), 'dep_sigmoid_gate')
+
+
+def loss_accumulate(loss, status, soft, acc):
+    """acc (3,) float64 on the device: [sum of step losses, max status word, max fallback word] (dep_loss_accumulate)."""
+    check(load().dep_loss_accumulate(_ptr(loss), _ptr(status), _ptr(soft), _ptr(acc), stream()), 'dep_loss_accumulate')
 
 
 def gather_rows(src, idx, out=None):

@@ -358,6 +358,14 @@ __global__ void copy2d_kernel(const float* __restrict__ src, long lds, float* __
         dst[r * ldd + c] = src[r * lds + c];
     }
 }
+// acc[0] += *loss (float64 sum of the fp32 step losses, the order Python's `total_loss += loss.item()` adds them in);
+// acc[1] = max(acc[1], *status), acc[2] = max(acc[2], *soft): the sweeps' status / fallback words folded into the epoch's flags
+__global__ void loss_accumulate_kernel(const float* loss, const unsigned* status, const unsigned* soft, double* acc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (loss) acc[0] += (double)loss[0];
+    if (status) { const double v = (double)*status; if (v > acc[1]) acc[1] = v; }
+    if (soft) { const double v = (double)*soft; if (v > acc[2]) acc[2] = v; }
+}
 // first maximum per row (torch.max(1) on the reference's CPU path returns the first index among equals)
 __global__ void argmax_count_kernel(const float* __restrict__ p, const void* __restrict__ labels, int i64, int B, int C,
                                     long long* __restrict__ count, long long* __restrict__ pred) {
@@ -646,6 +654,12 @@ extern "C" int dep_copy2d(const float* src, long lds, float* dst, long ldd, long
     DEP_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols);
     int gx = nblk(rows * cols); if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(copy2d_kernel, dim3(gx), dim3(256), 0, S_, src, lds, dst, ldd, rows, cols);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
+extern "C" int dep_loss_accumulate(const float* loss, const unsigned* status, const unsigned* soft, double* acc, void* stream) {
+    DEP_CHECK_ARG(acc && (loss || status || soft));
+    hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(64), 0, S_, loss, status, soft, acc);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

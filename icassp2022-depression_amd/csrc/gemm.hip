@@ -334,9 +334,11 @@ extern "C" int dep_set_gemm_mode(int mode, long min_macs) {
 extern "C" int dep_get_gemm_mode(void) { init_split_mode(); return g_split_mode; }
 bool dep_gemm_uses_bf16x3(int M, int N, int K, int seq_T) {
     init_split_mode();
-    if (naive_forced() || g_force_exact == 1) return false;
+    // same branch order as dep_gemm_internal
+    if (naive_forced()) return false;
     if (seq_T <= 0 && (long)dep_cdiv(M, BM) * dep_cdiv(N, BN) < 32 && K <= 8192 && (long)M * N * K <= (1L << 27)) return false;    // gemm_small
-    return g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs;
+    if (g_force_exact == 2) return true;
+    return g_force_exact == 0 && g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs;
 }
 
 extern "C" size_t dep_gemm_workspace_bytes(int transA, int transB, int M, int N, int K) {
@@ -389,7 +391,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     init_split_mode();
     if (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs))
         return dep_gemm_bf16x3_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
-                                      splits, kchunk, p.part, vec, s, g_split_mode == 2 ? 1 : 3);
+                                      splits, kchunk, p.part, vec, s, (g_force_exact != 2 && g_split_mode == 2) ? 1 : 3);     // the public bf16x3 entry is always 3 terms
 #define LAUNCH(TA, TB)                                                                    \
     do {                                                                                   \
         if (vec) hipLaunchKernelGGL((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \

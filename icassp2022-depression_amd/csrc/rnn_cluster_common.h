@@ -108,7 +108,10 @@ __device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, 
             const unsigned v = lane < NC ? ld_agent(hello + lane) : xcc;
             if (__all(v != 0)) { verdict = __all(v == xcc) ? 1 : 0; break; }
             if (soft) {
-                if (spins > HELLO_LIMIT_SOFT) { st_agent(soft, 1); verdict = -1; break; }
+                // giving up: take the own hello word back FIRST, so that a member dispatched in this very window can never see a
+                // complete cluster with a departed member in it; whoever got past the hello regardless leaves
+                // quietly at its first flag wait (wait_flags polls the soft word too)
+                if (spins > HELLO_LIMIT_SOFT) { if (lane == 0) { st_agent(hello + c, 0); st_agent(soft, 1); } verdict = -1; break; }
                 if ((spins & 15) == 15 && ld_agent(soft) != 0) { verdict = -1; break; }
             } else if (spins > SPIN_LIMIT) { st_agent(status, 5); verdict = -1; break; }
             if ((spins & 63) == 63 && ld_agent(status) != 0) { verdict = -1; break; }
@@ -123,13 +126,15 @@ __device__ __forceinline__ int cluster_same_xcd(unsigned* hello, int NC, int c, 
 // Poll the NC epoch flags of this cluster (lane i < NC reads flag i) until all reached `epoch` (flags only grow).
 // Called by every wave; returns false when the bounded spin gave up or another workgroup raised the status word --
 // the wave then simply leaves (the hardware barrier counts live waves only; the other waves give up the same way).
-__device__ __forceinline__ bool wait_flags(unsigned* tflags, int NC, unsigned epoch, unsigned* status, unsigned code) {
+// `soft` (kernels with a fallback behind them): a set soft word means another cluster gave this launch up -- leave without raising
+// the status, the fallback kernels redo the work.
+__device__ __forceinline__ bool wait_flags(unsigned* tflags, int NC, unsigned epoch, unsigned* status, unsigned code, unsigned* soft = nullptr) {
     const int lane = threadIdx.x & 63;
     for (unsigned spins = 0;; ++spins) {
         const bool ok = lane >= NC || ld_agent(tflags + lane) >= epoch;
         if (__all(ok)) return true;
         if (spins > SPIN_LIMIT) { st_agent(status, code); return false; }
-        if ((spins & 63) == 63 && ld_agent(status) != 0) return false;
+        if ((spins & 63) == 63 && (ld_agent(status) != 0 || (soft && ld_agent(soft) != 0))) return false;
         // no s_sleep between polls: the flag line's round trip (~500 ticks under load) paces the loop by itself, and the 64 clocks
         // the sleep added per failed poll were on every step's chain (A/B, three pairs: fused forward 1.028 -> 1.022 ms, backward
         // sweeps 1.575 -> 1.567 ms per step)

@@ -66,7 +66,12 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     if (p.b0 + bt * BT >= p.B) return;
     if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up (sticky status)
     if (p.soft && ld_agent(p.soft) != 0) return;   // dispatched after the clusters gave this launch up: the fallback kernels redo it
-    if (p.soft && p.force_soft) { if (threadIdx.x == 0) st_agent(p.soft, 1); return; }
+    if (p.soft && p.force_soft == 1) { if (threadIdx.x == 0) st_agent(p.soft, 1); return; }
+    // test hooks for the hello race: 2 = member FNC-1 of tile 0 arrives ~25 ms late (the others time out softly and take
+    // their hello words back; the late one must leave on the soft word), 3 = it vanishes right AFTER a complete hello (the others
+    // are already past it and must leave quietly at their first flag wait)
+    if (p.soft && p.force_soft == 2 && c == FNC - 1 && bt == 0)
+        for (int i = 0; i < 8000; ++i) __builtin_amdgcn_s_sleep(127);
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: role tests become scalar branches
     const int grp = w >> 2, gw = w & 3, jl = gw >> 1, kh = gw & 1;
@@ -115,6 +120,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     const int sxh = (p.nofast && !p.soft) ? 0 : cluster_same_xcd(p.hello + bt * FNC, FNC, c, p.status, p.soft);
     const int sx = (p.nofast && sxh >= 0) ? 0 : sxh;
     if (sx < 0) return;
+    if (p.soft && p.force_soft == 3 && c == FNC - 1 && bt == 0) { if (threadIdx.x == 0) st_agent(p.soft, 1); return; }
     const bool fast = sx == 1;
     const int b0t = p.b0 + bt * BT;                   // first utterance of the tile
 
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             // others' poll + gather and behind its own flag poll (the write-out stores come later, in slot Z: a wave's poll
             // loop would sit out its own stores).
             if (DROP && s < T) {
-                if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6)) return;
+                if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6, p.soft)) return;
                 u32x4 v[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             issue_gi(tv, s + 2);
         } else {
             FSTAMP(5);
-            if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6)) return;      // every wave polls (one poller + a verdict barrier measured no faster)
+            if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6, p.soft)) return;      // every wave polls (one poller + a verdict barrier measured no faster)
             FSTAMP(6);
             // gather: h0_s (next layer-0 step; also layer 1's input when there is no dropout) and h1_{s-2} (next layer-1 step)
             const bool need0 = (s + 1 < T) || (!DROP && s < T), need2 = s >= 2;
@@ -392,7 +398,7 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
     p.soft = a.soft_fallback ? (unsigned*)xbuf + 1 : nullptr;
-    { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] == '1') ? 1 : 0; } p.force_soft = fs; }
+    { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; } p.force_soft = fs; }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);

@@ -227,38 +227,51 @@ class Loss:
 
 class LossSum:
     """`total_loss += loss.item()` of the reference's loops (audio_gru_whole.py:195) without a host synchronisation per
-    mini-batch: the step losses are added on the device in float64 -- exactly what Python's float accumulation of the fp32
-    `loss.item()` values computes, in the same order -- and read ONCE with item().  The sweeps' status word is folded into a
-    device flag at every add(), so a sweep that gave up in any step of the epoch still raises (at item(), not silently).  Under
-    data parallelism the per-rank parts are summed by one all-reduce in item() (every rank calls it)."""
+    mini-batch: the step losses are added on the device in float64 and read ONCE with item().  On one rank that is exactly what
+    Python's float accumulation of the fp32 `loss.item()` values computes, in the same order; under data parallelism the
+    per-rank float64 partial sums are added by ONE all-reduce in item() (every rank calls it), which can differ in the last bits
+    from all-reducing every step loss first.  The sweeps' status word and the fused forward's fallback word are folded into two
+    device flags by the same launch (dep_loss_accumulate: one kernel per step and model stack), and they travel with the sum
+    in that all-reduce: a sweep that gave up on ANY rank raises on EVERY rank, at item() -- no rank goes on to the next
+    collective alone -- and every rank switches the exclusive forward off together."""
 
     def __init__(self, device):
-        self._acc = torch.zeros((), dtype=torch.float64, device=device)
-        self._bad = None
-        self._fell_back = None
+        self._acc = torch.zeros(3, dtype=torch.float64, device=device)       # [loss sum, max status word, max fallback word]
         self._reduce = False
 
     def add(self, loss, model=None):
-        self._acc += loss._v.reshape(-1)[0].double()
+        v = loss._v.reshape(-1)
         self._reduce = self._reduce or loss._reduce
         loss._reduce = False                              # summed here, once
-        for w in (model.status_words() if model is not None and hasattr(model, 'status_words') else []):
-            self._bad = w.clone() if self._bad is None else torch.maximum(self._bad, w)
-        for w in (model.fallback_words() if model is not None and hasattr(model, 'fallback_words') else []):
-            self._fell_back = w.clone() if self._fell_back is None else torch.maximum(self._fell_back, w)
+        sw = list(model.status_words()) if model is not None and hasattr(model, 'status_words') else []
+        fw = list(model.fallback_words()) if model is not None and hasattr(model, 'fallback_words') else []
+        if not v.is_cuda:                                 # host tensors: only the CPU stand-in model of tests/test_host_cpu.py
+            self._acc[0] += v[0].double()
+            for w in sw:
+                self._acc[1] = torch.maximum(self._acc[1], w.double())
+            for w in fw:
+                self._acc[2] = torch.maximum(self._acc[2], w.double())
+            return self
+        n = max(1, len(sw), len(fw))
+        for i in range(n):                                # one launch per recurrent stack of the model (fusion: two)
+            L.loss_accumulate(v if i == 0 else None, sw[i] if i < len(sw) else None, fw[i] if i < len(fw) else None, self._acc)
         return self
 
     def item(self):
-        if self._reduce:
-            parallel.all_reduce_sum(self._acc)
+        acc = self._acc
+        if parallel.world_size() > 1:
+            t = acc.clone()
+            if not self._reduce:
+                t[0] = 0.0                                # a loss that is already global: only the flags are shared
+            parallel.all_reduce_sum(t)                    # flags: a sum of non-negative words is non-zero iff one of them is
+            acc = t if self._reduce else torch.stack((acc[0], t[1], t[2]))
             self._reduce = False
-        v = float(self._acc.item())
-        if self._fell_back is not None and int(self._fell_back.item()) != 0:
-            L.note_fallback()                             # right results, but stop paying the hello time-out
-        if self._bad is not None and int(self._bad.item()) != 0:
-            raise L.DepError('a recurrent sweep gave up waiting for a cluster member during this epoch (status %d): the GPU was '
-                             'shared with another kernel; DEP_FUSED2=0 DEP_CLUSTER16=0 selects the sweeps that tolerate it'
-                             % int(self._bad.item()))
+        v, bad, fell = (float(x) for x in acc.tolist())
+        if fell != 0:
+            L.note_fallback()                             # right results, but stop paying the hello time-out (every rank together)
+        if bad != 0:
+            raise L.DepError('a recurrent sweep gave up waiting for a cluster member during this epoch (status %d on some rank): the GPU '
+                             'was shared with another kernel; DEP_FUSED2=0 DEP_CLUSTER16=0 selects the sweeps that tolerate it' % int(bad))
         return v
 
 

@@ -350,6 +350,10 @@ int dep_sigmoid_gate(const float* g, const float* x, float* y, long n, void* str
  *   dep_copy2d       : dst[r*ldd + c] = src[r*lds + c] -- torch.cat((text_feature, audio_feature), dim=1), fuse_net_whole.py:434
  *   dep_argmax_count : pred[b] = first arg-max of row b (output.data.max(1)[1]); *count += #(pred == label)
  *                      (pred.eq(y).sum(), audio_gru_whole.py:185-187); labels int32 or (labels_i64) int64; pred / count may be NULL */
+/* Epoch-level loss bookkeeping in ONE launch per step (nn.LossSum): acc[0] += *loss in float64 (`total_loss += loss.item()`,
+ * audio_gru_whole.py:195, without the per-step host sync), acc[1] = max(acc[1], *status), acc[2] = max(acc[2], *soft) -- the cluster
+ * sweeps' status word (dep_rnn_status) and fallback word (dep_rnn_set_exclusive) of the step.  Any of loss / status / soft may be NULL. */
+int dep_loss_accumulate(const float* loss, const unsigned* status, const unsigned* soft, double* acc, void* stream);
 int dep_gather_rows(const float* src, const long long* idx, float* dst, long nrows, long row_floats, void* stream);
 int dep_copy2d(const float* src, long lds, float* dst, long ldd, long rows, long cols, void* stream);
 int dep_argmax_count(const float* p, const void* labels, int labels_i64, int B, int C, long long* count, long long* pred,

@@ -58,3 +58,28 @@ def test_product_mel_table_equals_oracle():
     from icassp2022_depression_amd import audio_features_whole as m
     for sr in (8000, 16000, 22050, 44100):
         assert np.abs(m.mel_filters(sr, 2048, 80) - RF.mel_filterbank(sr, 2048, 80)).max() < 1e-12
+
+
+def test_power_spectrogram_equals_scipy_stft():
+    """The STFT half of the restatement (reflect-padded centred frames, periodic Hann, |rfft|^2) against an INDEPENDENT
+    implementation that is in the image: scipy.signal.stft.  This pins the framing / window / power
+    conventions to scipy's, not to the reference -- librosa and LOUPE are importable neither here nor in /root/reference, so
+    row f4 stays "parity unpinned"; what scipy cannot vouch for is the Slaney mel table and NetVLAD."""
+    import pytest
+    scipy_signal = pytest.importorskip("scipy.signal")
+    from oracle import ref_frontend as RF
+    rng = np.random.default_rng(4)
+    sr, n_fft, hop = 16000, 2048, 512
+    y = rng.standard_normal(sr // 2 + 333)
+    fr = RF.frames_centered(y, n_fft, hop) * RF.hann_periodic(n_fft)[None, :]
+    power = np.abs(np.fft.rfft(fr, axis=1)) ** 2                         # what log_melspectrogram forms before the mel table
+    # scipy: same centring when the signal is reflect-padded by hand (boundary=None, padded=False), 'hann' = periodic (fftbins=True)
+    ypad = np.pad(y, n_fft // 2, mode='reflect')
+    _, _, Z = scipy_signal.stft(ypad, fs=sr, window='hann', nperseg=n_fft, noverlap=n_fft - hop, nfft=n_fft, boundary=None,
+                                padded=False, return_onesided=True, scaling='spectrum')
+    win = scipy_signal.get_window('hann', n_fft, fftbins=True)
+    assert np.allclose(win, RF.hann_periodic(n_fft), atol=1e-15)
+    Zs = Z * win.sum()                                                    # scaling='spectrum' divides by sum(window)
+    assert Zs.shape == (n_fft // 2 + 1, power.shape[0])
+    got = np.abs(Zs.T) ** 2
+    assert np.abs(got - power).max() <= 1e-9 * power.max()

@@ -343,3 +343,32 @@ def test_regression_train_empty_shard_collective_order_gloo(modname):
     expect = float(np.mean(np.abs(np.arange(7) - pred)))
     for r in range(3):
         assert abs(got[r] - expect) < 1e-5, (r, got[r], expect)
+
+
+def test_device_feature_cache_notices_in_place_edits(monkeypatch):
+    """the HBM-resident feature cache is keyed on a content check, not only on the array object.  Default check: a
+    strided sample plus one probe per row; DEP_FEATURES_HASH=1: the whole array (xxh3)."""
+    import torch
+    from icassp2022_depression_amd import _common
+    _common.invalidate_device_features()
+    X = np.random.default_rng(0).standard_normal((40, 6, 8)).astype(np.float32)
+    t0 = _common.device_features(X, 'cpu', role='probe_test')
+    assert _common.device_features(X, 'cpu', role='probe_test') is t0                  # unchanged array: the cached copy
+    r = 17
+    col = (r * 2654435761) % 48
+    X.reshape(40, -1)[r, col] += 1.0                                                   # a middle row, edited in place at its probe
+    t1 = _common.device_features(X, 'cpu', role='probe_test')
+    assert t1 is not t0 and torch.equal(t1, torch.from_numpy(X))
+    monkeypatch.setenv('DEP_FEATURES_HASH', '1')
+    t2 = _common.device_features(X, 'cpu', role='probe_test')
+    X.reshape(40, -1)[r, (col + 1) % 48] += 1.0                                        # an element no probe looks at
+    t3 = _common.device_features(X, 'cpu', role='probe_test')
+    assert t3 is not t2 and torch.equal(t3, torch.from_numpy(X))
+    # the fusion scripts' pair list: editing a MIDDLE pair in place refreshes the stacked copy
+    pairs = [[np.full((3, 4), float(i), np.float32), np.full((3, 5), float(-i), np.float32)] for i in range(6)]
+    monkeypatch.delenv('DEP_FEATURES_HASH')
+    f0 = _common.PairFeeder(pairs, range(6), 'cpu')
+    pairs[3][1][0, 0] = 99.0
+    f1 = _common.PairFeeder(pairs, range(6), 'cpu')
+    assert float(f1.Xt[3, 0, 0]) == 99.0 and f1.Xt is not f0.Xt
+    _common.invalidate_device_features()
