@@ -184,7 +184,7 @@ def time_other_workload(name, dev, L, steps=8, warmup=3):
            'final_loss': round(loss.item(), 6),
            'dominant_kernel': {'kernel': d['dom'], 'avg_launch_ms': round(d['dom_ms'], 4), 'tflops': round(tfl, 2),
                                'frac_of_mfma_peak': round(tfl / peak, 4), 'peak_tflops': round(peak, 1)},
-           'gru_forward_path': (None if not fb else ('fallback (co-schedule-tolerant sweeps redid the forward)' if any(fb) else
+           'gru_forward_path': (None if (not fb or 'gru_fwd_sweep' not in d['cats']) else ('fallback (co-schedule-tolerant sweeps redid the forward)' if any(fb) else
                                                      'exclusive fused two-layer launch' if L.load().dep_rnn_get_exclusive() else 'tolerant sweeps (dep_rnn_set_exclusive(0))')),
            'kernels_ms_per_step': {k: round(v[0] / steps, 4) for k, v in d['cats'].items()},
            'workload': '%s.%s train step, B=%d T=%d F=%d H=%d' % (WORKLOADS[name][0], WORKLOADS[name][1], B, T, wl['F'], H)}

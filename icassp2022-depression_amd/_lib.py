@@ -65,6 +65,8 @@ _SIGS = {
                                _P, C.c_size_t, _P]),
     'dep_gemm_bf16x3': (C.c_int, [C.c_int] * 5 + [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_float, C.c_int, C.c_int,
                                   _P, C.c_size_t, _P]),
+    'dep_gemm': (C.c_int, [C.c_int] * 5 + [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_float, C.c_int, C.c_int,
+                           _P, C.c_size_t, _P]),
     'dep_set_gemm_mode': (C.c_int, [C.c_int, C.c_long]),
     'dep_get_gemm_mode': (C.c_int, []),
     'dep_layernorm_fwd': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
@@ -163,6 +165,14 @@ def gemm_split(transA, transB, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, beta
     wsb = ws.numel() * ws.element_size() if ws is not None else 0
     check(lib.dep_gemm_bf16x3(transA, transB, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(Cm), ldc, _ptr(bias), beta,
                               seq_T, shiftB, _ptr(ws), wsb, stream()), 'dep_gemm_bf16x3')
+
+
+def gemm_auto(transA, transB, M, N, K, A, lda, B, ldb, Cm, ldc, bias=None, beta=0.0, seq_T=0, shiftB=0, ws=None):
+    """dep_gemm: the precision dep_rnn_* would use for this contraction under the current dep_set_gemm_mode."""
+    lib = load()
+    wsb = ws.numel() * ws.element_size() if ws is not None else 0
+    check(lib.dep_gemm(transA, transB, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(Cm), ldc, _ptr(bias), beta,
+                       seq_T, shiftB, _ptr(ws), wsb, stream()), 'dep_gemm')
 
 
 def set_gemm_mode(mode, min_macs=-1):

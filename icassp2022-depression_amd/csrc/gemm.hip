@@ -421,6 +421,15 @@ extern "C" int dep_gemm_f32(int transA, int transB, int M, int N, int K, const f
     return rc;
 }
 
+// Same contract, precision as dep_rnn_forward / _backward would choose for a contraction of this size under the current
+// dep_set_gemm_mode (0 exact, 1 three-term split, 2 single bf16 products) -- the mode-following entry.
+extern "C" int dep_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda,
+                        const float* B, int ldb, float* C, int ldc, const float* bias, float beta,
+                        int seq_T, int shiftB, void* workspace, size_t workspace_bytes, void* stream) {
+    return dep_gemm_internal(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
+                             workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 // Same contract, 3-term bf16 split products (fp32 operands and accumulation): see gemm_bf16x3.hip.
 extern "C" int dep_gemm_bf16x3(int transA, int transB, int M, int N, int K, const float* A, int lda,
                                const float* B, int ldb, float* C, int ldc, const float* bias, float beta,

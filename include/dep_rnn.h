@@ -206,6 +206,13 @@ int dep_gemm_bf16x3(int transA, int transB, int M, int N, int K,
                     const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     const float* bias, float beta, int seq_T, int shiftB,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* Same contract, precision chosen exactly as dep_rnn_forward / dep_rnn_backward choose it for a contraction of this size under
+ * the current dep_set_gemm_mode (0: exact, 1: three-term split above min_macs, 2: single bf16 products).  dep_gemm_bf16x3 above
+ * is ALWAYS the three-term split, whatever the mode. */
+int dep_gemm(int transA, int transB, int M, int N, int K,
+             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+             const float* bias, float beta, int seq_T, int shiftB,
+             void* workspace, size_t workspace_bytes, void* stream);
 /* Experiment hook (tools/exp_overlap2.py): confine the working workgroups of the calling thread's next
  * split-precision GEMMs to XCDs [lo, lo + n) -- block index % 8 is the XCD.  (0, 8) = whole chip, the default. */
 int dep_gemm_set_xcds(int lo, int n);
