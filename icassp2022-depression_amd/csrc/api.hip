@@ -570,6 +570,20 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         a.dgi = dgi; a.dghn = dghn; a.lddg = lo.dg4 ? ldg : 0; a.lddghn = lo.dg4 ? ldg : 0;
         a.dbpart = W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
         a.hdr_slot = l < DEP_HDR_SLOTS ? l : 0; a.hdr_clean = l < DEP_HDR_SLOTS;
+        // Round 4: the sweep writes the gate gradients as the PK image (rows (t even, t + 1) = (hi, lo) bf16 pairs of both steps,
+        // gemm_bf16x3.hip) -- the three contractions that read them (dX, dW_ih, dW_hh) then stage them without converting; same
+        // bytes, same bits.  Only when all three really run the three-term kernel on its vector path.
+        static int pk_env = -1;
+        if (pk_env < 0) { const char* e = getenv("DEP_DGI_PK"); pk_env = (e && e[0] == '0') ? 0 : 1; }
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        float* dxl_probe = l == 0 ? dx : W + lo.dx[l & 1];
+        const bool pk = pk_env && lo.dg4 && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && a.split && dep_get_gemm_mode() == 1 &&
+                        dep_cluster_bwd_pk_ok(H, T) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(weights[(size_t)l * 4]) &&
+                        al16(dweights[(size_t)l * 4]) && al16(dweights[(size_t)l * 4 + 1]) &&
+                        dep_gemm_uses_bf16x3(G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(3 * H, H, BTr, T) &&
+                        (!dxl_probe || (dep_gemm_uses_bf16x3(BTr, Kl, G * H, 0) && al16(dxl_probe)));
+        a.dg_pk = pk ? 1 : 0;
+        struct FmtGuard { bool on; ~FmtGuard() { if (on) dep_gemm_set_operand_formats(0, 0); } } fmt_guard{pk};
         rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
@@ -591,6 +605,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         }
         rc = dep_finish_db(a, dbi, dbh);
         if (rc) return rc;
+        if (pk) dep_gemm_set_operand_formats(1, 0);               // A = the PK gate gradients in dX, dW_ih and dW_hh below (reset by fmt_guard)
         float* dxl = l == 0 ? dx : W + lo.dx[l & 1];
         // dX (B*T, Kl) (+)= dG * W_ih first: it is the only product the next layer's sweep waits for
         const bool stacked = D == 2 && lo.wstack[l] != 0;

@@ -91,6 +91,11 @@ const unsigned* dep_gemm_predicate();
 // A-operand column skip of the calling thread's next TN contractions (bf16x3 kernel only): logical column m of op(A) is stored
 // column m + (m >= at ? by : 0).  dW_hh of a GRU reads [dr | dz] and [dn*r] out of [dr | dz | dn | dn*r] with (2H, H).  (0, 0) = off.
 void dep_gemm_set_a_colskip(int at, int by);
+// Storage format of the calling thread's next contractions' operands (gemm_bf16x3.hip): 0 = fp32, 1 = PK, the pre-split row-pair
+// (hi, lo) bf16 image a producer kernel wrote in place of the fp32 array.  Only the bf16x3 kernel reads PK; dep_gemm_internal
+// refuses (DEP_ERR_ARG) a PK operand on any other path.  Reset to (0, 0) after the calls.
+void dep_gemm_set_operand_formats(int fmt_a, int fmt_b);
+bool dep_gemm_pk_pending();
 // true when dep_gemm_internal would run the bf16x3 kernel for a contraction of this size (it is the one that honours the skip)
 bool dep_gemm_uses_bf16x3(int M, int N, int K, int seq_T);
 // process-wide: may dep_rnn_forward use kernels that need every CU to themselves (dep_rnn_set_exclusive, include/dep_rnn.h)
@@ -150,8 +155,10 @@ struct dep_sweep_bwd_args {
     float* dbpart;           // partial bias sums, see dep_sweep_dbpart_floats
     int dbpart_rows;         // number of partial rows provided
     int hdr_slot, hdr_clean; // cluster sweeps: exchange-header slot of this launch; clean = the caller zeroed it
+    int dg_pk;               // GRU cluster sweep (burst kernel, 4H-wide rows): dgi / dghn as the PK image of gemm_bf16x3.hip instead of fp32
     hipStream_t stream;
 };
+bool dep_cluster_bwd_pk_ok(int H, int T);
 int dep_launch_sweep_bwd(const dep_sweep_bwd_args& a);
 int dep_sweep_num_wg(int B, int H, int impl);       // batch tiles (rows of dbpart) per direction
 bool dep_sweep_use_mfma(int H, int impl);

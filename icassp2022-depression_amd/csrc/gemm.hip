@@ -354,6 +354,13 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     DEP_CHECK_ARG(!(transA && transB));
     DEP_CHECK_ARG(!(seq_T > 0 && transB));
     GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, K, 1, nullptr, 1, 1, dep_gemm_predicate()};
+    init_split_mode();
+    const bool to_split = !naive_forced() && (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs)) &&
+                          !(seq_T <= 0 && (long)dep_cdiv(M, BM) * dep_cdiv(N, BN) < 32 && K <= 8192 && (long)M * N * K <= (1L << 27));
+    if (dep_gemm_pk_pending() && !(to_split && g_split_mode != 2)) {
+        dep_set_error("dep_gemm: a pre-split (PK) operand reached a contraction that does not run the three-term bf16x3 kernel");
+        return DEP_ERR_ARG;
+    }
     if (naive_forced()) {
         dim3 g(dep_cdiv(N, 128), M);
         hipLaunchKernelGGL(gemm_naive, g, dim3(128), 0, s, p, transA, transB);

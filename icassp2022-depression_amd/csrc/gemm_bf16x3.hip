@@ -35,17 +35,28 @@ struct GemmP {
     int skip_at, skip_by;       // A stored MN-contiguous (transA): logical column m lives at m + (m >= skip_at ? skip_by : 0); 0, 0 = off
 };
 
+// Operand storage formats (round 4).  FMT_F32: fp32 values, split while staging (above).  FMT_PK: the producer already stored the
+// (hi, lo) bf16 planes the staging would form, in place of the fp32 array (same 4 bytes per element, same row stride): physical
+// rows 2j / 2j+1 of the (rows x cols) array hold, per column c,
+//     row 2j   : bf16hi(x[2j][c]) | bf16hi(x[2j+1][c]) << 16          row 2j+1 : bf16lo(x[2j][c]) | bf16lo(x[2j+1][c]) << 16
+// i.e. k-pairs packed the way the LDS planes want them when the ROW index is the contraction index (TN forms: zero VALU per
+// element, the four loaded rows of a thread ARE hi01, lo01, hi23, lo23); when the row index is M (NN / NT A operand) a thread
+// loads both rows of a pair and separates the halves with one v_perm_b32 per element.  Bit-identical to the on-the-fly split.
+enum { FMT_F32 = 0, FMT_PK = 1 };
+
+
 // Operand tile of ROWS (128 or 256) rows x 32 k, 256 threads: a = tid&7, bq = tid>>3.
 //   !TR (K-contiguous rows): r[i]      = row (mn0 + bq + 32 i),            k  = k0 + a*4 + 0..3     i < ROWS/32
 //    TR (MN-contiguous)    : r[4jj + i] = k row (k0 + a*4 + i),           mn = mn0 + (bq + 32 jj)*4 + 0..3
-template <bool TR, bool VEC, int ROWS>
+template <bool TR, bool VEC, int ROWS, int FMT = FMT_F32>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int Kend,
                                           int tid, float (&r)[ROWS / 32][4], int seqT, int shift, int skip_at = 0, int skip_by = 0) {
     const int a = tid & 7, bq = tid >> 3;
     if (!TR) {
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
-            const int mn = mn0 + bq + 32 * i, k = k0 + a * 4;
+            // FMT_PK: slots 2j / 2j+1 are the hi-pair / lo-pair rows of logical rows (R, R+1), R = mn0 + 2 bq + 64 j
+            const int mn = FMT == FMT_PK ? mn0 + 2 * bq + 64 * (i >> 1) + (i & 1) : mn0 + bq + 32 * i, k = k0 + a * 4;
             const float* src = P + (size_t)mn * ld + k;
             if (VEC) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -119,10 +130,38 @@ __device__ __forceinline__ void hi4(f32x4 x, bf16x4& hi) {
 }
 
 // LDS images Sh/Sl: [ROWS rows (m or n)][LDK] bf16, k contiguous
-template <bool TR, int ROWS, int TERMS = 3>
+template <bool TR, int ROWS, int TERMS = 3, int FMT = FMT_F32>
 __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, const float (&r)[ROWS / 32][4]) {
     const int a = tid & 7, bq = tid >> 3;
-    if (!TR) {
+    if constexpr (FMT == FMT_PK && TR) {
+        // rows k0 + 4a + {0,1,2,3} of a thread = hi(k, k+1), lo(k, k+1), hi(k+2, k+3), lo(k+2, k+3) of its four columns: nothing to compute
+#pragma unroll
+        for (int jj = 0; jj < ROWS / 128; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = ((bq + 32 * jj) * 4 + e) * LDK + a * 4;
+                const u32x2v h = {__float_as_uint(r[jj * 4 + 0][e]), __float_as_uint(r[jj * 4 + 2][e])};
+                const u32x2v l = {__float_as_uint(r[jj * 4 + 1][e]), __float_as_uint(r[jj * 4 + 3][e])};
+                *reinterpret_cast<u32x2v*>(Sh + o) = h;
+                if constexpr (TERMS == 3) *reinterpret_cast<u32x2v*>(Sl + o) = l;
+            }
+    } else if constexpr (FMT == FMT_PK) {
+        // slots 2j / 2j+1 = hi-pair / lo-pair rows of logical rows (R, R+1): low halves belong to R, high halves to R+1
+#pragma unroll
+        for (int j = 0; j < ROWS / 64; ++j) {
+            const unsigned h0 = __float_as_uint(r[2 * j][0]), h1 = __float_as_uint(r[2 * j][1]), h2 = __float_as_uint(r[2 * j][2]), h3 = __float_as_uint(r[2 * j][3]);
+            const unsigned l0 = __float_as_uint(r[2 * j + 1][0]), l1 = __float_as_uint(r[2 * j + 1][1]), l2 = __float_as_uint(r[2 * j + 1][2]), l3 = __float_as_uint(r[2 * j + 1][3]);
+            const int o = (2 * bq + 64 * j) * LDK + a * 4;
+            const u32x2v he = {__builtin_amdgcn_perm(h1, h0, 0x05040100u), __builtin_amdgcn_perm(h3, h2, 0x05040100u)};
+            const u32x2v ho = {__builtin_amdgcn_perm(h1, h0, 0x07060302u), __builtin_amdgcn_perm(h3, h2, 0x07060302u)};
+            *reinterpret_cast<u32x2v*>(Sh + o) = he; *reinterpret_cast<u32x2v*>(Sh + o + LDK) = ho;
+            if constexpr (TERMS == 3) {
+                const u32x2v le = {__builtin_amdgcn_perm(l1, l0, 0x05040100u), __builtin_amdgcn_perm(l3, l2, 0x05040100u)};
+                const u32x2v lo = {__builtin_amdgcn_perm(l1, l0, 0x07060302u), __builtin_amdgcn_perm(l3, l2, 0x07060302u)};
+                *reinterpret_cast<u32x2v*>(Sl + o) = le; *reinterpret_cast<u32x2v*>(Sl + o + LDK) = lo;
+            }
+        }
+    } else if (!TR) {
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
             f32x4 x = {r[i][0], r[i][1], r[i][2], r[i][3]};
@@ -155,7 +194,7 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
 // TERMS = 3: the split-precision product (default).  TERMS = 1: a_hi * b_hi only -- plain bf16 products with fp32 accumulation
 // (dep_set_gemm_mode(2), the "bf16" throughput mode of BASELINE configs[1]: a third of the MFMAs, no lo planes; relative error
 // per product ~4e-3, so it is a separately labelled mode with its own tolerance, never the parity path).
-template <bool TA, bool TB, bool VEC, int BMT, int TERMS = 3>
+template <bool TA, bool TB, bool VEC, int BMT, int TERMS = 3, int FA = FMT_F32, int FB = FMT_F32>
 __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p) {
     if (p.only_if && *p.only_if == 0) return;
     constexpr bool A_TR = TA, B_TR = !TB;
@@ -186,8 +225,8 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
 
     f32x16 acc[MI][2];
     float ra[BMT / 32][4], rb[BN / 32][4];
-    load_tile<A_TR, VEC, BMT>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra, 0, 0, p.skip_at, p.skip_by);
-    load_tile<B_TR, VEC, BN>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb, p.seqT, p.shiftB);
+    load_tile<A_TR, VEC, BMT, FA>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra, 0, 0, p.skip_at, p.skip_by);
+    load_tile<B_TR, VEC, BN, FB>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb, p.seqT, p.shiftB);
 
     while (true) {
 #pragma unroll
@@ -203,17 +242,17 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
 
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             if (!(p.ablate & 8) || k0 == kbeg) {
-                store_tile<A_TR, BMT, TERMS>(Ah, Al, tid, ra);
-                store_tile<B_TR, BN, TERMS>(Bh, Bl, tid, rb);
+                store_tile<A_TR, BMT, TERMS, FA>(Ah, Al, tid, ra);
+                store_tile<B_TR, BN, TERMS, FB>(Bh, Bl, tid, rb);
             }
             __syncthreads();
             if (!(p.ablate & 4)) {
                 if (k0 + BK < kend) {
-                    load_tile<A_TR, VEC, BMT>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0, p.skip_at, p.skip_by);
-                    load_tile<B_TR, VEC, BN>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb, p.seqT, p.shiftB);
+                    load_tile<A_TR, VEC, BMT, FA>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, ra, 0, 0, p.skip_at, p.skip_by);
+                    load_tile<B_TR, VEC, BN, FB>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, rb, p.seqT, p.shiftB);
                 } else if (has_next) {       // first k-tile of the NEXT output tile
-                    load_tile<A_TR, VEC, BMT>(p.A, p.lda, nm0, p.M, nkb, nke, tid, ra, 0, 0, p.skip_at, p.skip_by);
-                    load_tile<B_TR, VEC, BN>(p.B, p.ldb, nn0, p.N, nkb, nke, tid, rb, p.seqT, p.shiftB);
+                    load_tile<A_TR, VEC, BMT, FA>(p.A, p.lda, nm0, p.M, nkb, nke, tid, ra, 0, 0, p.skip_at, p.skip_by);
+                    load_tile<B_TR, VEC, BN, FB>(p.B, p.ldb, nn0, p.N, nkb, nke, tid, rb, p.seqT, p.shiftB);
                 }
             }
             if (!(p.ablate & 2))
@@ -662,6 +701,9 @@ __global__ void splitk_reduce2(const unsigned* only_if, const float* __restrict_
 static thread_local int g_xcd_lo = 0, g_xcd_n = 8;
 static thread_local int g_skip_at = 0, g_skip_by = 0;
 void dep_gemm_set_a_colskip(int at, int by) { g_skip_at = at; g_skip_by = by; }
+static thread_local int g_fmt_a = FMT_F32, g_fmt_b = FMT_F32;
+void dep_gemm_set_operand_formats(int fmt_a, int fmt_b) { g_fmt_a = fmt_a; g_fmt_b = fmt_b; }
+bool dep_gemm_pk_pending() { return g_fmt_a != FMT_F32 || g_fmt_b != FMT_F32; }
 extern "C" int dep_gemm_set_xcds(int lo, int n) { if (lo < 0 || n < 1 || lo + n > 8) return DEP_ERR_ARG; g_xcd_lo = lo; g_xcd_n = n; return DEP_OK; }
 
 // Same contract as dep_gemm_internal (gemm.hip); `splits` is decided by the caller's shared heuristic.
@@ -673,7 +715,14 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     if (wsd == -2) { const char* e = getenv("DEP_GEMM_WS"); wsd = e ? atoi(e) : 0; if (wsd < 0 || wsd > 4) wsd = 0; }
     // (32-bit lane offsets: every operand must span less than 4 GB)
     const size_t spanA = (size_t)(transA ? K : M) * lda * 4, spanB = (size_t)(transB ? N : K) * ldb * 4;
-    if (wsd > 0 && terms == 3 && M >= 256 && !(transA && g_skip_by) && spanA < (1ull << 32) && spanB < (1ull << 32)) {
+    const int fa = g_fmt_a, fb = g_fmt_b;
+    if (fa != FMT_F32 || fb != FMT_F32) {
+        // pre-split operands: vector loads, three-term products; a PK operand pairs ROWS, so its row count must be even, the
+        // contraction index (TN) must start on even rows (k-chunks are multiples of 32) and a row-shifted operand cannot be PK
+        DEP_CHECK_ARG(vec && terms == 3 && fa == FMT_PK && (fb == FMT_F32 || (fb == FMT_PK && transA && !transB && shiftB == 0)));
+        DEP_CHECK_ARG(transA ? (K % 2 == 0 && kchunk % 2 == 0) : (M % 2 == 0));
+    }
+    if (wsd > 0 && fa == FMT_F32 && fb == FMT_F32 && terms == 3 && M >= 256 && !(transA && g_skip_by) && spanA < (1ull << 32) && spanB < (1ull << 32)) {
         // wave-specialised kernel: one 8-wave workgroup per CU, 256 x 128 tiles, `wsd` register sets of prefetch
         GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl, dep_gemm_predicate(), 0, 8, 0, 0};
         const int ntiles = p.gx * p.gy * splits;
@@ -723,9 +772,21 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
                    else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false, 128, TERMS>), g, dim3(NT), 0, s, p); }   \
     } while (0)
 #define LAUNCH(TA, TB) do { if (terms == 1) LAUNCH1(TA, TB, 1); else LAUNCH1(TA, TB, 3); } while (0)
-    if (!transA && transB) LAUNCH(false, true);
+#define LAUNCH_PK(TA, TB, BM, FA_, FB_) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, BM, 3, FA_, FB_>), g, dim3(NT), 0, s, p)
+    if (fa == FMT_PK) {
+        if (transA) {
+            if (big) { if (fb == FMT_PK) LAUNCH_PK(true, false, 256, FMT_PK, FMT_PK); else LAUNCH_PK(true, false, 256, FMT_PK, FMT_F32); }
+            else     { if (fb == FMT_PK) LAUNCH_PK(true, false, 128, FMT_PK, FMT_PK); else LAUNCH_PK(true, false, 128, FMT_PK, FMT_F32); }
+        } else if (!transB) {
+            if (big) LAUNCH_PK(false, false, 256, FMT_PK, FMT_F32); else LAUNCH_PK(false, false, 128, FMT_PK, FMT_F32);
+        } else {
+            LAUNCH_PK(false, true, 128, FMT_PK, FMT_F32);
+        }
+    }
+    else if (!transA && transB) LAUNCH(false, true);
     else if (!transA && !transB) LAUNCH(false, false);
     else LAUNCH(true, false);
+#undef LAUNCH_PK
 #undef LAUNCH
 #undef LAUNCH1
     DEP_CHECK_LAUNCH();

@@ -35,6 +35,7 @@ struct P2 {
     int trall_off;           // debug: LDS offset (32-bit words) of the per-step stamp array
     int ntstream;            // DEP_BWD_NT=1: non-temporal hint on the service waves' HBM streams
     int wflags;              // DEP_BWD_WFLAGS: every compute wave raises its OWN epoch flag once its own payload stores are acknowledged (no workgroup barrier in front of the flag; the pollers watch 4 NC words)
+    int dgpk;                // round 4: write the gate gradients as the PK image the bf16x3 GEMMs read without converting (gemm_bf16x3.hip FMT_PK): rows (t even, t+1) of an utterance hold the (hi, lo) bf16 pairs of both steps; burst kernel, 4H-wide layout, T even
     int xhalf;               // experiment (DEP_BWD_XHALF=1): the sweep's workgroups on XCDs 0-3 only, two per CU; the launch has twice the blocks and those of XCDs 4-7 leave at once
 };
 
@@ -61,7 +62,8 @@ constexpr int SVC_THREADS = 256;
 constexpr int SROW = 36;                             // LDS row stride (floats) of ibuf / obuf: 16-byte aligned rows, conflict-free columns
 constexpr int SARR = 16 * SROW;
 constexpr int TRACE_F = 2048, IBUF_F = 2304;         // float offsets into the workgroup's LDS (planes: [0, 2048))
-constexpr size_t burst_lds_bytes(int KB) { return (size_t)(IBUF_F + KB * 6 * SARR + (KB + 1) * 4 * SARR) * sizeof(float); }
+constexpr int obuf_slots(int KB) { return KB == 4 ? KB + 2 : KB + 1; }      // KB + 1 does for fp32 rows; the PK flush (KB = 4 only) works on step PAIRS and may lag one step
+constexpr size_t burst_lds_bytes(int KB) { return (size_t)(IBUF_F + KB * 6 * SARR + obuf_slots(KB) * 4 * SARR) * sizeof(float); }
 
 template <int NTW, bool SPLIT, int KB>      // output tiles per wave = H/64
 __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1(P2 p) {
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     constexpr int KBX = BURST ? KB : 1;
     const bool svc = BURST && tid >= CT;              // wave-uniform
     float* ibuf = smem + IBUF_F;                      // [KB][6][16][SROW]: r, z, n, hn, h_{t-1}, dy of step k in slot k % KB
-    float* obuf = ibuf + KBX * 6 * SARR;              // [KB+1][4][16][SROW]: dr, dz, dn, dn*r of step k in slot k % (KB+1)
+    constexpr int OSL = obuf_slots(KBX);
+    float* obuf = ibuf + KBX * 6 * SARR;              // [OSL][4][16][SROW]: dr, dz, dn, dn*r of step k in slot k % OSL
     f32x4 wr[SPLIT ? 1 : NTW][SPLIT ? 1 : KCB];
     u32x4 wq[SPLIT ? NTW : 1][SPLIT ? 3 : 1][2];       // [tile][k-step = gate][hi, lo]
     if (!svc) {
@@ -191,11 +194,33 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
         if (!svalid) return;
         for (int k = k0 < 0 ? 0 : k0; k < k1; ++k) {
             const size_t row = (size_t)sb * T + (T - 1 - k);
-            const float* o = obuf + (k % (KBX + 1)) * 4 * SARR + sr * SROW + sp * 4;
+            const float* o = obuf + (k % OSL) * 4 * SARR + sr * SROW + sp * 4;
             // arrays sarr0 (dr / dz) and 2 + sarr0 (dn / dn*r)
             stnt(p.dgi + row * p.lddg + (sodd ? H : 0) + scol, ld4(o + (sodd ? SARR : 0)));
             float* g1 = sodd ? p.dghn + row * p.lddghn + scol : p.dgi + row * p.lddg + 2 * H + scol;
             stnt(g1, ld4(o + (sodd ? 3 * SARR : 2 * SARR)));
+        }
+    };
+    // PK image (p.dgpk): steps (ka, ka+1), ka even, are rows t_even + 1, t_even (t_even = T-2-ka) of the utterance; physical row
+    // t_even holds bf16hi(x[t_even]) | bf16hi(x[t_even+1]) << 16 per column, row t_even + 1 the residual (lo) pairs -- exactly the
+    // (hi, lo) the GEMM's split4 would form (same v_cvt_pk_bf16_f32 roundings), so the contractions' bits do not change.
+    auto svc_flush_pk = [&](int k0, int k1) {         // complete step pairs in [k0, k1): both even
+        if (!svalid) return;
+        for (int ka = k0 < 0 ? 0 : k0; ka + 1 < k1; ka += 2) {
+            const size_t row = (size_t)sb * T + (T - 2 - ka);                    // the even row of the pair
+            const float* oo = obuf + (ka % OSL) * 4 * SARR + sr * SROW + sp * 4;        // step ka   = row t_even + 1
+            const float* oe = obuf + ((ka + 1) % OSL) * 4 * SARR + sr * SROW + sp * 4;  // step ka+1 = row t_even
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {             // arrays sarr0 (dr / dz) and 2 + sarr0 (dn / dn*r)
+                const int ao = (q ? 2 : 0) + (sodd ? 1 : 0);
+                const f32x4 xe = ld4(oe + ao * SARR), xo = ld4(oo + ao * SARR);
+                u32x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { unsigned hh, ll; split_pair(xe[e], xo[e], hh, ll); h[e] = hh; l[e] = ll; }
+                float* g = p.dgi + row * p.lddg + ao * H + scol;                 // 4H-wide rows [dr | dz | dn | dn*r]
+                stnt(g, __builtin_bit_cast(f32x4, h));
+                stnt(g + p.lddg, __builtin_bit_cast(f32x4, l));
+            }
         }
     };
     if constexpr (BURST) {
@@ -216,7 +241,8 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                     // measured the same launch time: the burst occupies the CU's memory pipeline for ~1.3 steps either way.)
                     svc_issue(k + KBX, KBX);
                     if (trs) p.trace[32 + (k - 100) * 4 + 1] = (long long)__builtin_readcyclecounter();
-                    svc_flush(k - KBX, k);
+                    if (p.dgpk) svc_flush_pk(k - KBX - (phi & 1), k - (phi & 1));      // whole pairs: one step later for the tiles with an odd phase
+                    else svc_flush(k - KBX, k);
                 }
                 if (trs) p.trace[32 + (k - 100) * 4 + 2] = (long long)__builtin_readcyclecounter();
                 bar_lds();                           // #1
@@ -231,7 +257,8 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                 if (!p.wflags) bar_lds();            // #2 (the compute waves' drain barrier; absent with per-wave flags)
             }
             const int jl2 = (T - 1 + KBX - phi) % KBX;
-            svc_flush(T - 1 - jl2, T);                // the gate gradients since the last dirty step
+            if (p.dgpk) svc_flush_pk(T - 1 - jl2 - (phi & 1), T);      // T is even: the last pair is complete
+            else svc_flush(T - 1 - jl2, T);           // the gate gradients since the last dirty step
             return;
         }
         __syncthreads();
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
             st2(dgs + j * LDG + ul, dr); st2(dgs + j * LDG + 32 + ul, dz); st2(dgs + j * LDG + 64 + ul, dnr);
         }
         if constexpr (BURST) {
-            float* ob = obuf + ((T - 1 - t) % (KBX + 1)) * 4 * SARR + j * SROW + ul;
+            float* ob = obuf + ((T - 1 - t) % OSL) * 4 * SARR + j * SROW + ul;
             st2(ob, dr); st2(ob + SARR, dz); st2(ob + 2 * SARR, dn); st2(ob + 3 * SARR, dnr);
         } else if (valid) {
             float* g = p.dgi + row * p.lddg;
@@ -749,6 +776,15 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
     return DEP_OK;
 }
 
+// May dep_launch_cluster_bwd write the gate gradients as the PK image (dep_sweep_bwd_args.dg_pk)?  Needs the burst-stream kernel
+// (its service waves' flush forms the pairs): H <= 256, bursts not switched off, not the two-per-CU placement experiment.
+bool dep_cluster_bwd_pk_ok(int H, int T) {
+    const char* v = getenv("DEP_BWD_BURST");
+    const int kbv = v ? atoi(v) : 4;
+    const char* x = getenv("DEP_BWD_XHALF");
+    return H <= 256 && T % 2 == 0 && kbv != 0 && kbv != 6 && !(x && x[0] == '1');
+}
+
 int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
     DEP_CHECK_ARG(dep_cluster_ok(a.cell, a.H, a.B, a.dirs) && xbuf && xbuf_bytes >= dep_cluster_xbuf_bytes(a.cell, a.H, a.B, a.dirs));
     const int NC = a.H / 32, CH = dep_cluster_chunk(NC, 1, 256), nbt = dep_cdiv(a.B, BT);
@@ -762,6 +798,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.dpooled = a.dpooled; p.pool_scale = a.pool_scale; p.dh_n = a.dh_n;
     p.sv0 = a.sv0; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
     p.dgi = a.dgi; p.lddg = a.lddg ? a.lddg : 3 * a.H; p.dghn = a.dghn; p.lddghn = a.lddghn ? a.lddghn : a.H; p.dbpart = a.dbpart;
+    p.dgpk = a.dg_pk;
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
     const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 256);
@@ -794,6 +831,9 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         DEP_BWD_ATTR(8, false, 0); DEP_BWD_ATTR(8, true, 0);
 #undef DEP_BWD_ATTR
         attr_b = true;
+    }
+    if (p.dgpk) {       // the PK image needs the burst kernel's flush, the 4H-wide rows and whole step pairs (dep_cluster_bwd_pk_ok)
+        DEP_CHECK_ARG(kb == 4 && a.split && a.T % 2 == 0 && a.lddg == 4 * a.H && a.lddghn == 4 * a.H && a.dghn == a.dgi + 3 * a.H);
     }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;

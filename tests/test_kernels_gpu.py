@@ -79,7 +79,7 @@ def test_gemm_bf16_products_mode_has_its_own_tolerance(tA, tB, M, N, K):
     a, b = dev(A), dev(B)
     c = torch.empty(M, N, device=DEV)
     ws = L.gemm_ws(tA, tB, M, N, K, DEV)
-    L.set_gemm_mode(2)
+    L.set_gemm_mode(2, 0)                                   # threshold 0: these test sizes are below the default 2^28 multiply-adds
     try:
         L.gemm_auto(tA, tB, M, N, K, a, a.stride(0), b, b.stride(0), c, N, ws=ws)       # the mode-following entry (what dep_rnn_* runs)
         err = np.abs(host(c) - ref) / scale
@@ -88,7 +88,7 @@ def test_gemm_bf16_products_mode_has_its_own_tolerance(tA, tB, M, N, K):
         L.gemm_split(tA, tB, M, N, K, a, a.stride(0), b, b.stride(0), c, N, ws=ws)
         assert (np.abs(host(c) - ref) / scale).max() < 1.5e-5
     finally:
-        L.set_gemm_mode(1)
+        L.set_gemm_mode(1, 1 << 28)
     L.gemm_split(tA, tB, M, N, K, a, a.stride(0), b, b.stride(0), c, N, ws=ws)
     assert (np.abs(host(c) - ref) / scale).max() < 1.5e-5          # and the default mode is back
 
