@@ -1,0 +1,36 @@
+"""Helper of test_presplit_gpu.py: one GRU-256 x2 forward + backward on seeded data; saves every gradient (and dX) to argv[1].
+Run twice by the test, with DEP_DGI_PK=0 and =1 in the environment (the switch is read once per process)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from icassp2022_depression_amd import _lib as L  # noqa: E402
+
+out, B, T, F = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+want_dx = len(sys.argv) > 5 and sys.argv[5] == 'dx'
+H, Lyr = 256, 2
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(B * 1000 + T)
+k = 1.0 / np.sqrt(H)
+W = []
+for l in range(Lyr):
+    for shp in ((3 * H, F if l == 0 else H), (3 * H, H), (3 * H,), (3 * H,)):
+        W.append(((torch.rand(*shp, generator=g) * 2 - 1) * k).to(dev))
+Gd = [torch.full_like(w, float('nan')) for w in W]
+x = torch.randn(B, T, F, generator=g).to(dev)
+dpool = torch.randn(B, H, generator=g).to(dev)
+dy = torch.randn(B, T, H, generator=g).to(dev)
+rnn = L.Rnn(L.CELL_GRU, B, T, F, H, Lyr, 1, True, 0.5, L.POOL_MEAN, dev)
+pooled = torch.empty(B, H, device=dev)
+dx = torch.full((B, T, F), float('nan'), device=dev) if want_dx else None
+rnn.forward(x, W, seed=11, pooled=pooled)
+rnn.backward(x, W, Gd, dy=dy, dpooled=dpool, dx=dx)
+rnn.check()
+torch.cuda.synchronize()
+res = {'g%d' % i: t.cpu().numpy() for i, t in enumerate(Gd)}
+if dx is not None:
+    res['dx'] = dx.cpu().numpy()
+np.savez(out, **res)

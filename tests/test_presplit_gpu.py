@@ -1,0 +1,33 @@
+"""Round 4: the GRU backward sweep writes its gate gradients as the pre-split PK image (gemm_bf16x3.hip FMT_PK) and the three
+contractions that read them stage that image without converting.  The image holds exactly the (hi, lo) bf16 planes the on-the-fly
+split forms, so EVERY gradient must come out BIT-IDENTICAL to the fp32-array path (DEP_DGI_PK=0)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(tmp_path, tag, pk, B, T, F, dx):
+    out = str(tmp_path / f'{tag}_{pk}.npz')
+    e = dict(os.environ, DEP_DGI_PK=str(pk))
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, str(B), str(T), str(F)] + (['dx'] if dx else []),
+                       env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return np.load(out)
+
+
+# B = 416: 26 tiles -> every burst phase 0..3 (the PK flush lags one step for the odd ones); T even, with 0 / 2 steps after the last
+# dirty step; F = 64 / 256: both layers' contractions above the three-term kernel's size threshold; dx: the NN form of layer 0 too
+@pytest.mark.parametrize('B,T,F,dx', [(416, 20, 64, False), (416, 22, 256, True), (160, 6, 256, False), (512, 300, 256, False)])
+def test_pk_gate_gradients_leave_every_gradient_bit_identical(tmp_path, B, T, F, dx):
+    a = _run(tmp_path, 'a', 0, B, T, F, dx)
+    b = _run(tmp_path, 'b', 1, B, T, F, dx)
+    for k in a.files:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
