@@ -91,6 +91,7 @@ struct Layout {
     bool cluster16;                  // forward with 16-unit members, two workgroups per CU (rnn_cluster16.hip)
     bool dg4;                        // GRU cluster backward: gate gradients as ONE (B*T, 4H) array [dr | dz | dn | dn*r] (dW_hh is then one contraction)
     bool cluster16_bwd;              // same for the backward (slower than 32-unit members: A/B only, DEP_CLUSTER16_BWD=1)
+    bool sv16;                       // GRU cluster sweeps: saved gates r, z, n as 16-bit fixed point (split-precision mode only; decided per call)
     bool fused2;                     // 2-layer GRU, H = 256: both layers in one launch (rnn_fused2.hip), split-precision mode only
     size_t wih_img;                  // workspace: packed W_ih of layer 1 for the fused forward
 };
@@ -182,6 +183,14 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
         lo.dbpart2 = w; w += al((size_t)lo.nwg * 4 * H);
     }
     lo.ws_floats = w;
+    // 16-bit saved gates: the kernels that implement them are the fused forward, the 32-unit-member forward and the 32-unit-member
+    // backward (burst or not); the 16-unit-member kernels and the opt-in fused backward read / write fp32 gates
+    {
+        static int sv_env = -1, fb_env = -1;
+        if (sv_env < 0) { const char* e = getenv("DEP_SV16"); sv_env = (e && e[0] == '0') ? 0 : 1; }
+        if (fb_env < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fb_env = (e && e[0] == '1') ? 1 : 0; }
+        lo.sv16 = sv_env && !fb_env && lo.cluster && d->cell == DEP_CELL_GRU && d->training && !lo.cluster16_bwd && (lo.fused2 || !lo.cluster16);
+    }
     return true;
 }
 
@@ -299,7 +308,8 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     if (lo.cluster) { rc = dep_cluster_reset_status(W + lo.xbuf, s); if (rc) return rc; }
     // the recurrent-weight images packed below are precision-mode specific: remember which mode this reserve holds
     // bit 0: precision mode; bit 1: the backward image is the 16-unit-member one (a caller flipping DEP_CLUSTER16_BWD is refused too)
-    record_reserve_mode(reserve, (sweep_split_mode() ? 1 : 0) | (lo.cluster16_bwd ? 2 : 0));
+    const bool sv16 = lo.sv16 && sweep_split_mode();      // (exact-fp32 mode keeps fp32 gates: its 16-unit-member forward has no 16-bit path)
+    record_reserve_mode(reserve, (sweep_split_mode() ? 1 : 0) | (lo.cluster16_bwd ? 2 : 0) | (sv16 ? 4 : 0));
     if (lo.fused2 && sweep_split_mode() && excl) {
         // both layers in one launch: layer 1 runs one step behind layer 0 and takes its input straight from the exchanged
         // h0_t (no layer-1 input-projection GEMM, no GI round trip through HBM for it)
@@ -330,6 +340,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         for (int l = 0; l < 2; ++l) for (int k = 0; k < 4; ++k) f.sv[l][k] = d->training ? R + lo.sv[l][k] : nullptr;
         f.stream = s;
         f.soft_fallback = 1;
+        f.sv16 = sv16 ? 1 : 0;
         f.hdr_clean = 1;                                   // dep_cluster_reset_status above zeroed every header slot
         rc = dep_launch_fused2_fwd(f, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
         // Fallback, decided ON THE DEVICE (no host synchronisation, identical on every data-parallel rank): the launch above
@@ -357,7 +368,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             a.pooled = (l == 1 && pooled) ? pooled : nullptr; a.pool_scale = f.pool_scale;
             a.h_n = h_n ? h_n + (size_t)l * B * H : nullptr;
             if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
-            a.only_if = soft; a.stream = s;
+            a.only_if = soft; a.stream = s; a.sv16 = sv16 ? 1 : 0;
             a.hdr_slot = 1 + l; a.hdr_clean = 1;             // own header slots: still zero from the call's one memset
             rc = dep_launch_cluster_fwd(a, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
         }
@@ -440,6 +451,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         a.h_n = h_n ? h_n + (size_t)l * D * B * H : nullptr;
         if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
         a.stream = s;
+        a.sv16 = (sv16 && lo.cluster && !use16 && d->cell == DEP_CELL_GRU) ? 1 : 0;
         a.hdr_slot = l < DEP_HDR_SLOTS ? l : 0; a.hdr_clean = l < DEP_HDR_SLOTS;      // one header slot per layer, zeroed once per call
         rc = use16 ? dep_launch_cluster16_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
@@ -481,6 +493,11 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
             dep_set_error("dep_rnn_backward: the reserve was produced by a forward in %s mode, the current mode is %s "
                           "(dep_set_gemm_mode / DEP_SWEEP_MODE must not change between a forward and its backward)",
                           (fm & 1) ? "bf16x3" : "f32", (fm & 1) ? "f32" : "bf16x3");
+            return DEP_ERR_ARG;
+        }
+        if (fm >= 0 && ((fm >> 2) & 1) != ((lo.sv16 && sweep_split_mode()) ? 1 : 0)) {
+            dep_set_error("dep_rnn_backward: the reserve holds %s saved gates, this call expects the other format (DEP_SV16 / DEP_EXCLUSIVE changed?)",
+                          (fm & 4) ? "16-bit" : "fp32");
             return DEP_ERR_ARG;
         }
         if (fm >= 0 && ((fm >> 1) & 1) != (lo.cluster16_bwd ? 1 : 0)) {
@@ -583,6 +600,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
                         dep_gemm_uses_bf16x3(G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(3 * H, H, BTr, T) &&
                         (!dxl_probe || (dep_gemm_uses_bf16x3(BTr, Kl, G * H, 0) && al16(dxl_probe)));
         a.dg_pk = pk ? 1 : 0;
+        a.sv16 = (lo.sv16 && sweep_split_mode() && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU) ? 1 : 0;
         struct FmtGuard { bool on; ~FmtGuard() { if (on) dep_gemm_set_operand_formats(0, 0); } } fmt_guard{pk};
         rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)

@@ -130,6 +130,7 @@ struct dep_sweep_args {
     // reserve (training): GRU r,z,n,hn each (B,T,H) ; LSTM gates (B,T,dirs*4H) + c (B,T,dirs*H)
     float* sv0; float* sv1; float* sv2; float* sv3;
     const unsigned* only_if;  // cluster forward: run only when this device word is non-zero (fallback behind an exclusive kernel), or NULL
+    int sv16;                 // GRU cluster sweeps: sv0..sv2 (r, z, n) are 16-bit fixed point (rnn_cluster_common.h), sv3 (hn) stays fp32
     int hdr_slot, hdr_clean;  // cluster sweeps: exchange-header slot of this launch; clean = the caller zeroed it (rnn_cluster_common.h)
     hipStream_t stream;
 };
@@ -155,6 +156,7 @@ struct dep_sweep_bwd_args {
     float* dbpart;           // partial bias sums, see dep_sweep_dbpart_floats
     int dbpart_rows;         // number of partial rows provided
     int hdr_slot, hdr_clean; // cluster sweeps: exchange-header slot of this launch; clean = the caller zeroed it
+    int sv16;                // saved gates r, z, n are 16-bit fixed point (must match the forward that wrote them)
     int dg_pk;               // GRU cluster sweep (burst kernel, 4H-wide rows): dgi / dghn as the PK image of gemm_bf16x3.hip instead of fp32
     hipStream_t stream;
 };
@@ -194,6 +196,7 @@ struct dep_fused2_args {
     float drop_p; uint64_t seed; uint32_t site;
     float* pooled; float pool_scale; float* hn0; float* hn1;
     float* sv[2][4];
+    int sv16;                                                 // saved gates r, z, n as 16-bit fixed point (rnn_cluster_common.h)
     int soft_fallback;                                        // 1: a failed hello sets the workspace's soft flag instead of the status word
     int hdr_clean;                                            // slot 0 was zeroed by the caller (dep_cluster_reset_status)
     hipStream_t stream;

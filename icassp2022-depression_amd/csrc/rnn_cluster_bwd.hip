@@ -35,7 +35,9 @@ struct P2 {
     int trall_off;           // debug: LDS offset (32-bit words) of the per-step stamp array
     int ntstream;            // DEP_BWD_NT=1: non-temporal hint on the service waves' HBM streams
     int wflags;              // DEP_BWD_WFLAGS: every compute wave raises its OWN epoch flag once its own payload stores are acknowledged (no workgroup barrier in front of the flag; the pollers watch 4 NC words)
+    int sv16;                // saved gates r, z, n are 16-bit fixed point (rnn_cluster_common.h)
     int dgpk;                // round 4: write the gate gradients as the PK image the bf16x3 GEMMs read without converting (gemm_bf16x3.hip FMT_PK): rows (t even, t+1) of an utterance hold the (hi, lo) bf16 pairs of both steps; burst kernel, 4H-wide layout, T even
+    int ablate;              // timing experiment only (DEP_BWD_ABLATE, WRONG results): 1 = the four saved-gate arrays all read r's rows (HBM reads 24H -> 12H per row, data stays non-zero), 2 = no gate-gradient write-out
     int xhalf;               // experiment (DEP_BWD_XHALF=1): the sweep's workgroups on XCDs 0-3 only, two per CU; the launch has twice the blocks and those of XCDs 4-7 leave at once
 };
 
@@ -136,7 +138,12 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
         if (valid && t >= 0) {
             const size_t row = (size_t)b * T + t;
             const size_t so = row * H + col;
-            s.r = ld2(p.sv0 + so); s.z = ld2(p.sv1 + so); s.n = ld2(p.sv2 + so); s.hn = ld2(p.sv3 + so);
+            if (p.sv16) {
+                s.r = unpack_unorm2(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(p.sv0) + so));
+                s.z = unpack_unorm2(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(p.sv1) + so));
+                s.n = unpack_snorm2(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(p.sv2) + so));
+            } else { s.r = ld2(p.sv0 + so); s.z = ld2(p.sv1 + so); s.n = ld2(p.sv2 + so); }
+            s.hn = ld2(p.sv3 + so);
             if (t > 0) s.hp = ld2(p.y + (row - 1) * p.ldy + col);
             if (p.dy) s.dy = ld2(p.dy + row * p.lddy + col);
         }
@@ -155,8 +162,8 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     // that the base pointers are selected in SGPRs (a per-lane choice makes hipcc index the kernel arguments in memory and
     // wait for that pointer load -- vmcnt(0) -- in front of every data load)
     const bool sodd = __builtin_amdgcn_readfirstlane(sarr0) != 0;
-    const float* sbase0 = sodd ? p.sv1 : p.sv0;
-    const float* sbase1 = sodd ? p.sv3 : p.sv2;
+    const float* sbase0 = (p.ablate & 1) ? p.sv0 : (sodd ? p.sv1 : p.sv0);
+    const float* sbase1 = (p.ablate & 1) ? p.sv0 : (sodd ? p.sv3 : p.sv2);
     const float* sbase2 = sodd ? p.dy : p.y;
     const int sld2 = sodd ? p.lddy : p.ldy;
     // DEP_BWD_NT=1: the service waves' one-touch streams carry the non-temporal hint, so that they do not displace the
@@ -168,6 +175,11 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
         const int t = T - 1 - k;
         if (!svalid || t < 0) return zero4();
         const size_t row = (size_t)sb * T + t;
+        if (p.sv16 && (i == 0 || (i == 1 && !sodd))) {     // four 16-bit values = 8 bytes; decoded when they go into the ring (svc_put)
+            const float2 w = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned short*>(i == 0 ? sbase0 : sbase1) + row * H + scol);
+            f32x4 r4 = {w.x, w.y, 0.f, 0.f};
+            return r4;
+        }
         if (i == 0) return ldnt(sbase0 + row * H + scol);
         if (i == 1) return ldnt(sbase1 + row * H + scol);
         if (sodd) return sbase2 ? ldnt(sbase2 + row * sld2 + scol) : zero4();
@@ -187,11 +199,19 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
             if (d < n) {
                 float* dst = ibuf + ((k0 + d) % KBX) * 6 * SARR + sr * SROW + sp * 4;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(dst + (sarr0 + 2 * i) * SARR) = sreg[d][i];
+                for (int i = 0; i < 3; ++i) {
+                    f32x4 v = sreg[d][i];
+                    if (p.sv16 && (i == 0 || (i == 1 && !sodd))) {
+                        const unsigned w0 = __float_as_uint(v[0]), w1 = __float_as_uint(v[1]);
+                        const float2 a = i == 0 ? unpack_unorm2(w0) : unpack_snorm2(w0), b = i == 0 ? unpack_unorm2(w1) : unpack_snorm2(w1);
+                        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+                    }
+                    *reinterpret_cast<f32x4*>(dst + (sarr0 + 2 * i) * SARR) = v;
+                }
             }
     };
     auto svc_flush = [&](int k0, int k1) {            // gate gradients of steps k0 .. k1-1: obuf -> dgi (dr, dz, dn), dghn (dn * r)
-        if (!svalid) return;
+        if (!svalid || (p.ablate & 2)) return;
         for (int k = k0 < 0 ? 0 : k0; k < k1; ++k) {
             const size_t row = (size_t)sb * T + (T - 1 - k);
             const float* o = obuf + (k % OSL) * 4 * SARR + sr * SROW + sp * 4;
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     // t_even holds bf16hi(x[t_even]) | bf16hi(x[t_even+1]) << 16 per column, row t_even + 1 the residual (lo) pairs -- exactly the
     // (hi, lo) the GEMM's split4 would form (same v_cvt_pk_bf16_f32 roundings), so the contractions' bits do not change.
     auto svc_flush_pk = [&](int k0, int k1) {         // complete step pairs in [k0, k1): both even
-        if (!svalid) return;
+        if (!svalid || (p.ablate & 2)) return;
         for (int ka = k0 < 0 ? 0 : k0; ka + 1 < k1; ka += 2) {
             const size_t row = (size_t)sb * T + (T - 2 - ka);                    // the even row of the pair
             const float* oo = obuf + (ka % OSL) * 4 * SARR + sr * SROW + sp * 4;        // step ka   = row t_even + 1
@@ -436,6 +456,7 @@ struct F2 {
     int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
     long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
     const unsigned* only_if; // run only if this word is set (fallback behind an exclusive forward kernel), or nullptr
+    int sv16;                // saved gates r, z, n written as 16-bit fixed point
 };
 
 template <int KCH, bool SPLIT>      // SPLIT: 3-term bf16 split of the recurrent product, as in gru_fwd_cluster16
@@ -585,7 +606,12 @@ __global__ __launch_bounds__(CT) void gru_fwd_cluster_r1(F2 p) {
             }
             if (p.sv0) {
                 const size_t so = row * H + col;
-                st2(p.sv0 + so, r); st2(p.sv1 + so, z); st2(p.sv2 + so, n); st2(p.sv3 + so, hn);
+                if (p.sv16) {
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.sv0) + so) = pack_unorm2(r.x, r.y);
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.sv1) + so) = pack_unorm2(z.x, z.y);
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.sv2) + so) = pack_snorm2(n.x, n.y);
+                } else { st2(p.sv0 + so, r); st2(p.sv1 + so, z); st2(p.sv2 + so, n); }
+                st2(p.sv3 + so, hn);
             }
         }
         if (more) {
@@ -742,7 +768,7 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
     p.nofast = nofast_env();
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
     p.trace = trace_env() ? (long long*)(hdr_base(xbuf, a.hdr_slot) + TRACE_OFF) : nullptr;
-    p.only_if = a.only_if;
+    p.only_if = a.only_if; p.sv16 = a.training ? a.sv16 : 0;
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream, a.only_if == nullptr);      // a conditional fallback launch is not a sweep of the step
     // Ask for more than half of the CU's 160 KiB LDS: the dispatcher can then never co-locate two members on one
     // CU (they would share the four matrix pipes and stretch every step of BOTH clusters).
@@ -798,7 +824,8 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.dpooled = a.dpooled; p.pool_scale = a.pool_scale; p.dh_n = a.dh_n;
     p.sv0 = a.sv0; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
     p.dgi = a.dgi; p.lddg = a.lddg ? a.lddg : 3 * a.H; p.dghn = a.dghn; p.lddghn = a.lddghn ? a.lddghn : a.H; p.dbpart = a.dbpart;
-    p.dgpk = a.dg_pk;
+    p.dgpk = a.dg_pk; p.sv16 = a.sv16;
+    { static int ab = -1; if (ab < 0) { const char* v = getenv("DEP_BWD_ABLATE"); ab = v ? atoi(v) : 0; } p.ablate = ab; }
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
     const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 256);

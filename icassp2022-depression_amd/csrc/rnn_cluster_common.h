@@ -80,6 +80,18 @@ __device__ __forceinline__ unsigned split_word(float x) {
     return (hi << 16) | lo;
 }
 
+// 16-bit fixed-point storage of the saved GRU gates (round 4, dep_sweep_args.sv16): r, z in (0, 1) as unorm16 (round(x * 65535),
+// |error| <= 7.6e-6), n in (-1, 1) as snorm16 (round(x * 32767), |error| <= 1.5e-5) -- V_CVT_PKNORM_{U,I}16_F32.  Same order as
+// the split products' own error; halves 6H of the 16H saved-gate bytes a step writes in the forward and reads in the backward.
+__device__ __forceinline__ unsigned pack_unorm2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(a, b)); }
+__device__ __forceinline__ unsigned pack_snorm2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_i16(a, b)); }
+__device__ __forceinline__ float2 unpack_unorm2(unsigned w) {
+    return make_float2((float)(w & 0xffffu) * (1.0f / 65535.0f), (float)(w >> 16) * (1.0f / 65535.0f));
+}
+__device__ __forceinline__ float2 unpack_snorm2(unsigned w) {
+    return make_float2((float)((int)(w << 16) >> 16) * (1.0f / 32767.0f), (float)((int)w >> 16) * (1.0f / 32767.0f));
+}
+
 // two adjacent values -> packed bf16 pairs: hi = (bf16(x1) << 16 | bf16(x0)), lo likewise for the residuals
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
     typedef float f2v __attribute__((ext_vector_type(2)));

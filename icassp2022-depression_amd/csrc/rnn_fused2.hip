@@ -48,6 +48,7 @@ struct FF {
     long long* trace;
     unsigned* soft;          // fallback flag (rnn_cluster_common.h), or nullptr: a failed hello then raises the status word
     int force_soft;          // test hook (DEP_FORCE_SOFT_FALLBACK=1): behave as if the hello had timed out
+    int sv16;                // saved gates r, z, n written as 16-bit fixed point (8-byte stores), hn / h / dropout(h) as fp32
 };
 
 #define FSTAMP(slot) do { if (TRACE && trl && s >= 100 && s < 104) trl[(s - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -152,7 +153,18 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             const int t = l0 ? s : s - 2;
             float* base = l0 ? p.y0 : p.y1;
             const unsigned slot = l0 ? dslot0[k] : k;
-            if (on) *reinterpret_cast<f32x4*>(base + (size_t)slot * p.ostride + (so + (unsigned)t * FH)) = ld4(obuf + a * OARR + su * OROW + sqd * 4);
+            if (on) {
+                const f32x4 v = ld4(obuf + a * OARR + su * OROW + sqd * 4);
+                float* arr = base + (size_t)slot * p.ostride;
+                if (p.sv16 && k >= 1 && k <= 3) {             // r, z: unorm16 ; n: snorm16 -- four values = one 8-byte store
+                    uint2 q;
+                    if (k == 3) { q.x = pack_snorm2(v[0], v[1]); q.y = pack_snorm2(v[2], v[3]); }
+                    else { q.x = pack_unorm2(v[0], v[1]); q.y = pack_unorm2(v[2], v[3]); }
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(arr) + (so + (unsigned)t * FH)) = q;
+                } else {
+                    *reinterpret_cast<f32x4*>(arr + (so + (unsigned)t * FH)) = v;
+                }
+            }
         }
     };
     // inter-layer dropout: the mask of step s+1 is drawn while step s waits for the other members
@@ -398,6 +410,7 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
     p.soft = a.soft_fallback ? (unsigned*)xbuf + 1 : nullptr;
+    p.sv16 = a.training ? a.sv16 : 0;
     { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; } p.force_soft = fs; }
     static bool attr = false;
     if (!attr) {
