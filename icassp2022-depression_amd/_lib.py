@@ -9,7 +9,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libdep_rnn.so')
+LIB_PATH = os.environ.get('DEP_LIB_PATH') or os.path.join(HERE, 'libdep_rnn.so')       # DEP_LIB_PATH: A/B runs against another build of the same ABI
 
 CELL_GRU, CELL_LSTM = 0, 1
 POOL_NONE, POOL_MEAN, POOL_SUM = 0, 1, 2

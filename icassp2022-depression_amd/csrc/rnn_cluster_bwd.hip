@@ -35,9 +35,7 @@ struct P2 {
     int trall_off;           // debug: LDS offset (32-bit words) of the per-step stamp array
     int ntstream;            // DEP_BWD_NT=1: non-temporal hint on the service waves' HBM streams
     int wflags;              // DEP_BWD_WFLAGS: every compute wave raises its OWN epoch flag once its own payload stores are acknowledged (no workgroup barrier in front of the flag; the pollers watch 4 NC words)
-    int sv16;                // saved gates r, z, n are 16-bit fixed point (rnn_cluster_common.h)
     int dgpk;                // round 4: write the gate gradients as the PK image the bf16x3 GEMMs read without converting (gemm_bf16x3.hip FMT_PK): rows (t even, t+1) of an utterance hold the (hi, lo) bf16 pairs of both steps; burst kernel, 4H-wide layout, T even
-    int ablate;              // timing experiment only (DEP_BWD_ABLATE, WRONG results): 1 = the four saved-gate arrays all read r's rows (HBM reads 24H -> 12H per row, data stays non-zero), 2 = no gate-gradient write-out
     int xhalf;               // experiment (DEP_BWD_XHALF=1): the sweep's workgroups on XCDs 0-3 only, two per CU; the launch has twice the blocks and those of XCDs 4-7 leave at once
 };
 
@@ -67,7 +65,10 @@ constexpr int TRACE_F = 2048, IBUF_F = 2304;         // float offsets into the w
 constexpr int obuf_slots(int KB) { return KB == 4 ? KB + 2 : KB + 1; }      // KB + 1 does for fp32 rows; the PK flush (KB = 4 only) works on step PAIRS and may lag one step
 constexpr size_t burst_lds_bytes(int KB) { return (size_t)(IBUF_F + KB * 6 * SARR + obuf_slots(KB) * 4 * SARR) * sizeof(float); }
 
-template <int NTW, bool SPLIT, int KB>      // output tiles per wave = H/64
+// SV16: the saved gates r, z, n are 16-bit fixed point (rnn_cluster_common.h).  A template parameter, not a kernel argument: as a
+// run-time switch the two load widths met in copies of the loaded registers and the service waves waited for every load they had
+// just issued (both settings 5-20 % slower than the kernel without the switch, profiles/r04_ab_pairs.txt).
+template <int NTW, bool SPLIT, int KB, bool SV16 = false>      // output tiles per wave = H/64
 __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1(P2 p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 96, KCB = KS / 16, LDG = KS + LPAD;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
         if (valid && t >= 0) {
             const size_t row = (size_t)b * T + t;
             const size_t so = row * H + col;
-            if (p.sv16) {
+            if constexpr (SV16) {
                 s.r = unpack_unorm2(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(p.sv0) + so));
                 s.z = unpack_unorm2(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(p.sv1) + so));
                 s.n = unpack_snorm2(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(p.sv2) + so));
@@ -162,56 +163,72 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     // that the base pointers are selected in SGPRs (a per-lane choice makes hipcc index the kernel arguments in memory and
     // wait for that pointer load -- vmcnt(0) -- in front of every data load)
     const bool sodd = __builtin_amdgcn_readfirstlane(sarr0) != 0;
-    const float* sbase0 = (p.ablate & 1) ? p.sv0 : (sodd ? p.sv1 : p.sv0);
-    const float* sbase1 = (p.ablate & 1) ? p.sv0 : (sodd ? p.sv3 : p.sv2);
-    const float* sbase2 = sodd ? p.dy : p.y;
+    // SV16: the wave pair 4, 5 (sodd = 0) streams the three fp32 arrays hn, h_{t-1}, dy (ring arrays 3, 4, 5), the pair 6, 7 the three
+    // 16-bit arrays r, z, n (ring arrays 0, 1, 2; 8-byte pieces, decoded when they go into the ring): one load width per wave
+    const float* sbase0 = SV16 ? (sodd ? p.sv0 : p.sv3) : (sodd ? p.sv1 : p.sv0);
+    const float* sbase1 = SV16 ? (sodd ? p.sv1 : p.y) : (sodd ? p.sv3 : p.sv2);
+    const float* sbase2 = SV16 ? (sodd ? p.sv2 : p.dy) : (sodd ? p.dy : p.y);
     const int sld2 = sodd ? p.lddy : p.ldy;
     // DEP_BWD_NT=1: the service waves' one-touch streams carry the non-temporal hint, so that they do not displace the
     // exchange payload (rewritten every other step) from this XCD's L2 and turn it into HBM write-backs
     const bool snt = p.ntstream != 0;
     auto ldnt = [&](const float* q) -> f32x4 { return snt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : ld4(q); };
     auto stnt = [&](float* q, f32x4 v) { if (snt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q)); else *reinterpret_cast<f32x4*>(q) = v; };
-    auto svc_load1 = [&](int k, int i) -> f32x4 {     // input array a = sarr0 + 2 i of step k
+    // W16 (a std::bool_constant): this wave streams the 16-bit arrays
+    auto svc_load1 = [&](auto W16, int k, int i) -> f32x4 {     // input i of this wave for step k
         const int t = T - 1 - k;
         if (!svalid || t < 0) return zero4();
         const size_t row = (size_t)sb * T + t;
-        if (p.sv16 && (i == 0 || (i == 1 && !sodd))) {     // four 16-bit values = 8 bytes; decoded when they go into the ring (svc_put)
-            const float2 w = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned short*>(i == 0 ? sbase0 : sbase1) + row * H + scol);
-            f32x4 r4 = {w.x, w.y, 0.f, 0.f};
-            return r4;
+        if constexpr (SV16) {
+            if constexpr (decltype(W16)::value) {             // four 16-bit values = 8 bytes
+                const float* base = i == 0 ? sbase0 : (i == 1 ? sbase1 : sbase2);
+                const float2 w = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned short*>(base) + row * H + scol);
+                const f32x4 r4 = {w.x, w.y, 0.f, 0.f};
+                return r4;
+            } else {
+                if (i == 0) return ldnt(sbase0 + row * H + scol);
+                if (i == 1) return t > 0 ? ldnt(sbase1 + (row - 1) * p.ldy + scol) : zero4();
+                return sbase2 ? ldnt(sbase2 + row * p.lddy + scol) : zero4();
+            }
+        } else {
+            if (i == 0) return ldnt(sbase0 + row * H + scol);
+            if (i == 1) return ldnt(sbase1 + row * H + scol);
+            if (sodd) return sbase2 ? ldnt(sbase2 + row * sld2 + scol) : zero4();
+            return t > 0 ? ldnt(sbase2 + (row - 1) * sld2 + scol) : zero4();
         }
-        if (i == 0) return ldnt(sbase0 + row * H + scol);
-        if (i == 1) return ldnt(sbase1 + row * H + scol);
-        if (sodd) return sbase2 ? ldnt(sbase2 + row * sld2 + scol) : zero4();
-        return t > 0 ? ldnt(sbase2 + (row - 1) * sld2 + scol) : zero4();
     };
-    auto svc_issue = [&](int k0, int n) {             // inputs of steps k0 .. k0+n-1 -> registers
+    auto svc_issue = [&](auto W16, int k0, int n) {   // inputs of steps k0 .. k0+n-1 -> registers
 #pragma unroll
         for (int d = 0; d < KBX; ++d)
             if (d < n) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) sreg[d][i] = svc_load1(k0 + d, i);
+                for (int i = 0; i < 3; ++i) sreg[d][i] = svc_load1(W16, k0 + d, i);
             }
     };
-    auto svc_put = [&](int k0, int n) {               // registers -> ibuf slots of steps k0 .. k0+n-1
+    auto svc_put = [&](auto W16, int k0, int n) {     // registers -> ibuf slots of steps k0 .. k0+n-1
 #pragma unroll
         for (int d = 0; d < KBX; ++d)
             if (d < n) {
                 float* dst = ibuf + ((k0 + d) % KBX) * 6 * SARR + sr * SROW + sp * 4;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    f32x4 v = sreg[d][i];
-                    if (p.sv16 && (i == 0 || (i == 1 && !sodd))) {
-                        const unsigned w0 = __float_as_uint(v[0]), w1 = __float_as_uint(v[1]);
-                        const float2 a = i == 0 ? unpack_unorm2(w0) : unpack_snorm2(w0), b = i == 0 ? unpack_unorm2(w1) : unpack_snorm2(w1);
-                        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+                    if constexpr (SV16) {
+                        if constexpr (decltype(W16)::value) {
+                            const unsigned w0 = __float_as_uint(sreg[d][i][0]), w1 = __float_as_uint(sreg[d][i][1]);
+                            const float2 a = i < 2 ? unpack_unorm2(w0) : unpack_snorm2(w0), b = i < 2 ? unpack_unorm2(w1) : unpack_snorm2(w1);
+                            const f32x4 v = {a.x, a.y, b.x, b.y};
+                            *reinterpret_cast<f32x4*>(dst + i * SARR) = v;
+                        } else {
+                            *reinterpret_cast<f32x4*>(dst + (3 + i) * SARR) = sreg[d][i];
+                        }
+                    } else {
+                        *reinterpret_cast<f32x4*>(dst + (sarr0 + 2 * i) * SARR) = sreg[d][i];
                     }
-                    *reinterpret_cast<f32x4*>(dst + (sarr0 + 2 * i) * SARR) = v;
                 }
             }
     };
     auto svc_flush = [&](int k0, int k1) {            // gate gradients of steps k0 .. k1-1: obuf -> dgi (dr, dz, dn), dghn (dn * r)
-        if (!svalid || (p.ablate & 2)) return;
+        if (!svalid) return;
         for (int k = k0 < 0 ? 0 : k0; k < k1; ++k) {
             const size_t row = (size_t)sb * T + (T - 1 - k);
             const float* o = obuf + (k % OSL) * 4 * SARR + sr * SROW + sp * 4;
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     // t_even holds bf16hi(x[t_even]) | bf16hi(x[t_even+1]) << 16 per column, row t_even + 1 the residual (lo) pairs -- exactly the
     // (hi, lo) the GEMM's split4 would form (same v_cvt_pk_bf16_f32 roundings), so the contractions' bits do not change.
     auto svc_flush_pk = [&](int k0, int k1) {         // complete step pairs in [k0, k1): both even
-        if (!svalid || (p.ablate & 2)) return;
+        if (!svalid) return;
         for (int ka = k0 < 0 ? 0 : k0; ka + 1 < k1; ka += 2) {
             const size_t row = (size_t)sb * T + (T - 2 - ka);                    // the even row of the pair
             const float* oo = obuf + (ka % OSL) * 4 * SARR + sr * SROW + sp * 4;        // step ka   = row t_even + 1
@@ -244,10 +261,11 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
         }
     };
     if constexpr (BURST) {
-        if (svc) {
+        // the service waves' whole life (W16: this wave pair streams the 16-bit arrays)
+        auto svc_life = [&](auto W16) {
             // the service waves' whole life: same barrier sequence as the compute waves' loop below (two per step, one in the last)
-            svc_issue(0, KBX); svc_put(0, KBX);       // steps 0 .. KB-1 straight into the ring
-            svc_issue(KBX, phi);                      // steps KB .. KB+phi-1: written at step phi-1, before the first dirty step (k = phi)
+            svc_issue(W16, 0, KBX); svc_put(W16, 0, KBX);       // steps 0 .. KB-1 straight into the ring
+            svc_issue(W16, KBX, phi);                      // steps KB .. KB+phi-1: written at step phi-1, before the first dirty step (k = phi)
             __syncthreads();
             for (int k = 0; k < T; ++k) {
                 const int jj = (k + KBX - phi) % KBX;                  // jj == 0: this tile's dirty step
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                     // ahead of the compute waves -- nothing holds them after barrier #2 -- so the burst starts during the
                     // previous step's poll; holding it back until the compute waves reach the dirty step's gate phase
                     // measured the same launch time: the burst occupies the CU's memory pipeline for ~1.3 steps either way.)
-                    svc_issue(k + KBX, KBX);
+                    svc_issue(W16, k + KBX, KBX);
                     if (trs) p.trace[32 + (k - 100) * 4 + 1] = (long long)__builtin_readcyclecounter();
                     if (p.dgpk) svc_flush_pk(k - KBX - (phi & 1), k - (phi & 1));      // whole pairs: one step later for the tiles with an odd phase
                     else svc_flush(k - KBX, k);
@@ -270,8 +288,8 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                 if (jj == KBX - 1) {
                     // last step of the burst: the ring slots of steps last .. k are consumed; the registers (requested at step
                     // `last', KB-1 steps ago) become steps last+KB .. k+KB
-                    if (last >= 0) svc_put(last + KBX, KBX);
-                    else svc_put(KBX, phi);
+                    if (last >= 0) svc_put(W16, last + KBX, KBX);
+                    else svc_put(W16, KBX, phi);
                 }
                 if (k == T - 1) break;
                 if (!p.wflags) bar_lds();            // #2 (the compute waves' drain barrier; absent with per-wave flags)
@@ -279,6 +297,10 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
             const int jl2 = (T - 1 + KBX - phi) % KBX;
             if (p.dgpk) svc_flush_pk(T - 1 - jl2 - (phi & 1), T);      // T is even: the last pair is complete
             else svc_flush(T - 1 - jl2, T);           // the gate gradients since the last dirty step
+        };
+        if (svc) {
+            if constexpr (SV16) { if (sodd) svc_life(std::true_type{}); else svc_life(std::false_type{}); }
+            else svc_life(std::false_type{});
             return;
         }
         __syncthreads();
@@ -824,8 +846,8 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.dpooled = a.dpooled; p.pool_scale = a.pool_scale; p.dh_n = a.dh_n;
     p.sv0 = a.sv0; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
     p.dgi = a.dgi; p.lddg = a.lddg ? a.lddg : 3 * a.H; p.dghn = a.dghn; p.lddghn = a.lddghn ? a.lddghn : a.H; p.dbpart = a.dbpart;
-    p.dgpk = a.dg_pk; p.sv16 = a.sv16;
-    { static int ab = -1; if (ab < 0) { const char* v = getenv("DEP_BWD_ABLATE"); ab = v ? atoi(v) : 0; } p.ablate = ab; }
+    p.dgpk = a.dg_pk;
+    DEP_CHECK_ARG(!a.sv16 || a.split);               // the 16-bit saved gates exist in split-precision mode only
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
     const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 256);
@@ -850,12 +872,14 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.trall_off = (int)((lds - 2048) / 4);
     static bool attr_b = false;
     if (!attr_b) {
-#define DEP_BWD_ATTR(N, S, V) (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<N, S, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((V ? burst_lds_bytes(V) > EXCLUSIVE_LDS ? burst_lds_bytes(V) : EXCLUSIVE_LDS : EXCLUSIVE_LDS) + 2048))
+#define DEP_BWD_ATTR1(N, S, V, X) (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<N, S, V, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((V ? burst_lds_bytes(V) > EXCLUSIVE_LDS ? burst_lds_bytes(V) : EXCLUSIVE_LDS : EXCLUSIVE_LDS) + 2048))
+#define DEP_BWD_ATTR(N, S, V) do { DEP_BWD_ATTR1(N, S, V, false); if (S) DEP_BWD_ATTR1(N, true, V, true); } while (0)
         DEP_BWD_ATTR(1, false, 0); DEP_BWD_ATTR(1, true, 0); DEP_BWD_ATTR(1, false, 4); DEP_BWD_ATTR(1, true, 4); DEP_BWD_ATTR(1, false, 6); DEP_BWD_ATTR(1, true, 6);
         DEP_BWD_ATTR(2, false, 0); DEP_BWD_ATTR(4, false, 0); DEP_BWD_ATTR(2, true, 0); DEP_BWD_ATTR(4, true, 0);
         DEP_BWD_ATTR(2, false, 4); DEP_BWD_ATTR(4, false, 4); DEP_BWD_ATTR(2, true, 4); DEP_BWD_ATTR(4, true, 4);
         DEP_BWD_ATTR(2, false, 6); DEP_BWD_ATTR(4, false, 6); DEP_BWD_ATTR(2, true, 6); DEP_BWD_ATTR(4, true, 6);
         DEP_BWD_ATTR(8, false, 0); DEP_BWD_ATTR(8, true, 0);
+#undef DEP_BWD_ATTR1
 #undef DEP_BWD_ATTR
         attr_b = true;
     }
@@ -869,19 +893,22 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         dim3 grid(NC * p.nbtp * (p.xhalf ? 2 : 1));
         const dim3 block(kb ? CT + SVC_THREADS : CT);
-#define DEP_BWD_LAUNCH(N, S)                                                                                              \
-        do { if (kb == 4) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 4>), grid, block, lds, a.stream, p);               \
-             else if (kb == 6) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 6>), grid, block, lds, a.stream, p);          \
-             else hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 0>), grid, block, lds, a.stream, p); } while (0)
+#define DEP_BWD_LAUNCH1(N, S, X)                                                                                          \
+        do { if (kb == 4) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 4, X>), grid, block, lds, a.stream, p);            \
+             else if (kb == 6) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 6, X>), grid, block, lds, a.stream, p);       \
+             else hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 0, X>), grid, block, lds, a.stream, p); } while (0)
+#define DEP_BWD_LAUNCH(N, S) do { if (S && a.sv16) DEP_BWD_LAUNCH1(N, true, true); else DEP_BWD_LAUNCH1(N, S, false); } while (0)
         switch (a.H) {                                // NTW = H / 64
             case 64: if (a.split) DEP_BWD_LAUNCH(1, true); else DEP_BWD_LAUNCH(1, false); break;
             case 128: if (a.split) DEP_BWD_LAUNCH(2, true); else DEP_BWD_LAUNCH(2, false); break;
             case 256: if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false); break;
             default:                                  // 512: round-1 schedule only (kb == 0)
-                if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<8, true, 0>), grid, block, lds, a.stream, p);
+                if (a.split && a.sv16) hipLaunchKernelGGL((gru_bwd_cluster_r1<8, true, 0, true>), grid, block, lds, a.stream, p);
+                else if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<8, true, 0>), grid, block, lds, a.stream, p);
                 else hipLaunchKernelGGL((gru_bwd_cluster_r1<8, false, 0>), grid, block, lds, a.stream, p);
                 break;
         }
+#undef DEP_BWD_LAUNCH1
 #undef DEP_BWD_LAUNCH
         DEP_CHECK_LAUNCH();
     }

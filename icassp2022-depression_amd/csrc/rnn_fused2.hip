@@ -48,7 +48,6 @@ struct FF {
     long long* trace;
     unsigned* soft;          // fallback flag (rnn_cluster_common.h), or nullptr: a failed hello then raises the status word
     int force_soft;          // test hook (DEP_FORCE_SOFT_FALLBACK=1): behave as if the hello had timed out
-    int sv16;                // saved gates r, z, n written as 16-bit fixed point (8-byte stores), hn / h / dropout(h) as fp32
 };
 
 #define FSTAMP(slot) do { if (TRACE && trl && s >= 100 && s < 104) trl[(s - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -59,7 +58,9 @@ __device__ __forceinline__ float2 add2(float2 a, float2 b) { return make_float2(
 // unit pair, LDS / payload offsets) is therefore RE-DERIVED inside the loop from a laundered copy of threadIdx.x (the
 // compiler would otherwise hoist ~40 loop-invariant address registers of all three roles out of the loop and spill -- and a
 // scratch reload in the streaming waves waits on vmcnt, i.e. on their outstanding HBM stores: 10k cycles per step measured).
-template <bool DROP, bool TRACE>
+// SV16 (saved gates r, z, n as 16-bit fixed point) is a template parameter: as a run-time switch the write-out's two store widths
+// cost the launch 4 % (profiles/r04_ab_pairs.txt).
+template <bool DROP, bool TRACE, bool SV16>
 __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T;
@@ -154,15 +155,14 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             float* base = l0 ? p.y0 : p.y1;
             const unsigned slot = l0 ? dslot0[k] : k;
             if (on) {
-                const f32x4 v = ld4(obuf + a * OARR + su * OROW + sqd * 4);
                 float* arr = base + (size_t)slot * p.ostride;
-                if (p.sv16 && k >= 1 && k <= 3) {             // r, z: unorm16 ; n: snorm16 -- four values = one 8-byte store
-                    uint2 q;
-                    if (k == 3) { q.x = pack_snorm2(v[0], v[1]); q.y = pack_snorm2(v[2], v[3]); }
-                    else { q.x = pack_unorm2(v[0], v[1]); q.y = pack_unorm2(v[2], v[3]); }
-                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(arr) + (so + (unsigned)t * FH)) = q;
+                if (SV16 && k >= 1 && k <= 3) {
+                    // r, z (unorm16), n (snorm16): the gate threads left them PACKED in obuf (two units per word, 16 words per
+                    // utterance row) -- four values = one 8-byte copy, no arithmetic in this group (it is the busiest one)
+                    const float2 q = ld2(obuf + a * OARR + su * OROW + sqd * 2);
+                    *reinterpret_cast<float2*>(reinterpret_cast<unsigned short*>(arr) + (so + (unsigned)t * FH)) = q;
                 } else {
-                    *reinterpret_cast<f32x4*>(arr + (so + (unsigned)t * FH)) = v;
+                    *reinterpret_cast<f32x4*>(arr + (so + (unsigned)t * FH)) = ld4(obuf + a * OARR + su * OROW + sqd * 4);
                 }
             }
         }
@@ -300,7 +300,14 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                 }
             }
             float* ob = obuf + grp * (6 * OARR) + j * OROW + ul;            // results for the streaming waves
-            st2(ob, h); st2(ob + OARR, r); st2(ob + 2 * OARR, z); st2(ob + 3 * OARR, n); st2(ob + 4 * OARR, hn);
+            st2(ob, h); st2(ob + 4 * OARR, hn);
+            if constexpr (SV16) {                         // 16-bit fixed point, one word per unit pair (rnn_cluster_common.h)
+                float* o16 = obuf + grp * (6 * OARR) + j * OROW + (ul >> 1);
+                o16[OARR] = __uint_as_float(pack_unorm2(r.x, r.y)); o16[2 * OARR] = __uint_as_float(pack_unorm2(z.x, z.y));
+                o16[3 * OARR] = __uint_as_float(pack_snorm2(n.x, n.y));
+            } else {
+                st2(ob + OARR, r); st2(ob + 2 * OARR, z); st2(ob + 3 * OARR, n);
+            }
             if (DROP && grp == 0) st2(ob + 5 * OARR, hd);
             // next step's dropout mask: Philox work in the shadow of the payload stores' acknowledgement (the drain below)
             if (DROP && grp == 0 && s + 1 < T) { const float2 mn = draw(tv, s + 1); st1[0] = mn.x; st1[1] = mn.y; }
@@ -410,14 +417,14 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
     p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
     p.soft = a.soft_fallback ? (unsigned*)xbuf + 1 : nullptr;
-    p.sv16 = a.training ? a.sv16 : 0;
+    const bool sv16 = a.training && a.sv16;
     { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; } p.force_soft = fs; }
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+#define F2_ATTR(D, TR, X) (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<D, TR, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES)
+        F2_ATTR(true, false, false); F2_ATTR(false, false, false); F2_ATTR(true, true, false); F2_ATTR(false, true, false);
+        F2_ATTR(true, false, true); F2_ATTR(false, false, true); F2_ATTR(true, true, true); F2_ATTR(false, true, true);
+#undef F2_ATTR
         attr = true;
     }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
@@ -427,13 +434,14 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, 0, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(FNC * p.nbtp), blk(FTHREADS);
+#define F2_LAUNCH(D, TR) do { if (sv16) hipLaunchKernelGGL((gru2_fwd_fused<D, TR, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
+                              else hipLaunchKernelGGL((gru2_fwd_fused<D, TR, false>), grid, blk, F_LDS_BYTES, a.stream, p); } while (0)
         if (p.trace) {                                    // DEP_TRACE=1: the stamped variant (tools/trace_fused.py)
-            if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
-            else hipLaunchKernelGGL((gru2_fwd_fused<false, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+            if (drop) F2_LAUNCH(true, true); else F2_LAUNCH(false, true);
         } else {
-            if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, false>), grid, blk, F_LDS_BYTES, a.stream, p);
-            else hipLaunchKernelGGL((gru2_fwd_fused<false, false>), grid, blk, F_LDS_BYTES, a.stream, p);
+            if (drop) F2_LAUNCH(true, false); else F2_LAUNCH(false, false);
         }
+#undef F2_LAUNCH
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
