@@ -33,7 +33,8 @@ struct P2 {
     int nofast;              // DEP_CLUSTER_NOFAST=1: always use the write-through (placement-agnostic) stores
     long long* trace;        // debug: s_memtime stamps of workgroup 0 (DEP_TRACE=1), else nullptr
     int trall_off;           // debug: LDS offset (32-bit words) of the per-step stamp array
-    int ntstream;            // DEP_BWD_NT=1: non-temporal hint on the service waves' HBM streams
+    int ntstream;            // non-temporal gate-gradient write-out (default on; DEP_BWD_NT=0: plain stores)
+    int ntload;              // non-temporal one-touch input streams (default on; DEP_BWD_NTLD=0: plain loads)
     int wflags;              // DEP_BWD_WFLAGS: every compute wave raises its OWN epoch flag once its own payload stores are acknowledged (no workgroup barrier in front of the flag; the pollers watch 4 NC words)
     int dgpk;                // round 4: write the gate gradients as the PK image the bf16x3 GEMMs read without converting (gemm_bf16x3.hip FMT_PK): rows (t even, t+1) of an utterance hold the (hi, lo) bf16 pairs of both steps; burst kernel, 4H-wide layout, T even
     int xhalf;               // experiment (DEP_BWD_XHALF=1): the sweep's workgroups on XCDs 0-3 only, two per CU; the launch has twice the blocks and those of XCDs 4-7 leave at once
@@ -171,38 +172,87 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     const int sld2 = sodd ? p.lddy : p.ldy;
     // DEP_BWD_NT=1: the service waves' one-touch streams carry the non-temporal hint, so that they do not displace the
     // exchange payload (rewritten every other step) from this XCD's L2 and turn it into HBM write-backs
+    // Round 4: the gate-gradient write-out goes out NON-TEMPORAL (buffer stores with the nt bit).  tools/micro/l2wb.hip + PMC:
+    // one-touch stores that allocate in L2 are what evicts the exchange payload (1 MB per XCD, rewritten in place every other step)
+    // before its next rewrite -- 0.8 GB of write-backs per launch; with nt stores the payload stays.  (Round 3's DEP_BWD_NT went
+    // through __builtin_nontemporal_store, which hipcc compiled to PLAIN stores -- no nt bit in the ISA -- so it measured nothing.)
     const bool snt = p.ntstream != 0;
-    auto ldnt = [&](const float* q) -> f32x4 { return snt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : ld4(q); };
-    auto stnt = [&](float* q, f32x4 v) { if (snt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q)); else *reinterpret_cast<f32x4*>(q) = v; };
+    // (resources are TILE-relative -- base = the tile's first row, extent = its 16 utterances -- so 32-bit offsets always suffice)
+    const size_t trow0 = (size_t)(p.b0 + bt * BT) * T;
+    float* const dgi_t = p.dgi + trow0 * p.lddg; float* const dghn_t = p.dghn + trow0 * p.lddghn;
+    __amdgpu_buffer_rsrc_t rs_dgi = __builtin_amdgcn_make_buffer_rsrc((void*)dgi_t, 0, (unsigned)((size_t)BT * T * p.lddg * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_dghn = __builtin_amdgcn_make_buffer_rsrc((void*)dghn_t, 0, (unsigned)((size_t)BT * T * p.lddghn * 4), 0x00020000);
+    // q inside the tile's rows of the array of `rs` (tile base `base`): 16-byte store, nt when enabled
+    auto stnt2 = [&](__amdgpu_buffer_rsrc_t rs, const float* base, float* q, f32x4 v) {
+        if (snt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (unsigned)((const char*)q - (const char*)base), 0, 2 /* nt */);
+        else *reinterpret_cast<f32x4*>(q) = v;
+    };
+    // ... and so do the service waves' one-touch READS (the saved gates, h_{t-1}, dy): p.ntload (DEP_BWD_NTLD, default on).  NT is a
+    // compile-time tag of the service waves' code (svc_life below), not a select per load: two load forms meeting in one register
+    // make hipcc wait for every load it has just issued.
+    const int mld = H > p.ldy ? (H > p.lddy ? H : p.lddy) : (p.ldy > p.lddy ? p.ldy : p.lddy);
+    const unsigned span = (unsigned)((size_t)(BT * T + 1) * mld * 4);        // bounds the tile's rows of every input array (+ the h_{t-1} row in front)
+    // bases one row in front of the tile's first row (h_{t-1} of t = 0 is never read; the offset stays non-negative)
+    // (the 16-bit arrays of the SV16 wave pair have 2-byte elements: their rows are H / 2 floats apart)
+    const bool w16 = SV16 && sodd;
+    const float* const in0_t = sbase0 ? (w16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(sbase0) + trow0 * H) : sbase0 + trow0 * H) : nullptr;
+    const float* const in1_t = sbase1 ? (w16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(sbase1) + trow0 * H)
+                                             : sbase1 + trow0 * (SV16 ? p.ldy : H)) : nullptr;
+    const float* const in2_t = sbase2 ? (w16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(sbase2) + trow0 * H)
+                                             : sbase2 + trow0 * (SV16 ? p.lddy : sld2)) : nullptr;
+    __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc((void*)in0_t, 0, span, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)in1_t, 0, span, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void*)in2_t, 0, span, 0x00020000);
+    auto ldnt = [&](auto NT, int which, const float* q) -> f32x4 {      // 16 bytes at q, inside input array `which` of this wave
+        if constexpr (decltype(NT)::value) {
+            const float* base = which == 0 ? in0_t : (which == 1 ? in1_t : in2_t);
+            const unsigned off = (unsigned)((const char*)q - (const char*)base);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(which == 0 ? rs_in0 : (which == 1 ? rs_in1 : rs_in2), off, 0, 2 /* nt */);
+            return __builtin_bit_cast(f32x4, v);
+        } else {
+            return ld4(q);
+        }
+    };
+    auto ldnt8 = [&](auto NT, int which, const unsigned short* q) -> float2 {
+        if constexpr (decltype(NT)::value) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const float* base = which == 0 ? in0_t : (which == 1 ? in1_t : in2_t);
+            const unsigned off = (unsigned)((const char*)q - (const char*)base);
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(which == 0 ? rs_in0 : (which == 1 ? rs_in1 : rs_in2), off, 0, 2 /* nt */);
+            return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+        } else {
+            return *reinterpret_cast<const float2*>(q);
+        }
+    };
     // W16 (a std::bool_constant): this wave streams the 16-bit arrays
-    auto svc_load1 = [&](auto W16, int k, int i) -> f32x4 {     // input i of this wave for step k
+    auto svc_load1 = [&](auto W16, auto NT, int k, int i) -> f32x4 {     // input i of this wave for step k
         const int t = T - 1 - k;
         if (!svalid || t < 0) return zero4();
         const size_t row = (size_t)sb * T + t;
         if constexpr (SV16) {
             if constexpr (decltype(W16)::value) {             // four 16-bit values = 8 bytes
                 const float* base = i == 0 ? sbase0 : (i == 1 ? sbase1 : sbase2);
-                const float2 w = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned short*>(base) + row * H + scol);
+                const float2 w = ldnt8(NT, i, reinterpret_cast<const unsigned short*>(base) + row * H + scol);
                 const f32x4 r4 = {w.x, w.y, 0.f, 0.f};
                 return r4;
             } else {
-                if (i == 0) return ldnt(sbase0 + row * H + scol);
-                if (i == 1) return t > 0 ? ldnt(sbase1 + (row - 1) * p.ldy + scol) : zero4();
-                return sbase2 ? ldnt(sbase2 + row * p.lddy + scol) : zero4();
+                if (i == 0) return ldnt(NT, 0, sbase0 + row * H + scol);
+                if (i == 1) return t > 0 ? ldnt(NT, 1, sbase1 + (row - 1) * p.ldy + scol) : zero4();
+                return sbase2 ? ldnt(NT, 2, sbase2 + row * p.lddy + scol) : zero4();
             }
         } else {
-            if (i == 0) return ldnt(sbase0 + row * H + scol);
-            if (i == 1) return ldnt(sbase1 + row * H + scol);
-            if (sodd) return sbase2 ? ldnt(sbase2 + row * sld2 + scol) : zero4();
-            return t > 0 ? ldnt(sbase2 + (row - 1) * sld2 + scol) : zero4();
+            if (i == 0) return ldnt(NT, 0, sbase0 + row * H + scol);
+            if (i == 1) return ldnt(NT, 1, sbase1 + row * H + scol);
+            if (sodd) return sbase2 ? ldnt(NT, 2, sbase2 + row * sld2 + scol) : zero4();
+            return t > 0 ? ldnt(NT, 2, sbase2 + (row - 1) * sld2 + scol) : zero4();
         }
     };
-    auto svc_issue = [&](auto W16, int k0, int n) {   // inputs of steps k0 .. k0+n-1 -> registers
+    auto svc_issue = [&](auto W16, auto NT, int k0, int n) {   // inputs of steps k0 .. k0+n-1 -> registers
 #pragma unroll
         for (int d = 0; d < KBX; ++d)
             if (d < n) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) sreg[d][i] = svc_load1(W16, k0 + d, i);
+                for (int i = 0; i < 3; ++i) sreg[d][i] = svc_load1(W16, NT, k0 + d, i);
             }
     };
     auto svc_put = [&](auto W16, int k0, int n) {     // registers -> ibuf slots of steps k0 .. k0+n-1
@@ -233,9 +283,9 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
             const size_t row = (size_t)sb * T + (T - 1 - k);
             const float* o = obuf + (k % OSL) * 4 * SARR + sr * SROW + sp * 4;
             // arrays sarr0 (dr / dz) and 2 + sarr0 (dn / dn*r)
-            stnt(p.dgi + row * p.lddg + (sodd ? H : 0) + scol, ld4(o + (sodd ? SARR : 0)));
-            float* g1 = sodd ? p.dghn + row * p.lddghn + scol : p.dgi + row * p.lddg + 2 * H + scol;
-            stnt(g1, ld4(o + (sodd ? 3 * SARR : 2 * SARR)));
+            stnt2(rs_dgi, dgi_t, p.dgi + row * p.lddg + (sodd ? H : 0) + scol, ld4(o + (sodd ? SARR : 0)));
+            if (sodd) stnt2(rs_dghn, dghn_t, p.dghn + row * p.lddghn + scol, ld4(o + 3 * SARR));
+            else stnt2(rs_dgi, dgi_t, p.dgi + row * p.lddg + 2 * H + scol, ld4(o + 2 * SARR));
         }
     };
     // PK image (p.dgpk): steps (ka, ka+1), ka even, are rows t_even + 1, t_even (t_even = T-2-ka) of the utterance; physical row
@@ -255,17 +305,17 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { unsigned hh, ll; split_pair(xe[e], xo[e], hh, ll); h[e] = hh; l[e] = ll; }
                 float* g = p.dgi + row * p.lddg + ao * H + scol;                 // 4H-wide rows [dr | dz | dn | dn*r]
-                stnt(g, __builtin_bit_cast(f32x4, h));
-                stnt(g + p.lddg, __builtin_bit_cast(f32x4, l));
+                stnt2(rs_dgi, dgi_t, g, __builtin_bit_cast(f32x4, h));
+                stnt2(rs_dgi, dgi_t, g + p.lddg, __builtin_bit_cast(f32x4, l));
             }
         }
     };
     if constexpr (BURST) {
         // the service waves' whole life (W16: this wave pair streams the 16-bit arrays)
-        auto svc_life = [&](auto W16) {
+        auto svc_life = [&](auto W16, auto NT) {
             // the service waves' whole life: same barrier sequence as the compute waves' loop below (two per step, one in the last)
-            svc_issue(W16, 0, KBX); svc_put(W16, 0, KBX);       // steps 0 .. KB-1 straight into the ring
-            svc_issue(W16, KBX, phi);                      // steps KB .. KB+phi-1: written at step phi-1, before the first dirty step (k = phi)
+            svc_issue(W16, NT, 0, KBX); svc_put(W16, 0, KBX);       // steps 0 .. KB-1 straight into the ring
+            svc_issue(W16, NT, KBX, phi);                      // steps KB .. KB+phi-1: written at step phi-1, before the first dirty step (k = phi)
             __syncthreads();
             for (int k = 0; k < T; ++k) {
                 const int jj = (k + KBX - phi) % KBX;                  // jj == 0: this tile's dirty step
@@ -277,7 +327,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                     // ahead of the compute waves -- nothing holds them after barrier #2 -- so the burst starts during the
                     // previous step's poll; holding it back until the compute waves reach the dirty step's gate phase
                     // measured the same launch time: the burst occupies the CU's memory pipeline for ~1.3 steps either way.)
-                    svc_issue(W16, k + KBX, KBX);
+                    svc_issue(W16, NT, k + KBX, KBX);
                     if (trs) p.trace[32 + (k - 100) * 4 + 1] = (long long)__builtin_readcyclecounter();
                     if (p.dgpk) svc_flush_pk(k - KBX - (phi & 1), k - (phi & 1));      // whole pairs: one step later for the tiles with an odd phase
                     else svc_flush(k - KBX, k);
@@ -299,8 +349,13 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
             else svc_flush(T - 1 - jl2, T);           // the gate gradients since the last dirty step
         };
         if (svc) {
-            if constexpr (SV16) { if (sodd) svc_life(std::true_type{}); else svc_life(std::false_type{}); }
-            else svc_life(std::false_type{});
+            const bool ntl = p.ntload != 0;             // uniform
+            if constexpr (SV16) {
+                if (sodd) { if (ntl) svc_life(std::true_type{}, std::true_type{}); else svc_life(std::true_type{}, std::false_type{}); }
+                else { if (ntl) svc_life(std::false_type{}, std::true_type{}); else svc_life(std::false_type{}, std::false_type{}); }
+            } else {
+                if (ntl) svc_life(std::false_type{}, std::true_type{}); else svc_life(std::false_type{}, std::false_type{});
+            }
             return;
         }
         __syncthreads();
@@ -859,7 +914,10 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     static int kb_env = -1;                           // DEP_BWD_BURST=0: the round-1 kernel (every wave streams for itself, every step); 4 (default) or 6: burst length
     if (kb_env < 0) { const char* v = getenv("DEP_BWD_BURST"); kb_env = v ? atoi(v) : 4; if (kb_env != 0 && kb_env != 4 && kb_env != 6) kb_env = 4; }
     { static int wf_env = -1; if (wf_env < 0) { const char* v = getenv("DEP_BWD_WFLAGS"); wf_env = (v && v[0] == '0') ? 0 : 1; } p.wflags = wf_env; }     // default on; DEP_BWD_WFLAGS=0: one flag per member behind a workgroup barrier
-    { static int nt_env = -1; if (nt_env < 0) { const char* v = getenv("DEP_BWD_NT"); nt_env = (v && v[0] == '1') ? 1 : 0; } p.ntstream = nt_env; }
+    { static int nt_env = -1; if (nt_env < 0) { const char* v = getenv("DEP_BWD_NT"); nt_env = (v && v[0] == '0') ? 0 : 1; } p.ntstream = nt_env; }
+    { static int ntl_env = -1; if (ntl_env < 0) { const char* v = getenv("DEP_BWD_NTLD"); ntl_env = (v && v[0] == '0') ? 0 : 1; } p.ntload = ntl_env; }
+    // (one tile's rows of the widest array must fit a 32-bit buffer offset)
+    { const int mxl = p.lddg > p.lddy ? p.lddg : p.lddy; DEP_CHECK_ARG((size_t)(BT * a.T + 1) * (mxl > p.ldy ? mxl : p.ldy) * 4 < 0xffffffffull); }
     static int xhalf_env = -1;
     if (xhalf_env < 0) { const char* v = getenv("DEP_BWD_XHALF"); xhalf_env = (v && v[0] == '1') ? 1 : (v && v[0] == '2') ? 2 : 0; }
     // 1: the whole batch's workgroups on XCDs 0-3, two per CU (round-1 schedule, 48 KB of LDS each); 2 (round 4, tools/exp_corun.py):

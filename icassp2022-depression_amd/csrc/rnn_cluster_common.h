@@ -153,6 +153,26 @@ __device__ __forceinline__ bool wait_flags(unsigned* tflags, int NC, unsigned ep
     }
 }
 
+// Non-temporal access to the sweeps' ONE-TOUCH HBM streams (round 4).  tools/micro/l2wb.hip + PMC: stream stores (and, less so, loads)
+// that allocate in the XCD's L2 evict the exchange payload -- rewritten in place every other step -- before its next rewrite, and
+// every eviction is a write-back to HBM plus fabric traffic in front of the hand-off; with the nt bit the payload stays.
+// (__builtin_nontemporal_load / _store compile to PLAIN accesses here; the buffer intrinsics' aux bit 1 does set `nt`.)
+// An NtArr addresses ONE tile's rows of an array (base = the tile's first row), so 32-bit offsets always suffice.
+struct NtArr { __amdgpu_buffer_rsrc_t rs; const char* base; };
+__device__ __forceinline__ NtArr nt_arr(const void* arr, size_t first_byte, size_t bytes) {
+    NtArr a;
+    a.base = reinterpret_cast<const char*>(arr) + first_byte;
+    a.rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.base, 0, (unsigned)(bytes < 0xfffffff0ull ? bytes : 0xfffffff0ull), 0x00020000);
+    return a;
+}
+__device__ __forceinline__ f32x4 nt_ld4(const NtArr& a, const float* q) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(a.rs, (unsigned)(reinterpret_cast<const char*>(q) - a.base), 0, 2 /* nt */);
+    return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ void nt_st4(const NtArr& a, float* q, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), a.rs, (unsigned)(reinterpret_cast<const char*>(q) - a.base), 0, 2 /* nt */);
+}
+
 inline int nofast_env() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("DEP_CLUSTER_NOFAST"); v = (e && e[0] == '1') ? 1 : 0; }

@@ -119,6 +119,12 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
             const int phi = (bt >> 3) % KBX;          // the clusters of an XCD take their dirty steps in turn
             f32x4 sreg[KBX][2];
             auto tstep = [&](int k) { return dir ? T - 1 - k : k; };
+            // the tile's rows of every streamed array, non-temporal (rnn_cluster_common.h)
+            const size_t trow0 = (size_t)(p.b0 + bt * BT) * T, trows = (size_t)BT * T;
+            const NtArr a_gi = nt_arr(p.gi, trow0 * p.ldgi * 4, trows * p.ldgi * 4);
+            const NtArr a_y = nt_arr(sodd ? p.ydrop : p.y, trow0 * p.ldy * 4, trows * p.ldy * 4);
+            const NtArr a_g = nt_arr(p.svg, trow0 * ldsg * 4, trows * ldsg * 4);
+            const NtArr a_c = nt_arr(p.svc, trow0 * ldsc * 4, trows * ldsc * 4);
             auto svc_issue = [&](int k0, int n) {     // input projection of steps k0 .. k0+n-1 -> registers (gates sodd, sodd + 2)
 #pragma unroll
                 for (int d = 0; d < KBX; ++d)
@@ -126,8 +132,8 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
                         const int k = k0 + d;
                         const bool on = svalid && k < T;
                         const float* src = p.gi + ((size_t)sb * T + tstep(k)) * p.ldgi + dir * 4 * H + (sodd ? H : 0) + scol;
-                        sreg[d][0] = on ? ld4(src) : zero4();
-                        sreg[d][1] = on ? ld4(src + 2 * H) : zero4();
+                        sreg[d][0] = on ? nt_ld4(a_gi, src) : zero4();
+                        sreg[d][1] = on ? nt_ld4(a_gi, src + 2 * H) : zero4();
                     }
             };
             auto svc_put = [&](int k0, int n) {
@@ -146,12 +152,12 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
                 for (int k = k0 < 0 ? 0 : k0; k < k1; ++k) {
                     const size_t row = (size_t)sb * T + tstep(k);
                     const float* o = obuf + (k % (KBX + 1)) * 7 * LARR + sr * LROW + sp * 4;
-                    if (ybase) *reinterpret_cast<f32x4*>(ybase + row * p.ldy + dir * H + scol) = ld4(o + (sodd ? LARR : 0));
+                    if (ybase) nt_st4(a_y, ybase + row * p.ldy + dir * H + scol, ld4(o + (sodd ? LARR : 0)));
                     if (p.svg) {
                         float* gs = p.svg + row * ldsg + dir * 4 * H + scol;
-                        *reinterpret_cast<f32x4*>(gs + (sodd ? H : 0)) = ld4(o + (sodd ? 3 : 2) * LARR);
-                        *reinterpret_cast<f32x4*>(gs + (sodd ? 3 * H : 2 * H)) = ld4(o + (sodd ? 5 : 4) * LARR);
-                        if (!sodd) *reinterpret_cast<f32x4*>(p.svc + row * ldsc + dir * H + scol) = ld4(o + 6 * LARR);
+                        nt_st4(a_g, gs + (sodd ? H : 0), ld4(o + (sodd ? 3 : 2) * LARR));
+                        nt_st4(a_g, gs + (sodd ? 3 * H : 2 * H), ld4(o + (sodd ? 5 : 4) * LARR));
+                        if (!sodd) nt_st4(a_c, p.svc + row * ldsc + dir * H + scol, ld4(o + 6 * LARR));
                     }
                 }
             };
@@ -401,6 +407,12 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
             const int scol = 32 * c + sp * 4;
             const int phi = (bt >> 3) % KBX;
             f32x4 sreg[KBX][4];
+            // the tile's rows of every streamed array, non-temporal (rnn_cluster_common.h)
+            const size_t trow0 = (size_t)(p.b0 + bt * BT) * T, trows = (size_t)BT * T;
+            const NtArr a_g = nt_arr(p.svg, trow0 * ldsg * 4, trows * ldsg * 4);
+            const NtArr a_c = nt_arr(p.svc, trow0 * ldsc * 4, trows * ldsc * 4);
+            const NtArr a_dy = nt_arr(p.dy, trow0 * p.lddy * 4, trows * p.lddy * 4);
+            const NtArr a_dg = nt_arr(p.dgi, trow0 * p.lddg * 4, trows * p.lddg * 4);
             // input arrays: even waves 0 i, 2 g, 4 c_t, 6 dy ; odd waves 1 f, 3 o, 5 c_{t-1}
             auto svc_issue = [&](int k0, int n) {
 #pragma unroll
@@ -411,11 +423,11 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                         const int t = dir ? (T - 1 - sstep) : sstep;
                         const size_t row = (size_t)sb * T + t;
                         const float* gs = p.svg + row * ldsg + dir * 4 * H + (sodd ? H : 0) + scol;
-                        sreg[d][0] = on ? ld4(gs) : zero4();
-                        sreg[d][1] = on ? ld4(gs + 2 * H) : zero4();
+                        sreg[d][0] = on ? nt_ld4(a_g, gs) : zero4();
+                        sreg[d][1] = on ? nt_ld4(a_g, gs + 2 * H) : zero4();
                         const size_t rowc = sodd ? (dir ? row + 1 : row - 1) : row;       // odd waves: c of the previous time step of this direction
-                        sreg[d][2] = (on && (!sodd || sstep > 0)) ? ld4(p.svc + rowc * ldsc + dir * H + scol) : zero4();
-                        sreg[d][3] = (on && !sodd && p.dy) ? ld4(p.dy + row * p.lddy + dir * H + scol) : zero4();
+                        sreg[d][2] = (on && (!sodd || sstep > 0)) ? nt_ld4(a_c, p.svc + rowc * ldsc + dir * H + scol) : zero4();
+                        sreg[d][3] = (on && !sodd && p.dy) ? nt_ld4(a_dy, p.dy + row * p.lddy + dir * H + scol) : zero4();
                     }
             };
             auto svc_put = [&](int k0, int n) {
@@ -435,8 +447,8 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                     const int sstep = T - 1 - k, t = dir ? (T - 1 - sstep) : sstep;
                     const float* o = obuf + (k % (KBX + 1)) * 4 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
                     float* g = p.dgi + ((size_t)sb * T + t) * p.lddg + dir * 4 * H + (sodd ? H : 0) + scol;
-                    *reinterpret_cast<f32x4*>(g) = ld4(o);
-                    *reinterpret_cast<f32x4*>(g + 2 * H) = ld4(o + 2 * LARR);
+                    nt_st4(a_dg, g, ld4(o));
+                    nt_st4(a_dg, g + 2 * H, ld4(o + 2 * LARR));
                 }
             };
             svc_issue(0, KBX); svc_put(0, KBX);

@@ -48,6 +48,7 @@ struct FF {
     long long* trace;
     unsigned* soft;          // fallback flag (rnn_cluster_common.h), or nullptr: a failed hello then raises the status word
     int force_soft;          // test hook (DEP_FORCE_SOFT_FALLBACK=1): behave as if the hello had timed out
+    int ntstore;             // write-out with non-temporal buffer stores (DEP_FWD_NT=1; A/B: no effect, default off)
 };
 
 #define FSTAMP(slot) do { if (TRACE && trl && s >= 100 && s < 104) trl[(s - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -154,7 +155,19 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             const int t = l0 ? s : s - 2;
             float* base = l0 ? p.y0 : p.y1;
             const unsigned slot = l0 ? dslot0[k] : k;
-            if (on) {
+            if (on && p.ntstore) {
+                // non-temporal: one-touch write-out that allocates in L2 evicts the exchange payload (tools/micro/l2wb.hip)
+                __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xfffffff0u, 0x00020000);
+                const unsigned eo = (unsigned)slot * p.ostride + so + (unsigned)t * FH;       // element offset inside the layer's arrays (< 2^30: host check)
+                if (SV16 && k >= 1 && k <= 3) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const float2 q = ld2(obuf + a * OARR + su * OROW + sqd * 2);
+                    const u32x2 qv = {__float_as_uint(q.x), __float_as_uint(q.y)};
+                    __builtin_amdgcn_raw_buffer_store_b64(qv, rso, (unsigned)slot * p.ostride * 4u + (so + (unsigned)t * FH) * 2u, 0, 2 /* nt */);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ld4(obuf + a * OARR + su * OROW + sqd * 4)), rso, eo * 4u, 0, 2 /* nt */);
+                }
+            } else if (on) {
                 float* arr = base + (size_t)slot * p.ostride;
                 if (SV16 && k >= 1 && k <= 3) {
                     // r, z (unorm16), n (snorm16): the gate threads left them PACKED in obuf (two units per word, 16 words per
@@ -418,6 +431,8 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
     p.soft = a.soft_fallback ? (unsigned*)xbuf + 1 : nullptr;
     const bool sv16 = a.training && a.sv16;
+    { static int nt = -1; if (nt < 0) { const char* e = getenv("DEP_FWD_NT"); nt = (e && e[0] == '1') ? 1 : 0; }      // measured: no effect on this launch (its payload, 0.4 MB per XCD, survives anyway) -> off
+      p.ntstore = (nt && (size_t)7 * a.ostride * sizeof(float) < 0xfffffff0ull) ? 1 : 0; }       // a layer's arrays span < 4 GB from its y
     { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; } p.force_soft = fs; }
     static bool attr = false;
     if (!attr) {
