@@ -257,6 +257,43 @@ def main():
                                      'exclusive fused two-layer launch' if L.load().dep_rnn_get_exclusive() else 'tolerant sweeps (dep_rnn_set_exclusive(0))')
 
     extras = not args.profile_run
+    # exposed communication per rank: the same step with the gradient exchange switched off, timed like the
+    # headline region; exposed = step - step_without_comm.  The replicas drift apart without the exchange: parameters and optimizer
+    # moments are snapshotted and restored around the leg.
+    exposed = None
+    if world > 1 and extras:
+        import torch.distributed as dist
+        snap = model._flat.clone()
+        st_snap = {k: (m.clone(), v.clone()) for k, (m, v) in optimizer._state.items()}
+        step_snap = optimizer._step
+        parallel.set_comm_enabled(False)
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize(); parallel.barrier()
+            n_x = max(3, min(args.steps, 10))
+            t4 = time.perf_counter()
+            for _ in range(n_x):
+                step()
+            torch.cuda.synchronize()
+            ms_nc = (time.perf_counter() - t4) / n_x * 1e3
+        finally:
+            parallel.set_comm_enabled(True)
+            model._flat.copy_(snap)
+            for k, (m, v) in st_snap.items():
+                optimizer._state[k][0].copy_(m); optimizer._state[k][1].copy_(v)
+            optimizer._step = step_snap
+        parallel.barrier()
+        mine = torch.tensor([ms_nc], device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if dist.get_backend() != 'nccl':
+            mine = mine.cpu(); allr = [t.cpu() for t in allr]
+        dist.all_gather(allr, mine)
+        step_ms = dt / args.steps * 1e3
+        exposed = {'step_without_comm_ms_by_rank': [round(float(t.item()), 4) for t in allr],
+                   'exposed_comm_ms_by_rank': [round(step_ms - float(t.item()), 4) for t in allr],
+                   'note': 'step_without_comm: the same train step with the gradient exchange switched off (local gradients), timed on every rank; '
+                           'exposed = ms_per_step (max over ranks, exchange on) - that'}
     # gradient exchange alone (every rank; gathered on rank 0): the same ranges the step reduces, nothing beside them
     comm_alone = None
     if world > 1 and extras:
@@ -478,7 +515,7 @@ def main():
     if eval_ms is not None:
         out['eval_forward'] = {'value': round(B / (eval_ms * 1e-3), 1), 'unit': 'utterances/s', 'ms_per_batch': round(eval_ms, 3),
                                'note': 'forward only (evaluate), rank 0, outside the headline region'}
-    out['extra'] = {'f32_exact': f32_exact, 'bf16_products': bf16_products, 'train_e2e': train_e2e, 'comm_alone_ms_per_step_by_rank': comm_alone,
+    out['extra'] = {'f32_exact': f32_exact, 'bf16_products': bf16_products, 'train_e2e': train_e2e, 'comm_alone_ms_per_step_by_rank': comm_alone, 'exposed_comm': exposed,
                     'other_workloads': other,
                     'precision_note': 'storage, state, accumulation and elementwise math fp32; products of the large contractions '
                                       'and of the recurrent sweeps: 3-term bf16 split on the bf16 matrix cores (DEP_GEMM_MODE=f32 = exact)'}

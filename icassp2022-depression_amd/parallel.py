@@ -74,6 +74,13 @@ def shard_slice(n, r=None, w=None):
 
 
 _count_override = [None]
+_comm_off = [False]
+
+
+def set_comm_enabled(on):
+    """Measurement only (bench.py `exposed_comm_ms`): with the gradient exchange off every rank steps on its LOCAL gradients --
+    the replicas drift apart, so the caller snapshots and restores the parameters around such a leg."""
+    _comm_off[0] = not on
 
 
 def set_global_count(n):
@@ -195,7 +202,7 @@ def layer_buckets(spans, n_live):
 
 def make_grad_sync(model, in_call):
     """GradSync for dep_rnn_backward_overlapped, or None without a native communicator.  in_call: {layer: (start, count)}."""
-    if _native['comm'] is None or not in_call:
+    if _native['comm'] is None or not in_call or _comm_off[0]:
         return None
     from . import _lib as L
     gs = L.GradSync()
@@ -212,6 +219,8 @@ def finish_grad_sync(model, in_call, post):
     """After the model's backward: reduce what is still local and join the streams.
     native communicator: `post` ranges (final only now) as one grouped RCCL operation on the communication stream, then the
     compute stream waits for that stream; otherwise one torch.distributed all-reduce of the whole bucket."""
+    if _comm_off[0]:
+        return
     if _native['comm'] is None:
         all_reduce_grads(model)
         return

@@ -255,4 +255,7 @@ def test_bench_two_rank_dry_run_on_one_gpu():
     assert d['n_gpus'] == 2 and d['config']['ranks'] == 2 and d['config']['global_batch'] == 1024 and d['scaling'] == 'weak'
     assert d['config']['backend'].startswith('rccl via torch.distributed') or d['config']['backend'] == 'torch.distributed'
     assert len(d['extra']['comm_alone_ms_per_step_by_rank']) == 2 and d['value'] > 0
+    ex = d['extra']['exposed_comm']                           # per-rank step time without the exchange, exposed = step - that
+    assert len(ex['step_without_comm_ms_by_rank']) == 2 and len(ex['exposed_comm_ms_by_rank']) == 2
+    assert all(t > 0 for t in ex['step_without_comm_ms_by_rank']) and d['extra']['other_workloads'] is None
     assert d['extra']['f32_exact'] is None and d['extra']['train_e2e'] is None and 'cpu_baseline' not in d       # rank-0-at-N=1 legs only
