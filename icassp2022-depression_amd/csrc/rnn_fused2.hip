@@ -146,6 +146,29 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         const unsigned so = ((unsigned)(b0t + su) * T) * FH + c * 32 + sqd * 4;       // < 2^28: one array is B*T*H floats
         // obuf slot k of layer l -> array index in the reserve's order (see FF): layer 0 with dropout h,hd,r,z,n,hn
         constexpr int dslot0[6] = {0, DROP ? 2 : 1, DROP ? 3 : 2, DROP ? 4 : 3, DROP ? 5 : 4, 1};
+        // Round 4: the steady state (both layers active, training) as straight-line code.  The general loop below decides per array
+        // whether / where to store with a dozen wave-uniform branches each (and reloads spilled scalars with v_readlane): the ISA
+        // showed ~40 instructions per store, 11 stores per step -- most of this group's ~3000-tick slot Z, which is what groups 0 / 1
+        // wait for at barrier #1.
+        if (s >= 2 && s < T && p.training != 0 && !p.ntstore) {
+            const float* ob = obuf + su * OROW;
+            const unsigned e0 = so + (unsigned)s * FH, e1 = so + (unsigned)(s - 2) * FH;
+            const size_t os = p.ostride;
+            auto st16 = [&](float* arr, unsigned e, int a) { *reinterpret_cast<f32x4*>(arr + e) = ld4(ob + a * OARR + sqd * 4); };
+            auto stg = [&](float* arr, unsigned e, int a) {       // a gate array: packed 16-bit words (SV16) or fp32
+                if constexpr (SV16) *reinterpret_cast<float2*>(reinterpret_cast<unsigned short*>(arr) + e) = ld2(ob + a * OARR + sqd * 2);
+                else *reinterpret_cast<f32x4*>(arr + e) = ld4(ob + a * OARR + sqd * 4);
+            };
+            if (shalf == 0) {                         // obuf arrays 0 h0, 2 z0, 4 hn0, 6 h1, 8 z1, 10 hn1
+                st16(p.y0, e0, 0); stg(p.y0 + dslot0[2] * os, e0, 2); st16(p.y0 + dslot0[4] * os, e0, 4);
+                st16(p.y1, e1, 6); stg(p.y1 + 2 * os, e1, 8); st16(p.y1 + 4 * os, e1, 10);
+            } else {                                  // 1 r0, 3 n0, 5 dropout(h0), 7 r1, 9 n1
+                stg(p.y0 + dslot0[1] * os, e0, 1); stg(p.y0 + dslot0[3] * os, e0, 3);
+                if constexpr (DROP) st16(p.y0 + dslot0[5] * os, e0, 5);
+                stg(p.y1 + 1 * os, e1, 7); stg(p.y1 + 3 * os, e1, 9);
+            }
+            return;
+        }
 #pragma unroll
         for (int pr = 0; pr < 6; ++pr) {
             const int a = pr * 2 + shalf;             // obuf array (wave-uniform): 0..5 layer 0, 6..10 layer 1
