@@ -594,11 +594,18 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         if (pk_env < 0) { const char* e = getenv("DEP_DGI_PK"); pk_env = (e && e[0] == '0') ? 0 : 1; }
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         float* dxl_probe = l == 0 ? dx : W + lo.dx[l & 1];
-        const bool pk = pk_env && lo.dg4 && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && a.split && dep_get_gemm_mode() == 1 &&
+        const bool pk_gru = pk_env && lo.dg4 && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && a.split && dep_get_gemm_mode() == 1 &&
                         dep_cluster_bwd_pk_ok(H, T) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(weights[(size_t)l * 4]) &&
                         al16(dweights[(size_t)l * 4]) && al16(dweights[(size_t)l * 4 + 1]) &&
                         dep_gemm_uses_bf16x3(G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(3 * H, H, BTr, T) &&
                         (!dxl_probe || (dep_gemm_uses_bf16x3(BTr, Kl, G * H, 0) && al16(dxl_probe)));
+        // the BiLSTM cluster sweep (both directions in one launch, direction-stacked contractions): same image, same conditions
+        bool pk_lstm = pk_env && lo.cluster && d->cell == DEP_CELL_LSTM && D == 2 && lo.wstack[l] != 0 && a.split && dep_get_gemm_mode() == 1 &&
+                       dep_cluster_lstm_bwd_pk_ok(T) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(W + lo.dwstack) &&
+                       dep_gemm_uses_bf16x3(D * G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(4 * H, H, BTr, T) &&
+                       (!dxl_probe || (dep_gemm_uses_bf16x3(BTr, Kl, D * G * H, 0) && al16(dxl_probe)));
+        for (int dd = 0; dd < D && pk_lstm; ++dd) pk_lstm = al16(dweights[(size_t)(l * D + dd) * 4 + 1]);
+        const bool pk = pk_gru || pk_lstm;
         a.dg_pk = pk ? 1 : 0;
         a.sv16 = (lo.sv16 && sweep_split_mode() && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU) ? 1 : 0;
         struct FmtGuard { bool on; ~FmtGuard() { if (on) dep_gemm_set_operand_formats(0, 0); } } fmt_guard{pk};

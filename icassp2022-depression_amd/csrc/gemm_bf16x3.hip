@@ -756,7 +756,10 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     if (persist < 0) { const char* e = getenv("DEP_GEMM_PERSIST"); persist = e ? atoi(e) : 768; if (persist < 8) persist = 8; persist = persist / 8 * 8; }
     if (bm256 < 0) { const char* e = getenv("DEP_GEMM_BM"); bm256 = (e && atoi(e) == 128) ? 0 : 1; }
     // measured at cfg2: 256-row tiles win 8-10 % on the NN (dX) and TN (dW) forms, lose 6 % on the short-K NT projection
-    const bool big = bm256 && M >= 512 && !(!transA && transB);
+    // (round 4: long-K projections -- cfg3's F = 1024 layer -- take the 256-row tile too; DEP_GEMM_NT256=0 restores 128 rows for every NT call)
+    static int nt256 = -1;
+    if (nt256 < 0) { const char* e = getenv("DEP_GEMM_NT256"); nt256 = (e && e[0] == '0') ? 0 : 1; }
+    const bool big = bm256 && M >= 512 && (!(!transA && transB) || (nt256 && K >= 512));
     const int BMT = big ? 256 : 128;
     GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl, dep_gemm_predicate(), g_xcd_lo, g_xcd_n, transA ? g_skip_at : 0, transA ? g_skip_by : 0};
     // persistent launch: at most `persist` workgroups (a multiple of 8: one share per XCD), each walks a list of tiles

@@ -33,6 +33,7 @@ struct LB {
     float* dbpart; int nwg;
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
     int nofast;
+    int dgpk;                // gate gradients as the PK image of gemm_bf16x3.hip (burst kernel, T even)
 };
 
 // block id = (dir*NC + c)*nbtp + bt  (nbtp a multiple of 8: all members of a cluster share blockIdx % 8)
@@ -325,7 +326,8 @@ struct StepIn { float2 ig, fg, gg, og, ct, cp, dy; };
 // KB > 0: burst streams (see lstm_fwd_cluster / gru_bwd_cluster_r1): the service waves bring the saved gates, c_t, c_{t-1} and dy of
 // KB steps per burst into the LDS ring `ibuf' and write the four gate gradients of the last KB steps out of `obuf'.
 constexpr int LB_IBUF = 2304;                        // float offset of ibuf (the gate-gradient planes live in [0, 2304))
-constexpr size_t lstm_bwd_lds_floats(int KB) { return KB ? (size_t)LB_IBUF + KB * 7 * LARR + (KB + 1) * 4 * LARR : (size_t)BT * (128 + 8); }
+constexpr int lstm_bwd_oslots(int KB) { return KB + 2; }      // KB + 1 would do for fp32 rows; the PK flush works on step pairs and may lag one step
+constexpr size_t lstm_bwd_lds_floats(int KB) { return KB ? (size_t)LB_IBUF + KB * 7 * LARR + lstm_bwd_oslots(KB) * 4 * LARR : (size_t)BT * (128 + 8); }
 
 template <int NTW, bool SPLIT, int KB>      // output tiles per wave = H/64
 __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
@@ -445,10 +447,33 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                 if (!svalid) return;
                 for (int k = k0 < 0 ? 0 : k0; k < k1; ++k) {
                     const int sstep = T - 1 - k, t = dir ? (T - 1 - sstep) : sstep;
-                    const float* o = obuf + (k % (KBX + 1)) * 4 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
+                    const float* o = obuf + (k % lstm_bwd_oslots(KBX)) * 4 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
                     float* g = p.dgi + ((size_t)sb * T + t) * p.lddg + dir * 4 * H + (sodd ? H : 0) + scol;
                     nt_st4(a_dg, g, ld4(o));
                     nt_st4(a_dg, g + 2 * H, ld4(o + 2 * LARR));
+                }
+            };
+            // PK image of the gate gradients (p.dgpk; gemm_bf16x3.hip FMT_PK, see gru_bwd_cluster_r1): the steps (ka, ka + 1), ka even,
+            // are two adjacent time steps of the utterance -- rows (T-2-ka, T-1-ka) for the forward direction, (ka, ka+1) for the reverse
+            // one; the even row holds the bf16 hi pairs of both, the odd row the residual pairs.  Same bytes, same bits in the GEMMs.
+            auto svc_flush_pk = [&](int k0, int k1) {
+                if (!svalid) return;
+                for (int ka = k0 < 0 ? 0 : k0; ka + 1 < k1; ka += 2) {
+                    const int t_even = dir ? ka : T - 2 - ka;
+                    const float* o0 = obuf + (ka % lstm_bwd_oslots(KBX)) * 4 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
+                    const float* o1 = obuf + ((ka + 1) % lstm_bwd_oslots(KBX)) * 4 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
+                    const float* oe = dir ? o0 : o1;      // the step that is row t_even
+                    const float* oo = dir ? o1 : o0;      // ... row t_even + 1
+                    float* g = p.dgi + ((size_t)sb * T + t_even) * p.lddg + dir * 4 * H + (sodd ? H : 0) + scol;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x4 xe = ld4(oe + q * 2 * LARR), xo = ld4(oo + q * 2 * LARR);
+                        u32x4 hw, lw;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { unsigned hh, ll; split_pair(xe[e], xo[e], hh, ll); hw[e] = hh; lw[e] = ll; }
+                        nt_st4(a_dg, g + q * 2 * H, __builtin_bit_cast(f32x4, hw));
+                        nt_st4(a_dg, g + q * 2 * H + p.lddg, __builtin_bit_cast(f32x4, lw));
+                    }
                 }
             };
             svc_issue(0, KBX); svc_put(0, KBX);
@@ -456,13 +481,14 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
             __syncthreads();
             for (int k = 0; k < T; ++k) {             // same barrier sequence as the compute waves: two per step, one in the last
                 const int jj = (k + KBX - phi) % KBX, last = k - jj;
-                if (jj == 0) { svc_issue(k + KBX, KBX); svc_flush(k - KBX, k); }
+                if (jj == 0) { svc_issue(k + KBX, KBX); if (p.dgpk) svc_flush_pk(k - KBX - (phi & 1), k - (phi & 1)); else svc_flush(k - KBX, k); }
                 bar_lds();                           // #1
                 if (jj == KBX - 1) { if (last >= 0) svc_put(last + KBX, KBX); else svc_put(KBX, phi); }
                 if (k == T - 1) break;
                 bar_lds();                           // #2 (the compute waves' drain barrier)
             }
-            svc_flush(T - 1 - (T - 1 + KBX - phi) % KBX, T);
+            if (p.dgpk) svc_flush_pk(T - 1 - (T - 1 + KBX - phi) % KBX - (phi & 1), T);
+            else svc_flush(T - 1 - (T - 1 + KBX - phi) % KBX, T);
             return;
         }
         __syncthreads();
@@ -512,7 +538,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
             st2(dl, dig); st2(dl + 32, dfg); st2(dl + 64, dgg); st2(dl + 96, dog);
         }
         if constexpr (BURST) {
-            float* ob = obuf + ((T - 1 - s) % (KBX + 1)) * 4 * LARR + j * LROW + ul;
+            float* ob = obuf + ((T - 1 - s) % lstm_bwd_oslots(KBX)) * 4 * LARR + j * LROW + ul;
             st2(ob, dig); st2(ob + LARR, dfg); st2(ob + 2 * LARR, dgg); st2(ob + 3 * LARR, dog);
         } else if (valid) {
             float* g = p.dgi + row * p.lddg + dir * 4 * H + col;
@@ -689,6 +715,11 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
     return DEP_OK;
 }
 
+bool dep_cluster_lstm_bwd_pk_ok(int T) {
+    const char* v = getenv("DEP_LSTM_BURST");
+    return T % 2 == 0 && !(v && atoi(v) == 0);
+}
+
 int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
     const int NC = a.H / 32, CH = dep_cluster_chunk(a.dirs * NC, 1, 256), nbt = dep_cdiv(a.B, BT);
     const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
@@ -699,7 +730,7 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
     p.drop_p = a.dy ? a.drop_p : 0.f; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     p.seed = a.seed; p.site = a.site;
     p.dh_n = a.dh_n; p.svg = a.sv0; p.svc = a.sv1;
-    p.dgi = a.dgi; p.lddg = a.dirs * 4 * a.H; p.dbpart = a.dbpart; p.nwg = nbt;
+    p.dgi = a.dgi; p.lddg = a.dirs * 4 * a.H; p.dbpart = a.dbpart; p.nwg = nbt; p.dgpk = a.dg_pk;
     DEP_CHECK_ARG(a.dbpart_rows >= nbt * a.dirs);
     const size_t pay = (size_t)2 * a.dirs * nbtp_max * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp_max * NC <= 256);
@@ -709,6 +740,7 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
     static int kb_env = -1;                           // DEP_LSTM_BURST=0: round-1 schedule
     if (kb_env < 0) { const char* v = getenv("DEP_LSTM_BURST"); kb_env = (v && atoi(v) == 0) ? 0 : 4; }
     const int kb = kb_env;
+    DEP_CHECK_ARG(!a.dg_pk || (kb == 4 && a.T % 2 == 0));      // the PK image comes out of the burst kernel's flush (dep_cluster_lstm_bwd_pk_ok)
     const size_t lds = lstm_bwd_lds_floats(kb) * sizeof(float);
     static bool attr = false;
     if (!attr) {

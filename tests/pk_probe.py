@@ -10,24 +10,33 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from icassp2022_depression_amd import _lib as L  # noqa: E402
 
 out, B, T, F = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-want_dx = len(sys.argv) > 5 and sys.argv[5] == 'dx'
-H, Lyr = 256, 2
+want_dx = 'dx' in sys.argv[5:]
+lstm = 'lstm' in sys.argv[5:]                 # the BiLSTM-128 x2 stack of the text model instead of the GRU-256 x2 one
+H, Lyr, dirs, G = (128, 2, 2, 4) if lstm else (256, 2, 1, 3)
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(B * 1000 + T)
 k = 1.0 / np.sqrt(H)
 W = []
 for l in range(Lyr):
-    for shp in ((3 * H, F if l == 0 else H), (3 * H, H), (3 * H,), (3 * H,)):
-        W.append(((torch.rand(*shp, generator=g) * 2 - 1) * k).to(dev))
+    for d in range(dirs):
+        for shp in ((G * H, F if l == 0 else H * dirs), (G * H, H), (G * H,), (G * H,)):
+            W.append(((torch.rand(*shp, generator=g) * 2 - 1) * k).to(dev))
 Gd = [torch.full_like(w, float('nan')) for w in W]
 x = torch.randn(B, T, F, generator=g).to(dev)
-dpool = torch.randn(B, H, generator=g).to(dev)
-dy = torch.randn(B, T, H, generator=g).to(dev)
-rnn = L.Rnn(L.CELL_GRU, B, T, F, H, Lyr, 1, True, 0.5, L.POOL_MEAN, dev)
-pooled = torch.empty(B, H, device=dev)
+dy = torch.randn(B, T, H * dirs, generator=g).to(dev)
 dx = torch.full((B, T, F), float('nan'), device=dev) if want_dx else None
-rnn.forward(x, W, seed=11, pooled=pooled)
-rnn.backward(x, W, Gd, dy=dy, dpooled=dpool, dx=dx)
+if lstm:
+    rnn = L.Rnn(L.CELL_LSTM, B, T, F, H, Lyr, 2, True, 0.5, L.POOL_NONE, dev)
+    h_n = torch.empty(2 * Lyr, B, H, device=dev)
+    dh_n = torch.randn(2 * Lyr, B, H, generator=g).to(dev)
+    rnn.forward(x, W, seed=11, h_n=h_n)
+    rnn.backward(x, W, Gd, dy=dy, dh_n=dh_n, dx=dx)
+else:
+    dpool = torch.randn(B, H, generator=g).to(dev)
+    rnn = L.Rnn(L.CELL_GRU, B, T, F, H, Lyr, 1, True, 0.5, L.POOL_MEAN, dev)
+    pooled = torch.empty(B, H, device=dev)
+    rnn.forward(x, W, seed=11, pooled=pooled)
+    rnn.backward(x, W, Gd, dy=dy, dpooled=dpool, dx=dx)
 rnn.check()
 torch.cuda.synchronize()
 res = {'g%d' % i: t.cpu().numpy() for i, t in enumerate(Gd)}

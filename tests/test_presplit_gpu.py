@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp_path, tag, pk, B, T, F, dx):
+def _run(tmp_path, tag, pk, B, T, F, dx, lstm=False):
     out = str(tmp_path / f'{tag}_{pk}.npz')
     e = dict(os.environ, DEP_DGI_PK=str(pk))
-    r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, str(B), str(T), str(F)] + (['dx'] if dx else []),
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, str(B), str(T), str(F)] + (['dx'] if dx else []) + (['lstm'] if lstm else []),
                        env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return np.load(out)
@@ -28,6 +28,17 @@ def _run(tmp_path, tag, pk, B, T, F, dx):
 def test_pk_gate_gradients_leave_every_gradient_bit_identical(tmp_path, B, T, F, dx):
     a = _run(tmp_path, 'a', 0, B, T, F, dx)
     b = _run(tmp_path, 'b', 1, B, T, F, dx)
+    for k in a.files:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+
+
+# the BiLSTM-128 x2 stack (both directions in one launch; the reverse direction's step pairs are rows (ka, ka + 1)): B = 416 -> 26 tiles x 2
+# directions, burst phases 0..3 again; cfg3's full shape once
+@pytest.mark.parametrize('B,T,F,dx', [(416, 20, 64, True), (416, 22, 1024, False), (512, 300, 1024, False)])
+def test_pk_gate_gradients_of_the_bilstm_stack_are_bit_identical_too(tmp_path, B, T, F, dx):
+    a = _run(tmp_path, 'a', 0, B, T, F, dx, lstm=True)
+    b = _run(tmp_path, 'b', 1, B, T, F, dx, lstm=True)
     for k in a.files:
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
