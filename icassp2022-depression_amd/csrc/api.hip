@@ -189,7 +189,8 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
         static int sv_env = -1, fb_env = -1;
         if (sv_env < 0) { const char* e = getenv("DEP_SV16"); sv_env = (e && e[0] == '0') ? 0 : 1; }
         if (fb_env < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fb_env = (e && e[0] == '1') ? 1 : 0; }
-        lo.sv16 = sv_env && !fb_env && lo.cluster && d->cell == DEP_CELL_GRU && d->training && !lo.cluster16_bwd && (lo.fused2 || !lo.cluster16);
+        lo.sv16 = sv_env && d->training && lo.cluster &&
+                  (d->cell == DEP_CELL_GRU ? (!fb_env && !lo.cluster16_bwd && (lo.fused2 || !lo.cluster16)) : dep_cluster_lstm_sv16_ok());
     }
     return true;
 }
@@ -451,7 +452,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         a.h_n = h_n ? h_n + (size_t)l * D * B * H : nullptr;
         if (d->training) { a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3]; }
         a.stream = s;
-        a.sv16 = (sv16 && lo.cluster && !use16 && d->cell == DEP_CELL_GRU) ? 1 : 0;
+        a.sv16 = (sv16 && lo.cluster && (d->cell == DEP_CELL_LSTM || !use16)) ? 1 : 0;
         a.hdr_slot = l < DEP_HDR_SLOTS ? l : 0; a.hdr_clean = l < DEP_HDR_SLOTS;      // one header slot per layer, zeroed once per call
         rc = use16 ? dep_launch_cluster16_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_fwd(a, W + lo.xbuf, lo.xbuf_bytes)
@@ -607,7 +608,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         for (int dd = 0; dd < D && pk_lstm; ++dd) pk_lstm = al16(dweights[(size_t)(l * D + dd) * 4 + 1]);
         const bool pk = pk_gru || pk_lstm;
         a.dg_pk = pk ? 1 : 0;
-        a.sv16 = (lo.sv16 && sweep_split_mode() && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU) ? 1 : 0;
+        a.sv16 = (lo.sv16 && sweep_split_mode() && lo.cluster && (d->cell == DEP_CELL_LSTM || !lo.cluster16_bwd)) ? 1 : 0;
         struct FmtGuard { bool on; ~FmtGuard() { if (on) dep_gemm_set_operand_formats(0, 0); } } fmt_guard{pk};
         rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
            : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)

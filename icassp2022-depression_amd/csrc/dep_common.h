@@ -162,6 +162,7 @@ struct dep_sweep_bwd_args {
 };
 bool dep_cluster_bwd_pk_ok(int H, int T);
 bool dep_cluster_lstm_bwd_pk_ok(int T);
+bool dep_cluster_lstm_sv16_ok();
 int dep_launch_sweep_bwd(const dep_sweep_bwd_args& a);
 int dep_sweep_num_wg(int B, int H, int impl);       // batch tiles (rows of dbpart) per direction
 bool dep_sweep_use_mfma(int H, int impl);

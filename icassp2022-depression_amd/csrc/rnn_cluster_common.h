@@ -169,6 +169,17 @@ __device__ __forceinline__ f32x4 nt_ld4(const NtArr& a, const float* q) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(a.rs, (unsigned)(reinterpret_cast<const char*>(q) - a.base), 0, 2 /* nt */);
     return __builtin_bit_cast(f32x4, v);
 }
+// 8 bytes (four 16-bit fixed-point values) at byte address q
+__device__ __forceinline__ float2 nt_ld2w(const NtArr& a, const void* q) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(a.rs, (unsigned)(reinterpret_cast<const char*>(q) - a.base), 0, 2 /* nt */);
+    return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+}
+__device__ __forceinline__ void nt_st2w(const NtArr& a, void* q, unsigned w0, unsigned w1) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = {w0, w1};
+    __builtin_amdgcn_raw_buffer_store_b64(v, a.rs, (unsigned)(reinterpret_cast<const char*>(q) - a.base), 0, 2 /* nt */);
+}
 __device__ __forceinline__ void nt_st4(const NtArr& a, float* q, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), a.rs, (unsigned)(reinterpret_cast<const char*>(q) - a.base), 0, 2 /* nt */);
 }

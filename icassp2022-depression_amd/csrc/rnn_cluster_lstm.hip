@@ -50,7 +50,9 @@ constexpr int L_SVC = 256;
 constexpr int LROW = 36, LARR = 16 * LROW;           // LDS row stride / array size (floats) of ibuf / obuf
 constexpr size_t lstm_fwd_lds_floats(int H, int KB) { return (size_t)BT * (H + 8) + 4 * 4 * 64 * 4 + (KB ? KB * 4 * LARR + (KB + 1) * 7 * LARR : 0); }
 
-template <int KCH, bool SPLIT, int KB>      // k-chunks of 16 per wave = H/32
+// SV16 (burst kernels only): the saved activated gates are 16-bit fixed point -- i, f, o in (0, 1) as unorm16, g in (-1, 1) as
+// snorm16 (rnn_cluster_common.h; same element positions inside the (B,T,dirs*4H) array, 2 bytes each); c stays fp32.
+template <int KCH, bool SPLIT, int KB, bool SV16 = false>      // k-chunks of 16 per wave = H/32
 __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
             const size_t trow0 = (size_t)(p.b0 + bt * BT) * T, trows = (size_t)BT * T;
             const NtArr a_gi = nt_arr(p.gi, trow0 * p.ldgi * 4, trows * p.ldgi * 4);
             const NtArr a_y = nt_arr(sodd ? p.ydrop : p.y, trow0 * p.ldy * 4, trows * p.ldy * 4);
-            const NtArr a_g = nt_arr(p.svg, trow0 * ldsg * 4, trows * ldsg * 4);
+            const NtArr a_g = nt_arr(p.svg, trow0 * ldsg * (SV16 ? 2 : 4), trows * ldsg * (SV16 ? 2 : 4));
             const NtArr a_c = nt_arr(p.svc, trow0 * ldsc * 4, trows * ldsc * 4);
             auto svc_issue = [&](int k0, int n) {     // input projection of steps k0 .. k0+n-1 -> registers (gates sodd, sodd + 2)
 #pragma unroll
@@ -155,9 +157,17 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
                     const float* o = obuf + (k % (KBX + 1)) * 7 * LARR + sr * LROW + sp * 4;
                     if (ybase) nt_st4(a_y, ybase + row * p.ldy + dir * H + scol, ld4(o + (sodd ? LARR : 0)));
                     if (p.svg) {
-                        float* gs = p.svg + row * ldsg + dir * 4 * H + scol;
-                        nt_st4(a_g, gs + (sodd ? H : 0), ld4(o + (sodd ? 3 : 2) * LARR));
-                        nt_st4(a_g, gs + (sodd ? 3 * H : 2 * H), ld4(o + (sodd ? 5 : 4) * LARR));
+                        if constexpr (SV16) {                 // even waves: i (unorm), g (snorm) ; odd waves: f, o (unorm)
+                            unsigned short* gs16 = reinterpret_cast<unsigned short*>(p.svg) + row * ldsg + dir * 4 * H + scol;
+                            const f32x4 v0 = ld4(o + (sodd ? 3 : 2) * LARR), v1 = ld4(o + (sodd ? 5 : 4) * LARR);
+                            nt_st2w(a_g, gs16 + (sodd ? H : 0), pack_unorm2(v0[0], v0[1]), pack_unorm2(v0[2], v0[3]));
+                            if (sodd) nt_st2w(a_g, gs16 + 3 * H, pack_unorm2(v1[0], v1[1]), pack_unorm2(v1[2], v1[3]));
+                            else nt_st2w(a_g, gs16 + 2 * H, pack_snorm2(v1[0], v1[1]), pack_snorm2(v1[2], v1[3]));
+                        } else {
+                            float* gs = p.svg + row * ldsg + dir * 4 * H + scol;
+                            nt_st4(a_g, gs + (sodd ? H : 0), ld4(o + (sodd ? 3 : 2) * LARR));
+                            nt_st4(a_g, gs + (sodd ? 3 * H : 2 * H), ld4(o + (sodd ? 5 : 4) * LARR));
+                        }
                         if (!sodd) nt_st4(a_c, p.svc + row * ldsc + dir * H + scol, ld4(o + 6 * LARR));
                     }
                 }
@@ -329,7 +339,7 @@ constexpr int LB_IBUF = 2304;                        // float offset of ibuf (th
 constexpr int lstm_bwd_oslots(int KB) { return KB + 2; }      // KB + 1 would do for fp32 rows; the PK flush works on step pairs and may lag one step
 constexpr size_t lstm_bwd_lds_floats(int KB) { return KB ? (size_t)LB_IBUF + KB * 7 * LARR + lstm_bwd_oslots(KB) * 4 * LARR : (size_t)BT * (128 + 8); }
 
-template <int NTW, bool SPLIT, int KB>      // output tiles per wave = H/64
+template <int NTW, bool SPLIT, int KB, bool SV16 = false>      // output tiles per wave = H/64; SV16: 16-bit saved gates (burst kernel only)
 __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 128, KCB = KS / 16, LDG = KS + LPAD;
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
             f32x4 sreg[KBX][4];
             // the tile's rows of every streamed array, non-temporal (rnn_cluster_common.h)
             const size_t trow0 = (size_t)(p.b0 + bt * BT) * T, trows = (size_t)BT * T;
-            const NtArr a_g = nt_arr(p.svg, trow0 * ldsg * 4, trows * ldsg * 4);
+            const NtArr a_g = nt_arr(p.svg, trow0 * ldsg * (SV16 ? 2 : 4), trows * ldsg * (SV16 ? 2 : 4));
             const NtArr a_c = nt_arr(p.svc, trow0 * ldsc * 4, trows * ldsc * 4);
             const NtArr a_dy = nt_arr(p.dy, trow0 * p.lddy * 4, trows * p.lddy * 4);
             const NtArr a_dg = nt_arr(p.dgi, trow0 * p.lddg * 4, trows * p.lddg * 4);
@@ -424,9 +434,15 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                         const bool on = svalid && sstep >= 0;
                         const int t = dir ? (T - 1 - sstep) : sstep;
                         const size_t row = (size_t)sb * T + t;
-                        const float* gs = p.svg + row * ldsg + dir * 4 * H + (sodd ? H : 0) + scol;
-                        sreg[d][0] = on ? nt_ld4(a_g, gs) : zero4();
-                        sreg[d][1] = on ? nt_ld4(a_g, gs + 2 * H) : zero4();
+                        if constexpr (SV16) {                 // four 16-bit values = 8 bytes per slot, decoded in svc_put
+                            const unsigned short* gs16 = reinterpret_cast<const unsigned short*>(p.svg) + row * ldsg + dir * 4 * H + (sodd ? H : 0) + scol;
+                            const float2 w0 = on ? nt_ld2w(a_g, gs16) : f2(0.f, 0.f), w1 = on ? nt_ld2w(a_g, gs16 + 2 * H) : f2(0.f, 0.f);
+                            sreg[d][0][0] = w0.x; sreg[d][0][1] = w0.y; sreg[d][1][0] = w1.x; sreg[d][1][1] = w1.y;
+                        } else {
+                            const float* gs = p.svg + row * ldsg + dir * 4 * H + (sodd ? H : 0) + scol;
+                            sreg[d][0] = on ? nt_ld4(a_g, gs) : zero4();
+                            sreg[d][1] = on ? nt_ld4(a_g, gs + 2 * H) : zero4();
+                        }
                         const size_t rowc = sodd ? (dir ? row + 1 : row - 1) : row;       // odd waves: c of the previous time step of this direction
                         sreg[d][2] = (on && (!sodd || sstep > 0)) ? nt_ld4(a_c, p.svc + rowc * ldsc + dir * H + scol) : zero4();
                         sreg[d][3] = (on && !sodd && p.dy) ? nt_ld4(a_dy, p.dy + row * p.lddy + dir * H + scol) : zero4();
@@ -437,8 +453,18 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                 for (int d = 0; d < KBX; ++d)
                     if (d < n) {
                         float* dst = ibuf + ((k0 + d) % KBX) * 7 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
-                        *reinterpret_cast<f32x4*>(dst) = sreg[d][0];
-                        *reinterpret_cast<f32x4*>(dst + 2 * LARR) = sreg[d][1];
+                        if constexpr (SV16) {                 // slot 0: i / f (unorm) ; slot 1: g (snorm, even waves) / o (unorm, odd waves)
+                            const unsigned a0 = __float_as_uint(sreg[d][0][0]), a1 = __float_as_uint(sreg[d][0][1]);
+                            const unsigned b0 = __float_as_uint(sreg[d][1][0]), b1 = __float_as_uint(sreg[d][1][1]);
+                            const float2 x0 = unpack_unorm2(a0), x1 = unpack_unorm2(a1);
+                            const float2 y0 = sodd ? unpack_unorm2(b0) : unpack_snorm2(b0), y1 = sodd ? unpack_unorm2(b1) : unpack_snorm2(b1);
+                            const f32x4 v0 = {x0.x, x0.y, x1.x, x1.y}, v1 = {y0.x, y0.y, y1.x, y1.y};
+                            *reinterpret_cast<f32x4*>(dst) = v0;
+                            *reinterpret_cast<f32x4*>(dst + 2 * LARR) = v1;
+                        } else {
+                            *reinterpret_cast<f32x4*>(dst) = sreg[d][0];
+                            *reinterpret_cast<f32x4*>(dst + 2 * LARR) = sreg[d][1];
+                        }
                         *reinterpret_cast<f32x4*>(dst + 4 * LARR) = sreg[d][2];
                         if (!sodd) *reinterpret_cast<f32x4*>(dst + 6 * LARR) = sreg[d][3];
                     }
@@ -697,6 +723,7 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4) * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4) * sizeof(float)));
         attr = true;
     }
@@ -706,13 +733,24 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
-        if (kb) { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4>), grid, block, lds, a.stream, p);
+        if (kb && a.split && a.sv16 && a.training) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true>), grid, block, lds, a.stream, p);
+        else if (kb) { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4>), grid, block, lds, a.stream, p);
                   else hipLaunchKernelGGL((lstm_fwd_cluster<4, false, 4>), grid, block, lds, a.stream, p); }
         else    { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 0>), grid, block, lds, a.stream, p);
                   else hipLaunchKernelGGL((lstm_fwd_cluster<4, false, 0>), grid, block, lds, a.stream, p); }
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
+}
+
+// both LSTM sweeps must be the burst kernels for the 16-bit saved gates (dep_sweep_args.sv16)
+// OPT-IN (DEP_LSTM_SV16=1): measured at cfg3 it buys 1.5 % on each sweep (1.18 -> 1.16, 1.35 -> 1.33 ms; the BiLSTM sweeps are less
+// byte-bound than the GRU backward), and it moves the text model's parameters after two AdamW steps by up to 8.6e-5 from the reference
+// fixture -- inside the path's 1e-4 bar but outside tests/test_scripts_gpu.py's tighter 7.1e-5 -- so the default keeps fp32 gates.
+bool dep_cluster_lstm_sv16_ok() {
+    const char* v = getenv("DEP_LSTM_BURST");
+    const char* e = getenv("DEP_LSTM_SV16");
+    return (e && e[0] == '1') && !(v && atoi(v) == 0);
 }
 
 bool dep_cluster_lstm_bwd_pk_ok(int T) {
@@ -740,11 +778,13 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
     static int kb_env = -1;                           // DEP_LSTM_BURST=0: round-1 schedule
     if (kb_env < 0) { const char* v = getenv("DEP_LSTM_BURST"); kb_env = (v && atoi(v) == 0) ? 0 : 4; }
     const int kb = kb_env;
-    DEP_CHECK_ARG(!a.dg_pk || (kb == 4 && a.T % 2 == 0));      // the PK image comes out of the burst kernel's flush (dep_cluster_lstm_bwd_pk_ok)
+    DEP_CHECK_ARG(!a.dg_pk || (kb == 4 && a.T % 2 == 0));
+    DEP_CHECK_ARG(!a.sv16 || (kb == 4 && a.split));           // 16-bit saved gates: burst kernel, split-precision mode      // the PK image comes out of the burst kernel's flush (dep_cluster_lstm_bwd_pk_ok)
     const size_t lds = lstm_bwd_lds_floats(kb) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
         attr = true;
     }
@@ -754,7 +794,8 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
-        if (kb) { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4>), grid, block, lds, a.stream, p);
+        if (kb && a.split && a.sv16) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4, true>), grid, block, lds, a.stream, p);
+        else if (kb) { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4>), grid, block, lds, a.stream, p);
                   else hipLaunchKernelGGL((lstm_bwd_cluster<2, false, 4>), grid, block, lds, a.stream, p); }
         else    { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 0>), grid, block, lds, a.stream, p);
                   else hipLaunchKernelGGL((lstm_bwd_cluster<2, false, 0>), grid, block, lds, a.stream, p); }
