@@ -42,3 +42,25 @@ def test_pk_gate_gradients_of_the_bilstm_stack_are_bit_identical_too(tmp_path, B
     for k in a.files:
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+
+
+def test_16bit_saved_gates_move_no_gradient_by_more_than_1e4_of_its_scale(tmp_path):
+    """Round 4: the GRU stack saves r, z (unorm16) and n (snorm16) as 16-bit fixed point (|error| <= 7.6e-6 / 1.5e-5) instead of fp32.
+    Forward outputs cannot change (the gates are only stored for the backward); every gradient of the cfg2-shaped stack must stay
+    within 1e-4 of its tensor's scale of the fp32-gates run (measured: a few 1e-6), and the contractions' operands stay bit-exact
+    functions of the gate gradients (PK on in both runs)."""
+    outs = {}
+    for sv in ('0', '1'):
+        out = str(tmp_path / f'sv{sv}.npz')
+        e = dict(os.environ, DEP_SV16=sv)
+        r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, '512', '300', '256', 'dx'], env=e, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[sv] = np.load(out)
+    worst = 0.0
+    for k in outs['0'].files:
+        a, b = outs['0'][k].astype(np.float64), outs['1'][k].astype(np.float64)
+        rel = np.abs(a - b).max() / max(np.abs(a).max(), 1e-30)
+        worst = max(worst, rel)
+        assert rel < 1e-4, (k, rel)
+    assert worst > 0.0            # the switch really changed the stored gates
