@@ -368,6 +368,31 @@ def main():
         finally:
             L.set_gemm_mode(1)
 
+    # ... and with bf16 STORAGE on top (dep_set_gemm_mode(3)): hidden sequences, hn and gate gradients as bf16 in HBM, saved gates 16-bit
+    # fixed point, state / accumulation fp32 -- BASELINE configs[1]'s "bf16" taken literally; own tolerance (tests: 1e-2 on gradients)
+    bf16_storage = None
+    if extras and split_mode and rank == 0 and world == 1 and args.workload == 'audio_gru':
+        L.set_gemm_mode(3)
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            n_f = max(3, min(args.steps, 10))
+            L.profile_enable(True); L.profile_read()
+            t2 = time.perf_counter()
+            for _ in range(n_f):
+                lf = step()
+            torch.cuda.synchronize()
+            ms_f = (time.perf_counter() - t2) / n_f * 1e3
+            pr3 = L.profile_read(); L.profile_enable(False)
+            bf16_storage = {'ms_per_step': round(ms_f, 3), 'value': round(B / (ms_f * 1e-3), 1), 'unit': 'utterances/s',
+                            'final_loss': round(lf.item(), 6),
+                            'kernels_ms_per_step': {k: round(v[0] / n_f, 4) for k, v in pr3.items() if v[1] > 0},
+                            'note': 'dep_set_gemm_mode(3): single bf16 products AND bf16 storage of y / hn / gate gradients (16-bit fixed-point '
+                                    'saved gates), fp32 state, accumulation and recurrence; NOT within the 1e-4 parity bar'}
+        finally:
+            L.set_gemm_mode(1)
+
     # train() as a user calls it: the script's own epoch loop over a host-resident corpus of 4 mini-batches (features uploaded
     # once and gathered on the device, labels / loss.item() / accuracy count per step as in the reference)
     train_e2e = None
@@ -515,7 +540,7 @@ def main():
     if eval_ms is not None:
         out['eval_forward'] = {'value': round(B / (eval_ms * 1e-3), 1), 'unit': 'utterances/s', 'ms_per_batch': round(eval_ms, 3),
                                'note': 'forward only (evaluate), rank 0, outside the headline region'}
-    out['extra'] = {'f32_exact': f32_exact, 'bf16_products': bf16_products, 'train_e2e': train_e2e, 'comm_alone_ms_per_step_by_rank': comm_alone, 'exposed_comm': exposed,
+    out['extra'] = {'f32_exact': f32_exact, 'bf16_products': bf16_products, 'bf16_storage': bf16_storage, 'train_e2e': train_e2e, 'comm_alone_ms_per_step_by_rank': comm_alone, 'exposed_comm': exposed,
                     'other_workloads': other,
                     'precision_note': 'storage, state, accumulation and elementwise math fp32; products of the large contractions '
                                       'and of the recurrent sweeps: 3-term bf16 split on the bf16 matrix cores (DEP_GEMM_MODE=f32 = exact)'}

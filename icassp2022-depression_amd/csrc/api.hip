@@ -91,6 +91,7 @@ struct Layout {
     bool cluster16;                  // forward with 16-unit members, two workgroups per CU (rnn_cluster16.hip)
     bool dg4;                        // GRU cluster backward: gate gradients as ONE (B*T, 4H) array [dr | dz | dn | dn*r] (dW_hh is then one contraction)
     bool cluster16_bwd;              // same for the backward (slower than 32-unit members: A/B only, DEP_CLUSTER16_BWD=1)
+    bool bf16st;                     // dep_set_gemm_mode(3) on a stack whose kernels have the bf16-storage variants (2-layer GRU, H = 256, fused forward): y, hn as bf16, gate gradients as PKH
     bool sv16;                       // GRU cluster sweeps: saved gates r, z, n as 16-bit fixed point (split-precision mode only; decided per call)
     bool fused2;                     // 2-layer GRU, H = 256: both layers in one launch (rnn_fused2.hip), split-precision mode only
     size_t wih_img;                  // workspace: packed W_ih of layer 1 for the fused forward
@@ -191,6 +192,11 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
         if (fb_env < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fb_env = (e && e[0] == '1') ? 1 : 0; }
         lo.sv16 = sv_env && d->training && lo.cluster &&
                   (d->cell == DEP_CELL_GRU ? (!fb_env && !lo.cluster16_bwd && (lo.fused2 || !lo.cluster16)) : dep_cluster_lstm_sv16_ok());
+        // bf16-STORAGE mode (dep_set_gemm_mode(3); a labelled throughput mode, never the parity path): only where every kernel of the
+        // stack has the variant -- the fused 2-layer GRU forward and the burst backward with the 4H-wide gate-gradient rows.  Other
+        // stacks run mode 3 exactly like mode 2 (single bf16 products, fp32 storage).
+        lo.bf16st = dep_get_gemm_mode() == 3 && lo.sv16 && lo.fused2 && lo.dg4 && d->cell == DEP_CELL_GRU && d->T % 2 == 0 &&
+                    dep_cluster_bwd_pk_ok(d->H, d->T);
     }
     return true;
 }
@@ -310,7 +316,12 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     // the recurrent-weight images packed below are precision-mode specific: remember which mode this reserve holds
     // bit 0: precision mode; bit 1: the backward image is the 16-unit-member one (a caller flipping DEP_CLUSTER16_BWD is refused too)
     const bool sv16 = lo.sv16 && sweep_split_mode();      // (exact-fp32 mode keeps fp32 gates: its 16-unit-member forward has no 16-bit path)
-    record_reserve_mode(reserve, (sweep_split_mode() ? 1 : 0) | (lo.cluster16_bwd ? 2 : 0) | (sv16 ? 4 : 0));
+    if (lo.bf16st && (!excl || y)) {
+        dep_set_error("dep_rnn_forward: bf16-storage mode (dep_set_gemm_mode(3)) runs the exclusive fused forward only (dep_rnn_set_exclusive(1)) "
+                      "and has no fp32 copy of the output sequence (y must be NULL)");
+        return DEP_ERR_ARG;
+    }
+    record_reserve_mode(reserve, (sweep_split_mode() ? 1 : 0) | (lo.cluster16_bwd ? 2 : 0) | (sv16 ? 4 : 0) | (lo.bf16st ? 8 : 0));
     if (lo.fused2 && sweep_split_mode() && excl) {
         // both layers in one launch: layer 1 runs one step behind layer 0 and takes its input straight from the exchanged
         // h0_t (no layer-1 input-projection GEMM, no GI round trip through HBM for it)
@@ -340,8 +351,8 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         f.hn0 = h_n; f.hn1 = h_n ? h_n + (size_t)B * H : nullptr;
         for (int l = 0; l < 2; ++l) for (int k = 0; k < 4; ++k) f.sv[l][k] = d->training ? R + lo.sv[l][k] : nullptr;
         f.stream = s;
-        f.soft_fallback = 1;
-        f.sv16 = sv16 ? 1 : 0;
+        f.soft_fallback = lo.bf16st ? 0 : 1;           // (the tolerant per-layer kernels have no bf16-storage variant: a failed hello raises the status)
+        f.sv16 = sv16 ? 1 : 0; f.bf16st = lo.bf16st ? 1 : 0;
         f.hdr_clean = 1;                                   // dep_cluster_reset_status above zeroed every header slot
         rc = dep_launch_fused2_fwd(f, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
         // Fallback, decided ON THE DEVICE (no host synchronisation, identical on every data-parallel rank): the launch above
@@ -350,7 +361,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
         // at entry unless the flag is set (3 near-empty launches per forward, ~10 us); they write the same reserve layout, so
         // the backward does not care which of the two produced it.
         const unsigned* soft = reinterpret_cast<const unsigned*>(W + lo.xbuf) + 1;
-        for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < 2 && !lo.bf16st; ++l) {
             const float* const* wl = l == 0 ? w0 : w1;
             if (l == 1) {
                 const float* in = lo.drop ? R + lo.ydrop[0] : R + lo.y[0];
@@ -496,6 +507,10 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
                           (fm & 1) ? "bf16x3" : "f32", (fm & 1) ? "f32" : "bf16x3");
             return DEP_ERR_ARG;
         }
+        if (fm >= 0 && ((fm >> 3) & 1) != (lo.bf16st ? 1 : 0)) {
+            dep_set_error("dep_rnn_backward: the reserve was %swritten in bf16-storage mode (dep_set_gemm_mode(3)), this call runs in the other", (fm & 8) ? "" : "not ");
+            return DEP_ERR_ARG;
+        }
         if (fm >= 0 && ((fm >> 2) & 1) != ((lo.sv16 && sweep_split_mode()) ? 1 : 0)) {
             dep_set_error("dep_rnn_backward: the reserve holds %s saved gates, this call expects the other format (DEP_SV16 / DEP_EXCLUSIVE changed?)",
                           (fm & 4) ? "16-bit" : "fp32");
@@ -595,7 +610,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         if (pk_env < 0) { const char* e = getenv("DEP_DGI_PK"); pk_env = (e && e[0] == '0') ? 0 : 1; }
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         float* dxl_probe = l == 0 ? dx : W + lo.dx[l & 1];
-        const bool pk_gru = pk_env && lo.dg4 && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && a.split && dep_get_gemm_mode() == 1 &&
+        const bool pk_gru = pk_env && lo.dg4 && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && a.split && (dep_get_gemm_mode() == 1 || lo.bf16st) &&
                         dep_cluster_bwd_pk_ok(H, T) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(weights[(size_t)l * 4]) &&
                         al16(dweights[(size_t)l * 4]) && al16(dweights[(size_t)l * 4 + 1]) &&
                         dep_gemm_uses_bf16x3(G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(3 * H, H, BTr, T) &&
@@ -608,6 +623,12 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         for (int dd = 0; dd < D && pk_lstm; ++dd) pk_lstm = al16(dweights[(size_t)(l * D + dd) * 4 + 1]);
         const bool pk = pk_gru || pk_lstm;
         a.dg_pk = pk ? 1 : 0;
+        if (lo.bf16st && !pk) {
+            dep_set_error("dep_rnn_backward: bf16-storage mode needs the pre-split gate-gradient path (aligned operands, DEP_DGI_PK not 0, contractions above the split threshold)");
+            return DEP_ERR_ARG;
+        }
+        a.bf16st = lo.bf16st ? 1 : 0;
+        const int fmt_a = lo.bf16st ? 2 : 1;                       // FMT_PKH / FMT_PK (gemm_bf16x3.hip)
         a.sv16 = (lo.sv16 && sweep_split_mode() && lo.cluster && (d->cell == DEP_CELL_LSTM || !lo.cluster16_bwd)) ? 1 : 0;
         struct FmtGuard { bool on; ~FmtGuard() { if (on) dep_gemm_set_operand_formats(0, 0); } } fmt_guard{pk};
         rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
@@ -631,7 +652,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         }
         rc = dep_finish_db(a, dbi, dbh);
         if (rc) return rc;
-        if (pk) dep_gemm_set_operand_formats(1, 0);               // A = the PK gate gradients in dX, dW_ih and dW_hh below (reset by fmt_guard)
+        if (pk) dep_gemm_set_operand_formats(fmt_a, 0);           // A = the PK gate gradients in dX, dW_ih and dW_hh below (reset by fmt_guard)
         float* dxl = l == 0 ? dx : W + lo.dx[l & 1];
         // dX (B*T, Kl) (+)= dG * W_ih first: it is the only product the next layer's sweep waits for
         const bool stacked = D == 2 && lo.wstack[l] != 0;
@@ -664,9 +685,11 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
             const float* dg = dgi + (size_t)dd * G * H;
             // dW_ih (G*H, Kl) = dG^T * in
             if (!stacked) {
+                if (lo.bf16st && l > 0) dep_gemm_set_operand_formats(fmt_a, 3);          // the layer below's (dropped) output is a bf16 array
                 rc = dep_gemm_internal(1, 0, G * H, Kl, BTr, dg, ldg, in, Kl, gl[0], Kl, nullptr, 0.f, 0, 0, gws, gwsb, s);
                 if (rc) return rc;
             }
+            if (lo.bf16st) dep_gemm_set_operand_formats(fmt_a, 3);                       // dW_hh: B = this layer's bf16 output, shifted one step
             // dW_hh (G*H, H) = dGH^T * h_prev   (h_prev = layer output shifted by one step along the sweep)
             const float* yl = R + lo.y[l] + (size_t)dd * H;
             const int shift = dd == 0 ? -1 : 1;

@@ -158,6 +158,7 @@ struct dep_sweep_bwd_args {
     int hdr_slot, hdr_clean; // cluster sweeps: exchange-header slot of this launch; clean = the caller zeroed it
     int sv16;                // saved gates r, z, n are 16-bit fixed point (must match the forward that wrote them)
     int dg_pk;               // GRU cluster sweep (burst kernel, 4H-wide rows): dgi / dghn as the PK image of gemm_bf16x3.hip instead of fp32
+    int bf16st;              // bf16-storage mode (dep_set_gemm_mode(3)): y and hn are bf16 arrays, the gate gradients the PKH image (hi rows only)
     hipStream_t stream;
 };
 bool dep_cluster_bwd_pk_ok(int H, int T);
@@ -199,6 +200,7 @@ struct dep_fused2_args {
     float* pooled; float pool_scale; float* hn0; float* hn1;
     float* sv[2][4];
     int sv16;                                                 // saved gates r, z, n as 16-bit fixed point (rnn_cluster_common.h)
+    int bf16st;                                               // bf16-storage mode: h, dropout(h), hn are written as bf16 (2-byte elements at the same positions)
     int soft_fallback;                                        // 1: a failed hello sets the workspace's soft flag instead of the status word
     int hdr_clean;                                            // slot 0 was zeroed by the caller (dep_cluster_reset_status)
     hipStream_t stream;

@@ -323,10 +323,10 @@ void dep_gemm_set_predicate(const unsigned* only_if) { g_only_if = only_if; }
 const unsigned* dep_gemm_predicate() { return g_only_if; }
 static thread_local int g_force_exact = 0;       // per calling thread: 1 = this call is exact fp32, 2 = this call is bf16x3 whatever the global mode
 static void init_split_mode() {
-    if (g_split_mode < 0) { const char* e = getenv("DEP_GEMM_MODE"); g_split_mode = (e && e[0] == 'f') ? 0 : ((e && !strcmp(e, "bf16")) ? 2 : 1); }   // "f32" | "bf16" | default ("bf16x3")
+    if (g_split_mode < 0) { const char* e = getenv("DEP_GEMM_MODE"); g_split_mode = (e && e[0] == 'f') ? 0 : ((e && !strcmp(e, "bf16")) ? 2 : ((e && !strcmp(e, "bf16s")) ? 3 : 1)); }   // "f32" | "bf16" | "bf16s" | default ("bf16x3")
 }
 extern "C" int dep_set_gemm_mode(int mode, long min_macs) {
-    if (mode < 0 || mode > 2) { dep_set_error("dep_set_gemm_mode: mode must be 0 (f32), 1 (bf16x3 split) or 2 (bf16 products)"); return DEP_ERR_ARG; }
+    if (mode < 0 || mode > 3) { dep_set_error("dep_set_gemm_mode: mode must be 0 (f32), 1 (bf16x3 split), 2 (bf16 products) or 3 (bf16 products + bf16 storage)"); return DEP_ERR_ARG; }
     g_split_mode = mode;
     if (min_macs >= 0) g_split_min_macs = min_macs;
     return DEP_OK;
@@ -357,7 +357,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     init_split_mode();
     const bool to_split = !naive_forced() && (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs)) &&
                           !(seq_T <= 0 && (long)dep_cdiv(M, BM) * dep_cdiv(N, BN) < 32 && K <= 8192 && (long)M * N * K <= (1L << 27));
-    if (dep_gemm_pk_pending() && !(to_split && g_split_mode != 2)) {
+    if (dep_gemm_pk_pending() && !to_split) {      // (the launcher checks that the format matches the term count)
         dep_set_error("dep_gemm: a pre-split (PK) operand reached a contraction that does not run the three-term bf16x3 kernel");
         return DEP_ERR_ARG;
     }
@@ -398,7 +398,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     init_split_mode();
     if (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs))
         return dep_gemm_bf16x3_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
-                                      splits, kchunk, p.part, vec, s, (g_force_exact != 2 && g_split_mode == 2) ? 1 : 3);     // the public bf16x3 entry is always 3 terms
+                                      splits, kchunk, p.part, vec, s, (g_force_exact != 2 && g_split_mode >= 2) ? 1 : 3);     // the public bf16x3 entry is always 3 terms
 #define LAUNCH(TA, TB)                                                                    \
     do {                                                                                   \
         if (vec) hipLaunchKernelGGL((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \

@@ -42,7 +42,12 @@ struct GemmP {
 // i.e. k-pairs packed the way the LDS planes want them when the ROW index is the contraction index (TN forms: zero VALU per
 // element, the four loaded rows of a thread ARE hi01, lo01, hi23, lo23); when the row index is M (NN / NT A operand) a thread
 // loads both rows of a pair and separates the halves with one v_perm_b32 per element.  Bit-identical to the on-the-fly split.
-enum { FMT_F32 = 0, FMT_PK = 1 };
+// bf16-STORAGE mode (dep_set_gemm_mode(3), single products only, never the parity path):
+//   FMT_PKH : the PK image with ONLY its hi rows written (rows 2j: bf16 pairs of logical rows 2j, 2j+1; rows 2j+1 unused) -- the gate
+//             gradients as bf16 with the k-pairs already packed: half the operand bytes, nothing to convert
+//   FMT_BF16: a plain row-major bf16 array (ld counted in bf16 elements) -- the hidden sequences y / dropout(y) as the B operand of
+//             the TN contractions (rows may be shifted: dW_hh)
+enum { FMT_F32 = 0, FMT_PK = 1, FMT_PKH = 2, FMT_BF16 = 3 };
 
 
 // Operand tile of ROWS (128 or 256) rows x 32 k, 256 threads: a = tid&7, bq = tid>>3.
@@ -55,8 +60,9 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     if (!TR) {
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
-            // FMT_PK: slots 2j / 2j+1 are the hi-pair / lo-pair rows of logical rows (R, R+1), R = mn0 + 2 bq + 64 j
-            const int mn = FMT == FMT_PK ? mn0 + 2 * bq + 64 * (i >> 1) + (i & 1) : mn0 + bq + 32 * i, k = k0 + a * 4;
+            // FMT_PK: slots 2j / 2j+1 are the hi-pair / lo-pair rows of logical rows (R, R+1), R = mn0 + 2 bq + 64 j  (FMT_PKH: the hi row only)
+            if (FMT == FMT_PKH && (i & 1)) continue;
+            const int mn = (FMT == FMT_PK || FMT == FMT_PKH) ? mn0 + 2 * bq + 64 * (i >> 1) + (i & 1) : mn0 + bq + 32 * i, k = k0 + a * 4;
             const float* src = P + (size_t)mn * ld + k;
             if (VEC) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -72,13 +78,18 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
         for (int jj = 0; jj < ROWS / 128; ++jj)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (FMT == FMT_PKH && (i & 1)) continue;      // the lo rows are not there
                 const int k = k0 + a * 4 + i, mn = mn0 + (bq + 32 * jj) * 4;
                 bool ok = k < Kend;
                 if (seqT > 0) { const int tt = k % seqT + shift; ok = ok && tt >= 0 && tt < seqT; }
                 // column skip: skip_at is a multiple of the tile's 4-column pieces, so a piece never straddles it
                 const float* src = P + ((long)k + shift) * ld + mn + ((skip_by && mn >= skip_at) ? skip_by : 0);
                 float (&rr)[4] = r[jj * 4 + i];
-                if (VEC) {
+                if (FMT == FMT_BF16) {                        // four bf16 of row k: 8 bytes -> rr[0], rr[1]
+                    float2 v = {0.f, 0.f};
+                    if (ok && mn < MN) v = *reinterpret_cast<const float2*>(reinterpret_cast<const unsigned short*>(P) + ((long)k + shift) * ld + mn);
+                    rr[0] = v.x; rr[1] = v.y;
+                } else if (VEC) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (ok && mn < MN) v = *reinterpret_cast<const f32x4*>(src);
                     rr[0] = v[0]; rr[1] = v[1]; rr[2] = v[2]; rr[3] = v[3];
@@ -133,7 +144,21 @@ __device__ __forceinline__ void hi4(f32x4 x, bf16x4& hi) {
 template <bool TR, int ROWS, int TERMS = 3, int FMT = FMT_F32>
 __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, const float (&r)[ROWS / 32][4]) {
     const int a = tid & 7, bq = tid >> 3;
-    if constexpr (FMT == FMT_PK && TR) {
+    if constexpr (FMT == FMT_BF16) {
+        static_assert(TR && TERMS == 1, "FMT_BF16: MN-contiguous operand of the single-product kernel");
+        // rows k0 + 4a + i (i < 4) of four columns, two bf16 per word: column e sits in half e & 1 of word e >> 1
+#pragma unroll
+        for (int jj = 0; jj < ROWS / 128; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                const unsigned w0 = __float_as_uint(r[jj * 4 + 0][e >> 1]), w1 = __float_as_uint(r[jj * 4 + 1][e >> 1]);
+                const unsigned w2 = __float_as_uint(r[jj * 4 + 2][e >> 1]), w3 = __float_as_uint(r[jj * 4 + 3][e >> 1]);
+                const u32x2v h = {__builtin_amdgcn_perm(w1, w0, sel), __builtin_amdgcn_perm(w3, w2, sel)};
+                *reinterpret_cast<u32x2v*>(Sh + ((bq + 32 * jj) * 4 + e) * LDK + a * 4) = h;
+            }
+    } else if constexpr ((FMT == FMT_PK || FMT == FMT_PKH) && TR) {
+        static_assert(FMT != FMT_PKH || TERMS == 1, "FMT_PKH carries no lo planes");
         // rows k0 + 4a + {0,1,2,3} of a thread = hi(k, k+1), lo(k, k+1), hi(k+2, k+3), lo(k+2, k+3) of its four columns: nothing to compute
 #pragma unroll
         for (int jj = 0; jj < ROWS / 128; ++jj)
@@ -141,21 +166,24 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
             for (int e = 0; e < 4; ++e) {
                 const int o = ((bq + 32 * jj) * 4 + e) * LDK + a * 4;
                 const u32x2v h = {__float_as_uint(r[jj * 4 + 0][e]), __float_as_uint(r[jj * 4 + 2][e])};
-                const u32x2v l = {__float_as_uint(r[jj * 4 + 1][e]), __float_as_uint(r[jj * 4 + 3][e])};
                 *reinterpret_cast<u32x2v*>(Sh + o) = h;
-                if constexpr (TERMS == 3) *reinterpret_cast<u32x2v*>(Sl + o) = l;
+                if constexpr (TERMS == 3) {
+                    const u32x2v l = {__float_as_uint(r[jj * 4 + 1][e]), __float_as_uint(r[jj * 4 + 3][e])};
+                    *reinterpret_cast<u32x2v*>(Sl + o) = l;
+                }
             }
-    } else if constexpr (FMT == FMT_PK) {
+    } else if constexpr (FMT == FMT_PK || FMT == FMT_PKH) {
+        static_assert(FMT != FMT_PKH || TERMS == 1, "FMT_PKH carries no lo planes");
         // slots 2j / 2j+1 = hi-pair / lo-pair rows of logical rows (R, R+1): low halves belong to R, high halves to R+1
 #pragma unroll
         for (int j = 0; j < ROWS / 64; ++j) {
             const unsigned h0 = __float_as_uint(r[2 * j][0]), h1 = __float_as_uint(r[2 * j][1]), h2 = __float_as_uint(r[2 * j][2]), h3 = __float_as_uint(r[2 * j][3]);
-            const unsigned l0 = __float_as_uint(r[2 * j + 1][0]), l1 = __float_as_uint(r[2 * j + 1][1]), l2 = __float_as_uint(r[2 * j + 1][2]), l3 = __float_as_uint(r[2 * j + 1][3]);
             const int o = (2 * bq + 64 * j) * LDK + a * 4;
             const u32x2v he = {__builtin_amdgcn_perm(h1, h0, 0x05040100u), __builtin_amdgcn_perm(h3, h2, 0x05040100u)};
             const u32x2v ho = {__builtin_amdgcn_perm(h1, h0, 0x07060302u), __builtin_amdgcn_perm(h3, h2, 0x07060302u)};
             *reinterpret_cast<u32x2v*>(Sh + o) = he; *reinterpret_cast<u32x2v*>(Sh + o + LDK) = ho;
             if constexpr (TERMS == 3) {
+                const unsigned l0 = __float_as_uint(r[2 * j + 1][0]), l1 = __float_as_uint(r[2 * j + 1][1]), l2 = __float_as_uint(r[2 * j + 1][2]), l3 = __float_as_uint(r[2 * j + 1][3]);
                 const u32x2v le = {__builtin_amdgcn_perm(l1, l0, 0x05040100u), __builtin_amdgcn_perm(l3, l2, 0x05040100u)};
                 const u32x2v lo = {__builtin_amdgcn_perm(l1, l0, 0x07060302u), __builtin_amdgcn_perm(l3, l2, 0x07060302u)};
                 *reinterpret_cast<u32x2v*>(Sl + o) = le; *reinterpret_cast<u32x2v*>(Sl + o + LDK) = lo;
@@ -719,7 +747,12 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     if (fa != FMT_F32 || fb != FMT_F32) {
         // pre-split operands: vector loads, three-term products; a PK operand pairs ROWS, so its row count must be even, the
         // contraction index (TN) must start on even rows (k-chunks are multiples of 32) and a row-shifted operand cannot be PK
-        DEP_CHECK_ARG(vec && terms == 3 && fa == FMT_PK && (fb == FMT_F32 || (fb == FMT_PK && transA && !transB && shiftB == 0)));
+        if (fa == FMT_PKH || fb == FMT_BF16) {
+            // bf16-storage mode: single products; A = PKH gate gradients (TN / NN), B = fp32 or (TN only) a row-major bf16 sequence
+            DEP_CHECK_ARG(vec && terms == 1 && fa == FMT_PKH && !(!transA && transB) && (fb == FMT_F32 || (fb == FMT_BF16 && transA)));
+        } else {
+            DEP_CHECK_ARG(vec && terms == 3 && fa == FMT_PK && (fb == FMT_F32 || (fb == FMT_PK && transA && !transB && shiftB == 0)));
+        }
         DEP_CHECK_ARG(transA ? (K % 2 == 0 && kchunk % 2 == 0) : (M % 2 == 0));
     }
     if (wsd > 0 && fa == FMT_F32 && fb == FMT_F32 && terms == 3 && M >= 256 && !(transA && g_skip_by) && spanA < (1ull << 32) && spanB < (1ull << 32)) {
@@ -776,7 +809,16 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     } while (0)
 #define LAUNCH(TA, TB) do { if (terms == 1) LAUNCH1(TA, TB, 1); else LAUNCH1(TA, TB, 3); } while (0)
 #define LAUNCH_PK(TA, TB, BM, FA_, FB_) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, BM, 3, FA_, FB_>), g, dim3(NT), 0, s, p)
-    if (fa == FMT_PK) {
+#define LAUNCH_H(TA, TB, BM, FB_) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, BM, 1, FMT_PKH, FB_>), g, dim3(NT), 0, s, p)
+    if (fa == FMT_PKH) {
+        if (transA) {
+            if (big) { if (fb == FMT_BF16) LAUNCH_H(true, false, 256, FMT_BF16); else LAUNCH_H(true, false, 256, FMT_F32); }
+            else     { if (fb == FMT_BF16) LAUNCH_H(true, false, 128, FMT_BF16); else LAUNCH_H(true, false, 128, FMT_F32); }
+        } else {
+            if (big) LAUNCH_H(false, false, 256, FMT_F32); else LAUNCH_H(false, false, 128, FMT_F32);
+        }
+    }
+    else if (fa == FMT_PK) {
         if (transA) {
             if (big) { if (fb == FMT_PK) LAUNCH_PK(true, false, 256, FMT_PK, FMT_PK); else LAUNCH_PK(true, false, 256, FMT_PK, FMT_F32); }
             else     { if (fb == FMT_PK) LAUNCH_PK(true, false, 128, FMT_PK, FMT_PK); else LAUNCH_PK(true, false, 128, FMT_PK, FMT_F32); }
@@ -790,6 +832,7 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     else if (!transA && !transB) LAUNCH(false, false);
     else LAUNCH(true, false);
 #undef LAUNCH_PK
+#undef LAUNCH_H
 #undef LAUNCH
 #undef LAUNCH1
     DEP_CHECK_LAUNCH();

@@ -69,8 +69,11 @@ constexpr size_t burst_lds_bytes(int KB) { return (size_t)(IBUF_F + KB * 6 * SAR
 // SV16: the saved gates r, z, n are 16-bit fixed point (rnn_cluster_common.h).  A template parameter, not a kernel argument: as a
 // run-time switch the two load widths met in copies of the loaded registers and the service waves waited for every load they had
 // just issued (both settings 5-20 % slower than the kernel without the switch, profiles/r04_ab_pairs.txt).
-template <int NTW, bool SPLIT, int KB, bool SV16 = false>      // output tiles per wave = H/64
+// BF (bf16-storage mode, dep_set_gemm_mode(3); implies SV16, burst kernel only): hn and the hidden sequence y are bf16 arrays (2-byte
+// elements at the same positions), and the gate gradients go out as the PKH image (only the hi rows of the PK image).
+template <int NTW, bool SPLIT, int KB, bool SV16 = false, bool BF = false>      // output tiles per wave = H/64
 __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1(P2 p) {
+    static_assert(!BF || (SV16 && KB > 0), "bf16 storage: 16-bit gates, burst kernel");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 96, KCB = KS / 16, LDG = KS + LPAD;
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane (208-byte rows)
@@ -195,11 +198,12 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     // bases one row in front of the tile's first row (h_{t-1} of t = 0 is never read; the offset stays non-negative)
     // (the 16-bit arrays of the SV16 wave pair have 2-byte elements: their rows are H / 2 floats apart)
     const bool w16 = SV16 && sodd;
-    const float* const in0_t = sbase0 ? (w16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(sbase0) + trow0 * H) : sbase0 + trow0 * H) : nullptr;
-    const float* const in1_t = sbase1 ? (w16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(sbase1) + trow0 * H)
-                                             : sbase1 + trow0 * (SV16 ? p.ldy : H)) : nullptr;
-    const float* const in2_t = sbase2 ? (w16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(sbase2) + trow0 * H)
-                                             : sbase2 + trow0 * (SV16 ? p.lddy : sld2)) : nullptr;
+    // byte offset of the tile's first row in each of this wave's three input arrays (element size x row stride)
+    const size_t es0 = (w16 || BF) ? 2 : 4, es1 = (w16 || BF) ? 2 : 4, es2 = w16 ? 2 : 4;
+    const size_t rs1 = SV16 ? (sodd ? (size_t)H : (size_t)p.ldy) : (size_t)H, rs2 = SV16 ? (sodd ? (size_t)H : (size_t)p.lddy) : (size_t)sld2;
+    const float* const in0_t = sbase0 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase0) + trow0 * H * es0) : nullptr;
+    const float* const in1_t = sbase1 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase1) + trow0 * rs1 * es1) : nullptr;
+    const float* const in2_t = sbase2 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase2) + trow0 * rs2 * es2) : nullptr;
     __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc((void*)in0_t, 0, span, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc((void*)in1_t, 0, span, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void*)in2_t, 0, span, 0x00020000);
@@ -236,9 +240,19 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                 const f32x4 r4 = {w.x, w.y, 0.f, 0.f};
                 return r4;
             } else {
-                if (i == 0) return ldnt(NT, 0, sbase0 + row * H + scol);
-                if (i == 1) return t > 0 ? ldnt(NT, 1, sbase1 + (row - 1) * p.ldy + scol) : zero4();
-                return sbase2 ? ldnt(NT, 2, sbase2 + row * p.lddy + scol) : zero4();
+                if constexpr (BF) {                           // hn, h_{t-1}: bf16 arrays, four values = 8 bytes (decoded in svc_put)
+                    if (i == 0) { const float2 w = ldnt8(NT, 0, reinterpret_cast<const unsigned short*>(sbase0) + row * H + scol); const f32x4 r4 = {w.x, w.y, 0.f, 0.f}; return r4; }
+                    if (i == 1) {
+                        if (t <= 0) return zero4();
+                        const float2 w = ldnt8(NT, 1, reinterpret_cast<const unsigned short*>(sbase1) + (row - 1) * p.ldy + scol);
+                        const f32x4 r4 = {w.x, w.y, 0.f, 0.f}; return r4;
+                    }
+                    return sbase2 ? ldnt(NT, 2, sbase2 + row * p.lddy + scol) : zero4();
+                } else {
+                    if (i == 0) return ldnt(NT, 0, sbase0 + row * H + scol);
+                    if (i == 1) return t > 0 ? ldnt(NT, 1, sbase1 + (row - 1) * p.ldy + scol) : zero4();
+                    return sbase2 ? ldnt(NT, 2, sbase2 + row * p.lddy + scol) : zero4();
+                }
             }
         } else {
             if (i == 0) return ldnt(NT, 0, sbase0 + row * H + scol);
@@ -268,6 +282,10 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                             const float2 a = i < 2 ? unpack_unorm2(w0) : unpack_snorm2(w0), b = i < 2 ? unpack_unorm2(w1) : unpack_snorm2(w1);
                             const f32x4 v = {a.x, a.y, b.x, b.y};
                             *reinterpret_cast<f32x4*>(dst + i * SARR) = v;
+                        } else if (BF && i < 2) {               // bf16 pairs -> fp32 (the value sits in the upper half)
+                            const unsigned w0 = __float_as_uint(sreg[d][i][0]), w1 = __float_as_uint(sreg[d][i][1]);
+                            const f32x4 v = {__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
+                            *reinterpret_cast<f32x4*>(dst + (3 + i) * SARR) = v;
                         } else {
                             *reinterpret_cast<f32x4*>(dst + (3 + i) * SARR) = sreg[d][i];
                         }
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                 for (int e = 0; e < 4; ++e) { unsigned hh, ll; split_pair(xe[e], xo[e], hh, ll); h[e] = hh; l[e] = ll; }
                 float* g = p.dgi + row * p.lddg + ao * H + scol;                 // 4H-wide rows [dr | dz | dn | dn*r]
                 stnt2(rs_dgi, dgi_t, g, __builtin_bit_cast(f32x4, h));
-                stnt2(rs_dgi, dgi_t, g + p.lddg, __builtin_bit_cast(f32x4, l));
+                if constexpr (!BF) stnt2(rs_dgi, dgi_t, g + p.lddg, __builtin_bit_cast(f32x4, l));      // (PKH: the hi rows only)
             }
         }
     };
@@ -903,6 +921,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.dgi = a.dgi; p.lddg = a.lddg ? a.lddg : 3 * a.H; p.dghn = a.dghn; p.lddghn = a.lddghn ? a.lddghn : a.H; p.dbpart = a.dbpart;
     p.dgpk = a.dg_pk;
     DEP_CHECK_ARG(!a.sv16 || a.split);               // the 16-bit saved gates exist in split-precision mode only
+    DEP_CHECK_ARG(!a.bf16st || (a.H == 256 && a.split && a.sv16 && a.dg_pk));      // bf16-storage mode: H = 256, burst kernel (checked below via dg_pk)
     DEP_CHECK_ARG(a.dbpart_rows >= nbt);
     const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
     DEP_CHECK_ARG(PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 256);
@@ -932,6 +951,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     if (!attr_b) {
 #define DEP_BWD_ATTR1(N, S, V, X) (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<N, S, V, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((V ? burst_lds_bytes(V) > EXCLUSIVE_LDS ? burst_lds_bytes(V) : EXCLUSIVE_LDS : EXCLUSIVE_LDS) + 2048))
 #define DEP_BWD_ATTR(N, S, V) do { DEP_BWD_ATTR1(N, S, V, false); if (S) DEP_BWD_ATTR1(N, true, V, true); } while (0)
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((burst_lds_bytes(4) > EXCLUSIVE_LDS ? burst_lds_bytes(4) : EXCLUSIVE_LDS) + 2048));
         DEP_BWD_ATTR(1, false, 0); DEP_BWD_ATTR(1, true, 0); DEP_BWD_ATTR(1, false, 4); DEP_BWD_ATTR(1, true, 4); DEP_BWD_ATTR(1, false, 6); DEP_BWD_ATTR(1, true, 6);
         DEP_BWD_ATTR(2, false, 0); DEP_BWD_ATTR(4, false, 0); DEP_BWD_ATTR(2, true, 0); DEP_BWD_ATTR(4, true, 0);
         DEP_BWD_ATTR(2, false, 4); DEP_BWD_ATTR(4, false, 4); DEP_BWD_ATTR(2, true, 4); DEP_BWD_ATTR(4, true, 4);
@@ -959,7 +979,10 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         switch (a.H) {                                // NTW = H / 64
             case 64: if (a.split) DEP_BWD_LAUNCH(1, true); else DEP_BWD_LAUNCH(1, false); break;
             case 128: if (a.split) DEP_BWD_LAUNCH(2, true); else DEP_BWD_LAUNCH(2, false); break;
-            case 256: if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false); break;
+            case 256:
+                if (a.bf16st) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, true>), grid, block, lds, a.stream, p);
+                else if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false);
+                break;
             default:                                  // 512: round-1 schedule only (kb == 0)
                 if (a.split && a.sv16) hipLaunchKernelGGL((gru_bwd_cluster_r1<8, true, 0, true>), grid, block, lds, a.stream, p);
                 else if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<8, true, 0>), grid, block, lds, a.stream, p);

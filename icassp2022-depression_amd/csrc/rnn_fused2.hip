@@ -61,8 +61,11 @@ __device__ __forceinline__ float2 add2(float2 a, float2 b) { return make_float2(
 // scratch reload in the streaming waves waits on vmcnt, i.e. on their outstanding HBM stores: 10k cycles per step measured).
 // SV16 (saved gates r, z, n as 16-bit fixed point) is a template parameter: as a run-time switch the write-out's two store widths
 // cost the launch 4 % (profiles/r04_ab_pairs.txt).
-template <bool DROP, bool TRACE, bool SV16>
+// BF (bf16-storage mode, implies SV16): h, dropout(h) and hn are written as bf16 too (2-byte elements at the same positions of their
+// arrays); the recurrence itself is unchanged -- the exchanged h words keep both split planes.
+template <bool DROP, bool TRACE, bool SV16, bool BF = false>
 __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
+    static_assert(!BF || SV16, "bf16 storage implies 16-bit gates");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
@@ -154,9 +157,12 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             const float* ob = obuf + su * OROW;
             const unsigned e0 = so + (unsigned)s * FH, e1 = so + (unsigned)(s - 2) * FH;
             const size_t os = p.ostride;
-            auto st16 = [&](float* arr, unsigned e, int a) { *reinterpret_cast<f32x4*>(arr + e) = ld4(ob + a * OARR + sqd * 4); };
             auto stg = [&](float* arr, unsigned e, int a) {       // a gate array: packed 16-bit words (SV16) or fp32
                 if constexpr (SV16) *reinterpret_cast<float2*>(reinterpret_cast<unsigned short*>(arr) + e) = ld2(ob + a * OARR + sqd * 2);
+                else *reinterpret_cast<f32x4*>(arr + e) = ld4(ob + a * OARR + sqd * 4);
+            };
+            auto st16 = [&](float* arr, unsigned e, int a) {      // h, dropout(h), hn: fp32, or (BF) packed bf16 pairs like the gates
+                if constexpr (BF) stg(arr, e, a);
                 else *reinterpret_cast<f32x4*>(arr + e) = ld4(ob + a * OARR + sqd * 4);
             };
             if (shalf == 0) {                         // obuf arrays 0 h0, 2 z0, 4 hn0, 6 h1, 8 z1, 10 hn1
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                 // non-temporal: one-touch write-out that allocates in L2 evicts the exchange payload (tools/micro/l2wb.hip)
                 __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xfffffff0u, 0x00020000);
                 const unsigned eo = (unsigned)slot * p.ostride + so + (unsigned)t * FH;       // element offset inside the layer's arrays (< 2^30: host check)
-                if (SV16 && k >= 1 && k <= 3) {
+                if (BF || (SV16 && k >= 1 && k <= 3)) {
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     const float2 q = ld2(obuf + a * OARR + su * OROW + sqd * 2);
                     const u32x2 qv = {__float_as_uint(q.x), __float_as_uint(q.y)};
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                 }
             } else if (on) {
                 float* arr = base + (size_t)slot * p.ostride;
-                if (SV16 && k >= 1 && k <= 3) {
-                    // r, z (unorm16), n (snorm16): the gate threads left them PACKED in obuf (two units per word, 16 words per
+                if (BF || (SV16 && k >= 1 && k <= 3)) {
+                    // r, z (unorm16), n (snorm16) [BF: every array, as bf16]: the gate threads left them PACKED in obuf (two units per word, 16 words per
                     // utterance row) -- four values = one 8-byte copy, no arithmetic in this group (it is the busiest one)
                     const float2 q = ld2(obuf + a * OARR + su * OROW + sqd * 2);
                     *reinterpret_cast<float2*>(reinterpret_cast<unsigned short*>(arr) + (so + (unsigned)t * FH)) = q;
@@ -336,7 +342,14 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                 }
             }
             float* ob = obuf + grp * (6 * OARR) + j * OROW + ul;            // results for the streaming waves
-            st2(ob, h); st2(ob + 4 * OARR, hn);
+            if constexpr (BF) {                           // bf16 pairs, one word per unit pair
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+                float* o16 = obuf + grp * (6 * OARR) + j * OROW + (ul >> 1);
+                const f2v hv = {h.x, h.y}, nv = {hn.x, hn.y};
+                o16[0] = __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(hv, b2v)));
+                o16[4 * OARR] = __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(nv, b2v)));
+            } else { st2(ob, h); st2(ob + 4 * OARR, hn); }
             if constexpr (SV16) {                         // 16-bit fixed point, one word per unit pair (rnn_cluster_common.h)
                 float* o16 = obuf + grp * (6 * OARR) + j * OROW + (ul >> 1);
                 o16[OARR] = __uint_as_float(pack_unorm2(r.x, r.y)); o16[2 * OARR] = __uint_as_float(pack_unorm2(z.x, z.y));
@@ -344,7 +357,14 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             } else {
                 st2(ob + OARR, r); st2(ob + 2 * OARR, z); st2(ob + 3 * OARR, n);
             }
-            if (DROP && grp == 0) st2(ob + 5 * OARR, hd);
+            if (DROP && grp == 0) {
+                if constexpr (BF) {
+                    typedef float f2v __attribute__((ext_vector_type(2)));
+                    typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+                    const f2v dv = {hd.x, hd.y};
+                    obuf[j * OROW + (ul >> 1) + 5 * OARR] = __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(dv, b2v)));
+                } else st2(ob + 5 * OARR, hd);
+            }
             // next step's dropout mask: Philox work in the shadow of the payload stores' acknowledgement (the drain below)
             if (DROP && grp == 0 && s + 1 < T) { const float2 mn = draw(tv, s + 1); st1[0] = mn.x; st1[1] = mn.y; }
         }
@@ -454,12 +474,16 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
     p.soft = a.soft_fallback ? (unsigned*)xbuf + 1 : nullptr;
     const bool sv16 = a.training && a.sv16;
+    const bool bf = a.training && a.bf16st;
+    DEP_CHECK_ARG(!bf || sv16);
     { static int nt = -1; if (nt < 0) { const char* e = getenv("DEP_FWD_NT"); nt = (e && e[0] == '1') ? 1 : 0; }      // measured: no effect on this launch (its payload, 0.4 MB per XCD, survives anyway) -> off
       p.ntstore = (nt && (size_t)7 * a.ostride * sizeof(float) < 0xfffffff0ull) ? 1 : 0; }       // a layer's arrays span < 4 GB from its y
     { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; } p.force_soft = fs; }
     static bool attr = false;
     if (!attr) {
 #define F2_ATTR(D, TR, X) (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<D, TR, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES)
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
         F2_ATTR(true, false, false); F2_ATTR(false, false, false); F2_ATTR(true, true, false); F2_ATTR(false, true, false);
         F2_ATTR(true, false, true); F2_ATTR(false, false, true); F2_ATTR(true, true, true); F2_ATTR(false, true, true);
 #undef F2_ATTR
@@ -474,7 +498,10 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
         const dim3 grid(FNC * p.nbtp), blk(FTHREADS);
 #define F2_LAUNCH(D, TR) do { if (sv16) hipLaunchKernelGGL((gru2_fwd_fused<D, TR, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
                               else hipLaunchKernelGGL((gru2_fwd_fused<D, TR, false>), grid, blk, F_LDS_BYTES, a.stream, p); } while (0)
-        if (p.trace) {                                    // DEP_TRACE=1: the stamped variant (tools/trace_fused.py)
+        if (bf) {                                         // bf16-storage mode (never traced)
+            if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+            else hipLaunchKernelGGL((gru2_fwd_fused<false, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+        } else if (p.trace) {                             // DEP_TRACE=1: the stamped variant (tools/trace_fused.py)
             if (drop) F2_LAUNCH(true, true); else F2_LAUNCH(false, true);
         } else {
             if (drop) F2_LAUNCH(true, false); else F2_LAUNCH(false, false);

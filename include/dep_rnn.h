@@ -218,8 +218,14 @@ int dep_gemm(int transA, int transB, int M, int N, int K,
 int dep_gemm_set_xcds(int lo, int n);
 /* mode 2 (DEP_GEMM_MODE=bf16) is the THROUGHPUT mode BASELINE configs[1] calls "bf16": the large contractions form a_hi * b_hi only
  * (plain bf16 products, fp32 accumulation; a third of the MFMAs).  Relative error per product ~4e-3: it cannot meet the path's
- * 1e-4 parity bar, is never the default and is benchmarked on its own labelled line (bench.py extra.bf16_products). */
-int dep_set_gemm_mode(int mode, long min_macs);   /* PROCESS-GLOBAL. mode 0 exact f32 | 1 bf16x3 split | 2 bf16 products ; min_macs < 0 keeps it */
+ * 1e-4 parity bar, is never the default and is benchmarked on its own labelled line (bench.py extra.bf16_products).
+ * mode 3 (DEP_GEMM_MODE=bf16s) adds bf16 STORAGE to mode 2 for the stack whose kernels have the variants (2-layer GRU, H = 256, T even,
+ * the exclusive fused forward): the hidden sequences y / dropout(y), hn and the gate gradients live in the reserve / workspace as bf16
+ * (2-byte elements at the positions of the fp32 arrays; the gate gradients as the hi rows of the PK image), the saved gates as 16-bit
+ * fixed point; state, accumulation and the recurrence stay fp32.  dep_rnn_forward then takes y == NULL only and
+ * dep_rnn_reserve_y_offset points at bf16 data.  Other stacks run mode 3 exactly like mode 2.  Gradients within ~1e-2 of their scale
+ * (tests/test_presplit_gpu.py); bench.py extra.bf16_storage. */
+int dep_set_gemm_mode(int mode, long min_macs);   /* PROCESS-GLOBAL. mode 0 exact f32 | 1 bf16x3 split | 2 bf16 products | 3 bf16 products + storage ; min_macs < 0 keeps it */
 int dep_get_gemm_mode(void);
 
 /* nn.LayerNorm(F) over the last axis (audio_gru_whole.py:62,104). rows = B*T.

@@ -40,6 +40,8 @@ else:
 rnn.check()
 torch.cuda.synchronize()
 res = {'g%d' % i: t.cpu().numpy() for i, t in enumerate(Gd)}
+if not lstm:
+    res['pooled'] = pooled.cpu().numpy()
 if dx is not None:
     res['dx'] = dx.cpu().numpy()
 np.savez(out, **res)
