@@ -460,13 +460,13 @@ def main():
     sweep_flops = 2.0 * B * T * (G * H) * H * dirs * layers_per_launch
     fusion = args.workload == 'fusion'
     design_per_ut = ({'gru_fwd_sweep': 18 * H, 'lstm_fwd_sweep': 44 * H} if fusion else
-                     {'gru_fwd_sweep': 34 * H, 'gru_bwd_sweep': 38 * H, 'lstm_fwd_sweep': 84 * H, 'lstm_bwd_sweep': 88 * H})[dom]
+                     {'gru_fwd_sweep': 34 * H, 'gru_bwd_sweep': 32 * H, 'lstm_fwd_sweep': 84 * H, 'lstm_bwd_sweep': 88 * H})[dom]      # (round 4: GRU saved gates r, z, n are 2 bytes each: backward 38H -> 32H)
     compulsory_per_ut = 4 * H * dirs
     design_bytes = float(design_per_ut) * B * T * layers_per_launch
     if dom == 'gru_fwd_sweep' and layers_per_launch > 1.5:
-        # the fused two-layer forward: layer 0's input projection in (12H), both layers' h (8H) and saved gates (32H) out, the
+        # the fused two-layer forward: layer 0's input projection in (12H), both layers' h (8H) and saved gates (2 x (6H + 4H)) out, the
         # dropped copy of layer 0's h (4H); layer 1's projection never exists in HBM
-        design_bytes = float(56 * H) * B * T
+        design_bytes = float(44 * H) * B * T              # (round 4: 16-bit r, z, n: 56H -> 44H)
     compulsory_bytes = float(compulsory_per_ut) * B * T * layers_per_launch
     split = L.get_gemm_mode() == 1                           # the cluster sweeps follow the GEMM precision mode
     mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS

@@ -4,19 +4,19 @@ set -u
 export TMPDIR=/tmp
 tag=${1:-final}; out=$PWD/gpurun_out/$tag; mkdir -p $out
 for wl in audio_gru text_bilstm fusion; do
-  bash tools/prof_pmc.sh $tag/pmc_$wl python $PWD/bench.py --steps 3 --warmup 1 --profile-run --workload $wl > $out/pmc_$wl.txt 2>&1
+  bash tools/prof_pmc.sh $tag/pmc_$wl python $PWD/bench.py --steps 3 --warmup 1 --profile-run --no-other-workloads --workload $wl > $out/pmc_$wl.txt 2>&1
 done
 grep -h "launches=" $out/pmc_audio_gru.txt | head -4
 python tools/update_pmc_traffic.py $out 4 > $out/pmc_traffic_update.txt 2>&1     # so that the bench lines below carry the traffic record
 cp profiles/pmc_traffic.json $out/pmc_traffic.json
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 3 --profile-run ) > $out/stats.log 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 3 --profile-run --no-other-workloads ) > $out/stats.log 2>&1
 find $out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
-bash tools/prof_sq.sh $tag/sq python $PWD/bench.py --steps 3 --warmup 1 --profile-run > $out/sq.txt 2>&1
+bash tools/prof_sq.sh $tag/sq python $PWD/bench.py --steps 3 --warmup 1 --profile-run --no-other-workloads > $out/sq.txt 2>&1
 python -m pytest tests/ -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_cfg2.json 2> $out/bench.err
-python bench.py --steps 20 --warmup 5 --workload text_bilstm > $out/bench_cfg3.json 2>> $out/bench.err
-python bench.py --steps 20 --warmup 5 --workload fusion > $out/bench_cfg4_fusion.json 2>> $out/bench.err
+python bench.py --steps 20 --warmup 5 --no-other-workloads --workload text_bilstm > $out/bench_cfg3.json 2>> $out/bench.err
+python bench.py --steps 20 --warmup 5 --no-other-workloads --workload fusion > $out/bench_cfg4_fusion.json 2>> $out/bench.err
 python - "$out" <<'PY'
 import json, sys
 for f in ('bench_cfg2', 'bench_cfg3', 'bench_cfg4_fusion'):
