@@ -143,7 +143,8 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         *reinterpret_cast<f32x4*>(gbuf + shalf * OARR + ro) = st0;
         if (shalf == 0) *reinterpret_cast<f32x4*>(gbuf + 2 * OARR + ro) = st1;
     };
-    auto flush = [&](int tv, int s) {                 // results of fused step s: LDS -> HBM (16-byte stores)
+    // part: 0 = everything, 1 = layer 1's arrays only, 2 = layer 0's only (the steady state splits the write-out over slots Y and Z)
+    auto flush = [&](int tv, int s, int part) {       // results of fused step s: LDS -> HBM (16-byte stores)
         const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
         if (b0t + su >= p.B) return;
         const unsigned so = ((unsigned)(b0t + su) * T) * FH + c * 32 + sqd * 4;       // < 2^28: one array is B*T*H floats
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         // whether / where to store with a dozen wave-uniform branches each (and reloads spilled scalars with v_readlane): the ISA
         // showed ~40 instructions per store, 11 stores per step -- most of this group's ~3000-tick slot Z, which is what groups 0 / 1
         // wait for at barrier #1.
-        if (s >= 2 && s < T && p.training != 0 && !p.ntstore) {
+        const bool steady = s >= 2 && s < T && p.training != 0 && !p.ntstore;
+        if (!steady && part == 1) return;                 // (outside the steady state slot Z writes everything)
+        if (steady) {
             const float* ob = obuf + su * OROW;
             const unsigned e0 = so + (unsigned)s * FH, e1 = so + (unsigned)(s - 2) * FH;
             const size_t os = p.ostride;
@@ -166,12 +169,14 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                 else *reinterpret_cast<f32x4*>(arr + e) = ld4(ob + a * OARR + sqd * 4);
             };
             if (shalf == 0) {                         // obuf arrays 0 h0, 2 z0, 4 hn0, 6 h1, 8 z1, 10 hn1
-                st16(p.y0, e0, 0); stg(p.y0 + dslot0[2] * os, e0, 2); st16(p.y0 + dslot0[4] * os, e0, 4);
-                st16(p.y1, e1, 6); stg(p.y1 + 2 * os, e1, 8); st16(p.y1 + 4 * os, e1, 10);
+                if (part != 1) { st16(p.y0, e0, 0); stg(p.y0 + dslot0[2] * os, e0, 2); st16(p.y0 + dslot0[4] * os, e0, 4); }
+                if (part != 2) { st16(p.y1, e1, 6); stg(p.y1 + 2 * os, e1, 8); st16(p.y1 + 4 * os, e1, 10); }
             } else {                                  // 1 r0, 3 n0, 5 dropout(h0), 7 r1, 9 n1
-                stg(p.y0 + dslot0[1] * os, e0, 1); stg(p.y0 + dslot0[3] * os, e0, 3);
-                if constexpr (DROP) st16(p.y0 + dslot0[5] * os, e0, 5);
-                stg(p.y1 + 1 * os, e1, 7); stg(p.y1 + 3 * os, e1, 9);
+                if (part != 1) {
+                    stg(p.y0 + dslot0[1] * os, e0, 1); stg(p.y0 + dslot0[3] * os, e0, 3);
+                    if constexpr (DROP) st16(p.y0 + dslot0[5] * os, e0, 5);
+                }
+                if (part != 2) { stg(p.y1 + 1 * os, e1, 7); stg(p.y1 + 3 * os, e1, 9); }
             }
             return;
         }
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         f32x4 acc[3] = {zero4(), zero4(), zero4()};
         auto matvec = [&]() {
             // the accumulators of the K-half-0 wave start from the group's bias (b_hh l0 / b_hh l1 / b_ih l1): the bias add is free
-            if (kh == 0) {
+            if (kh == 0 && !(DROP && grp == 2)) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[g] = ld4(bias_l + grp * 96 + g * 32 + jl * 16 + q * 4);
             }
@@ -283,27 +288,23 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         const unsigned pbase = (unsigned)(s & 1) * pstride + tile_base;
         if (grp == 2) {                                   // ---- slot Y of group 2 (the others are polling / gathering); placed before the gate block so that
                                                           // the accumulators' live range does not span it
-            if (act) put_red();                           // group 1 reads these partial sums in the next step's gate phase
-            write_gbuf(tv);                               // layer-0 input projection of step s+1
-            // dropout(h0_s) is only read by this group (its next slot X), so it gathers that block itself -- here, beside the
-            // others' poll + gather and behind its own flag poll (the write-out stores come later, in slot Z: a wave's poll
-            // loop would sit out its own stores).
-            if (DROP && s < T) {
-                if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6, p.soft)) return;
-                u32x4 v[4];
+            if (act) {
+                if constexpr (DROP) {
+                    // Round 4: this group multiplied W_ih(l1) with the MASKED but UNSCALED planes of h0 (below): the dropout scale goes onto
+                    // the sums, then b_ih (K half 0): W (m * s * h) + b = s * (W (m * h)) + b
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pbase + (unsigned)F_REGION + (unsigned)((tv & 255) + 256 * k) * 4) * 4, 0, 16 /* sc1 */);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i4 = ((tv & 255) + 256 * k) * 4;
-                    const int o = (i4 >> 8) * FLDHB + (i4 & (FH - 1));
-                    uint2 hi2, lo2;
-                    hi2.x = (v[k].x >> 16) | (v[k].y & 0xffff0000u); hi2.y = (v[k].z >> 16) | (v[k].w & 0xffff0000u);
-                    lo2.x = (v[k].x & 0xffffu) | (v[k].y << 16);      lo2.y = (v[k].z & 0xffffu) | (v[k].w << 16);
-                    *reinterpret_cast<uint2*>(hs0d + o) = hi2; *reinterpret_cast<uint2*>(hs0d + FPLANE + o) = lo2;
+                    for (int g = 0; g < 3; ++g) {
+                        const f32x4 bb = kh == 0 ? ld4(bias_l + 2 * 96 + g * 32 + jl * 16 + q * 4) : zero4();
+                        acc[g] = acc[g] * p.drop_scale + bb;
+                    }
                 }
+                put_red();                                // group 1 reads these partial sums in the next step's gate phase
             }
+            write_gbuf(tv);                               // layer-0 input projection of step s+1
+            flush(tv, s, 1);                              // layer 1's arrays of step s go out here (obuf is complete: the others wrote it before this barrier) ...
+            // (Until round 4 this group polled the flags and gathered a third payload block, dropout(h0_s), here -- ~2000 ticks that made it
+            // the long pole of the step.  Now group 0 publishes the two mask BITS of its unit pair as one byte and the waves that gather h0_s
+            // write the masked planes too.)
         }
         if (grp < 2 && act) {
             // branch-free over the two roles: the input-projection term is gi = A + B with
@@ -336,9 +337,12 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                 if (fast) __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (DROP && grp == 0) {
-                    const u64 dbits = (u64)split_word(hd.x) | ((u64)split_word(hd.y) << 32);
-                    if (fast) __hip_atomic_store(dst + F_REGION / 2, dbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else __hip_atomic_store(dst + F_REGION / 2, dbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the mask bits of this lane's unit pair: byte [utterance j][pair (32 c + ul) / 2] of the second payload block
+                    typedef __attribute__((address_space(1))) unsigned char gu8;
+                    const unsigned char mb = (unsigned char)((st1[0] != 0.f ? 1u : 0u) | (st1[1] != 0.f ? 2u : 0u));
+                    gu8* mdst = (gu8*)(reinterpret_cast<unsigned char*>(p.payload + (pbase + (unsigned)F_REGION)) + j * (FH / 2) + c * 16 + (ul >> 1));
+                    if (fast) __hip_atomic_store(mdst, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store(mdst, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             float* ob = obuf + grp * (6 * OARR) + j * OROW + ul;            // results for the streaming waves
@@ -383,21 +387,27 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             // prefetch all here 1.66; poll + gather + write-out in slot Y 1.58; poll + gather in slot Y, write-out + prefetch
             // here 1.39 (this one).  The group is close to being the critical resource: ~1400 ticks of MFMAs, ~1800 of
             // poll + gather, ~2700 to push 31 KB through the CU's memory pipeline, out of a 6800-tick step.
-            flush(tv, s);                                 // write-out of step s (obuf is next written in the others' slot Y of step s+1)
+            flush(tv, s, 2);                              // ... layer 0's (everything outside the steady state) here (obuf is next written in the others' slot Y of step s+1)
             issue_gi(tv, s + 2);
         } else {
             FSTAMP(5);
             if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6, p.soft)) return;      // every wave polls (one poller + a verdict barrier measured no faster)
             FSTAMP(6);
             // gather: h0_s (next layer-0 step; also layer 1's input when there is no dropout) and h1_{s-2} (next layer-1 step)
-            const bool need0 = (s + 1 < T) || (!DROP && s < T), need2 = s >= 2;
+            const bool need0 = s < T, need2 = s >= 2;    // (h0_{T-1} is still layer 1's last input)
             u32x4 v[2][2];
+            unsigned mk[2] = {0u, 0u};                    // DROP: the four mask bits of the piece's units (two bytes: pairs col0 / 2, col0 / 2 + 1)
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
                 if (rg == 0 ? need0 : need2) {
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
+                    for (int k = 0; k < 2; ++k) {
                         v[rg][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pbase + (unsigned)(rg * 2) * F_REGION + (unsigned)(tv + 512 * k) * 4) * 4, 0, 16 /* sc1 */);
+                        if (DROP && rg == 0) {
+                            const int i4 = (tv + 512 * k) * 4;
+                            mk[k] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (pbase + (unsigned)F_REGION) * 4 + (unsigned)((i4 >> 8) * (FH / 2) + ((i4 & (FH - 1)) >> 1)), 0, 16 /* sc1 */);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -413,6 +423,15 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                         hi2.x = (x.x >> 16) | (x.y & 0xffff0000u); hi2.y = (x.z >> 16) | (x.w & 0xffff0000u);
                         lo2.x = (x.x & 0xffffu) | (x.y << 16);      lo2.y = (x.z & 0xffffu) | (x.w << 16);
                         *reinterpret_cast<uint2*>(hi + o) = hi2; *reinterpret_cast<uint2*>(hi + FPLANE + o) = lo2;
+                        if (DROP && rg == 0) {
+                            // dropout(h0) for group 2: the same planes with the dropped units zeroed (the scale is applied to its sums)
+                            const unsigned w = mk[k];
+                            const unsigned m01 = ((0u - (w & 1u)) & 0xffffu) | ((0u - ((w >> 1) & 1u)) & 0xffff0000u);
+                            const unsigned m23 = ((0u - ((w >> 8) & 1u)) & 0xffffu) | ((0u - ((w >> 9) & 1u)) & 0xffff0000u);
+                            uint2 dh, dl;
+                            dh.x = hi2.x & m01; dh.y = hi2.y & m23; dl.x = lo2.x & m01; dl.y = lo2.y & m23;
+                            *reinterpret_cast<uint2*>(hs0d + o) = dh; *reinterpret_cast<uint2*>(hs0d + FPLANE + o) = dl;
+                        }
                     }
                 }
             }
@@ -422,7 +441,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     }
     bar_lds();                                            // the last layer-1 step's results are in obuf
     if (TRACE && trl) { long long* o = p.trace + (tid ? 32 : 0); for (int i = 0; i < 32; ++i) o[i] = trl[i]; }
-    if (grp == 2) flush(tid, T + 1);
+    if (grp == 2) flush(tid, T + 1, 0);
     {
         const int lane = tid & 63, j = lane & 15, ul = jl * 16 + (lane >> 4) * 4 + 2 * kh;
         const int b = b0t + j, col = c * 32 + ul;
