@@ -32,8 +32,9 @@ constexpr int F_GBUF = 3 * OARR;              // [gate][16 utterances][32 units]
 constexpr int F_OBUF = 12 * OARR;             // per layer 6 slots: h, r, z, n, hn, dropout(h) (layer 0 only)
 constexpr int F_REGION = BT * FH;             // words of one payload block (one tile, one tensor)
 constexpr int F_BIAS = 3 * 3 * 32;            // b_hh l0, b_hh l1, b_ih l1 slices of the member: [vector][gate][32 units]
-constexpr int F_TRACE = 2 * 4 * 8 * 2;        // debug stamps (DEP_TRACE=1): [role 0 / 2][4 steps][8 slots] 64-bit
-constexpr size_t F_LDS_BYTES = (size_t)(3 * FPLANE + F_RED + F_GBUF + F_OBUF + F_BIAS + 4 + F_TRACE + 16) * sizeof(float);
+constexpr int F_TRACE = 3 * 4 * 8 * 2;        // debug stamps (DEP_TRACE=1): [role 0 / 2 / 1][4 steps][8 slots] 64-bit
+constexpr int F_MBUF = OARR;                  // next step's dropout mask values of the member's [16 utterances][32 units] (drawn by group 2)
+constexpr size_t F_LDS_BYTES = (size_t)(3 * FPLANE + F_RED + F_GBUF + F_OBUF + F_BIAS + 4 + F_TRACE + 16 + F_MBUF) * sizeof(float);
 
 struct FF {
     int B, T, nbtp, b0;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     float* obuf = gbuf + F_GBUF;
     float* bias_l = obuf + F_OBUF;                    // biases live in LDS, not in registers (the weight slice needs those)
     float* zpair = bias_l + F_BIAS;                   // two zeros (branch-free gate math), then the debug stamps
+    float* mbuf = zpair + 4 + F_TRACE + 16;
     for (int i = tid; i < 3 * FPLANE; i += FTHREADS) smem[i] = 0.f;
     if (tid < 4) zpair[tid] = 0.f;
     if (tid < F_BIAS) {
@@ -226,8 +228,8 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     if (DROP && grp == 0) { const float2 m0 = draw(tid, 0); st1[0] = m0.x; st1[1] = m0.y; }
     __syncthreads();
 
-    long long* trl = nullptr;                         // workgroup 0, thread 0 (group 0) and thread 512 (group 2)
-    if (TRACE && p.trace && blockIdx.x == 0 && (tid == 0 || tid == 512)) trl = reinterpret_cast<long long*>(zpair + 4) + (tid ? 32 : 0);
+    long long* trl = nullptr;                         // workgroup 0, thread 0 (group 0), thread 512 (group 2), thread 256 (group 1)
+    if (TRACE && p.trace && blockIdx.x == 0 && (tid == 0 || tid == 512 || tid == 256)) trl = reinterpret_cast<long long*>(zpair + 4) + (tid == 0 ? 0 : (tid == 512 ? 32 : 64));
     // Group 2 runs ONE BARRIER out of phase with groups 0 / 1 (it passes one extra barrier here and one fewer at the end): its
     // slot X (the MFMAs) then coincides with their slot Y (gate math, matrix pipe idle), its slot Y (partial sums to LDS, staged
     // projection, its own poll + gather of the dropout block) with their slot Z (poll + gather), its slot Z (write-out of the
@@ -302,6 +304,17 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             }
             write_gbuf(tv);                               // layer-0 input projection of step s+1
             flush(tv, s, 1);                              // layer 1's arrays of step s go out here (obuf is complete: the others wrote it before this barrier) ...
+            if constexpr (DROP) {
+                // layer 0's dropout mask of step s+1 (read by group 0 at the start of its next gate block): the Philox draw is ~150 VALU
+                // instructions; inside group 0's gate block it sat on every SIMD's VALU beside both groups' gate math (a third of that
+                // phase's instructions).  Here two of this group's waves (the ones with less to write out) draw the member's 128 blocks
+                // once, while the others poll and gather.
+                if (shalf == 1 && s + 1 < T) {
+                    const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
+                    const size_t o = ((size_t)(b0t + su) * T + (s + 1)) * FH + c * 32 + sqd * 4;
+                    *reinterpret_cast<f32x4*>(mbuf + su * OROW + sqd * 4) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+                }
+            }
             // (Until round 4 this group polled the flags and gathered a third payload block, dropout(h0_s), here -- ~2000 ticks that made it
             // the long pole of the step.  Now group 0 publishes the two mask BITS of its unit pair as one byte and the waves that gather h0_s
             // write the masked planes too.)
@@ -310,6 +323,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             // branch-free over the two roles: the input-projection term is gi = A + B with
             //   layer 0: A = prefetched projection (gbuf), B = a zero pair ; layer 1: A, B = group 2's two K halves (b_ih inside)
             const int e2 = lane * 4 + 2 * kh;             // this lane's pair inside a [64][4] fragment block
+            if (DROP && grp == 0 && s >= 1) { const float2 mn = ld2(mbuf + j * OROW + ul); st1[0] = mn.x; st1[1] = mn.y; }      // this step's mask (group 2 drew it)
             // both K halves of the lane's pair come back from LDS (the own half too: selecting acc[g][2 kh + i] in registers
             // compiles to a dynamic-index select tree of ~150 instructions)
             const float* po = red + (w * 3) * 256 + e2;
@@ -369,8 +383,6 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                     obuf[j * OROW + (ul >> 1) + 5 * OARR] = __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(dv, b2v)));
                 } else st2(ob + 5 * OARR, hd);
             }
-            // next step's dropout mask: Philox work in the shadow of the payload stores' acknowledgement (the drain below)
-            if (DROP && grp == 0 && s + 1 < T) { const float2 mn = draw(tv, s + 1); st1[0] = mn.x; st1[1] = mn.y; }
         }
         if (grp < 2 && s == T + 1) break;
         FSTAMP(3);
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         bar_lds();                                        // groups 0/1: #3 (planes of step s+1 complete) | group 2: #1 of step s+1
     }
     bar_lds();                                            // the last layer-1 step's results are in obuf
-    if (TRACE && trl) { long long* o = p.trace + (tid ? 32 : 0); for (int i = 0; i < 32; ++i) o[i] = trl[i]; }
+    if (TRACE && trl) { long long* o = p.trace + (tid == 0 ? 0 : (tid == 512 ? 32 : 64)); for (int i = 0; i < 32; ++i) o[i] = trl[i]; }
     if (grp == 2) flush(tid, T + 1, 0);
     {
         const int lane = tid & 63, j = lane & 15, ul = jl * 16 + (lane >> 4) * 4 + 2 * kh;

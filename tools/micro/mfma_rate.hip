@@ -8,8 +8,32 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// Round 4: the same loop on v_mfma_f32_16x16x32_bf16 (the recurrent sweeps' instruction): one wave issues one every ~32 cycles whatever the
+// instruction's size, so the small form moves half the flops per issue slot (profiles/r04_micro_mfma_16x16x32.txt).
 template <int NACC>
-__global__ __launch_bounds__(512) void mfma_loop(const unsigned* seed, int iters, float* out, long long* cyc) {
+__global__ __launch_bounds__(1024) void mfma_loop16(const unsigned* seed, int iters, float* out, long long* cyc) {
+    unsigned s0 = seed[threadIdx.x & 63], s1 = seed[64 + (threadIdx.x & 63)];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 ua = {s0, s1, s0 * 3u, s1 * 5u}, ub = {s1, s0 * 7u, s1 * 11u, s0};
+    for (int i = 0; i < 4; ++i) { ua[i] &= 0xbfffbfffu; ub[i] &= 0xbfffbfffu; }
+    bf16x8 a = __builtin_bit_cast(bf16x8, ua), b = __builtin_bit_cast(bf16x8, ub);
+    f32x4v acc[NACC];
+    for (int n = 0; n < NACC; ++n) for (int e = 0; e < 4; ++e) acc[n][e] = 0.f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[n], 0, 0, 0);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int n = 0; n < NACC; ++n) s += acc[n][0];
+    if (s == 1.2345e30f) out[threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int NACC>
+__global__ __launch_bounds__(1024) void mfma_loop(const unsigned* seed, int iters, float* out, long long* cyc) {
     unsigned s0 = seed[threadIdx.x & 63], s1 = seed[64 + (threadIdx.x & 63)];
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     u4 ua = {s0, s1, s0 * 3u, s1 * 5u}, ub = {s1, s0 * 7u, s1 * 11u, s0};
@@ -31,7 +55,7 @@ __global__ __launch_bounds__(512) void mfma_loop(const unsigned* seed, int iters
 }
 
 template <int NACC>
-static void run(int waves_per_simd, bool random, int cus) {
+static void run(int waves_per_simd, bool random, int cus, bool small = false) {
     unsigned h[128];
     for (int i = 0; i < 128; ++i) h[i] = random ? (unsigned)rand() * 2654435761u + (unsigned)rand() : 0u;
     unsigned* d; float* out; long long* cyc;
@@ -41,15 +65,16 @@ static void run(int waves_per_simd, bool random, int cus) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(a, 0);
-        hipLaunchKernelGGL(mfma_loop<NACC>, dim3(cus), dim3(threads), 0, 0, d, iters, out, cyc);
+        if (small) hipLaunchKernelGGL(mfma_loop16<NACC>, dim3(cus), dim3(threads), 0, 0, d, iters, out, cyc);
+        else hipLaunchKernelGGL(mfma_loop<NACC>, dim3(cus), dim3(threads), 0, 0, d, iters, out, cyc);
         hipEventRecord(b, 0); hipEventSynchronize(b);
     }
     float ms; hipEventElapsedTime(&ms, a, b);
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     const double nm = (double)cus * 4 * waves_per_simd * iters * NACC;      // MFMAs
-    printf("acc %d  waves/SIMD %d  data %-6s: %8.3f ms  wave0 %lld cyc (%.1f cyc per MFMA and SIMD)  clock %.2f GHz  %7.1f TFLOP/s\n", NACC,
-           waves_per_simd, random ? "random" : "zeros", ms, c, (double)c / ((double)iters * NACC * waves_per_simd), c / ms / 1e6,
-           nm * 32768.0 / ms / 1e9);
+    printf("%s CUs %3d acc %d  waves/SIMD %d  data %-6s: %8.3f ms  wave0 %lld cyc (%.1f cyc per MFMA of a wave, %.1f per MFMA and SIMD)  clock %.2f GHz  %7.1f TFLOP/s\n",
+           small ? "16x16x32" : "32x32x16", cus, NACC, waves_per_simd, random ? "random" : "zeros", ms, c, (double)c / ((double)iters * NACC),
+           (double)c / ((double)iters * NACC * waves_per_simd), c / ms / 1e6, nm * (small ? 16384.0 : 32768.0) / ms / 1e9);
     hipFree(d); hipFree(out); hipFree(cyc);
 }
 
@@ -57,6 +82,12 @@ int main() {
     hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
     const int cus = pr.multiProcessorCount;
     printf("%s, %d CUs\n", pr.name, cus);
+    if (getenv("MFMA_SMALL")) {         // round 4: instruction size x waves per SIMD, on few CUs (no power throttling) and on all of them
+        for (int ncu : {32, cus})
+            for (int sm = 0; sm < 2; ++sm)
+                for (int wv = 1; wv <= 4; ++wv) run<4>(wv, true, ncu, sm != 0);
+        return 0;
+    }
     for (int rnd = 0; rnd < 2; ++rnd) {
         run<2>(1, rnd, cus); run<4>(1, rnd, cus); run<8>(1, rnd, cus);
         run<4>(2, rnd, cus); run<8>(2, rnd, cus);

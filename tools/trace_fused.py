@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """DEP_TRACE=1 python tools/trace_fused.py : phase timings (shader cycles) of workgroup 0 of the fused 2-layer GRU forward
-(rnn_fused2.hip): thread 0 (group 0, on the critical path) and thread 512 (group 2, input projection + HBM streams)."""
+(rnn_fused2.hip): thread 0 (group 0), thread 256 (group 1) and thread 512 (group 2, input projection + HBM streams)."""
 import ctypes as C
 import os
 import sys
@@ -27,14 +27,15 @@ for _ in range(3):
 torch.cuda.synchronize()
 rnn.check()
 off = L.load().dep_rnn_workspace_xbuf_offset(C.byref(rnn.desc))
-tr = rnn.workspace[(off + 6400) // 4:(off + 6400) // 4 + 128].view(torch.int64).cpu().numpy().reshape(2, 4, 8)
+tr = rnn.workspace[(off + 6400) // 4:(off + 6400) // 4 + 192].view(torch.int64).cpu().numpy().reshape(3, 4, 8)
 n0 = ['frags+MFMA+red', 'barrier#1', 'gates+publish+deposit+mask draw', 'drain vmcnt', 'barrier#2+flag', 'poll', 'gather->LDS']
-for s in range(4):
-    a = tr[0, s]
-    d = [int(a[i + 1] - a[i]) for i in range(7)]
-    nxt = int(tr[0, s + 1, 0] - a[7]) if s < 3 else 0
-    print(f'g0 step {100 + s}: total {int(a[7] - a[0])} + barrier#3 {nxt} | ' + ' | '.join(f'{n}: {v}' for n, v in zip(n0, d)))
+for g, row in ((0, 0), (1, 2)):                     # thread 0 (group 0), thread 256 (group 1)
+    for s in range(4):
+        a = tr[row, s]
+        d = [int(a[i + 1] - a[i]) for i in range(7)]
+        nxt = int(tr[row, s + 1, 0] - a[7]) if s < 3 else 0
+        print(f'g{g} step {100 + s}: start {int(a[0] - tr[0, 0, 0])} total {int(a[7] - a[0])} + barrier#3 {nxt} | ' + ' | '.join(f'{n}: {v}' for n, v in zip(n0, d)))
 for s in range(4):
     a = tr[1, s]
-    print(f'g2 step {100 + s}: MFMA+red {int(a[1] - a[0])} | barrier#1 {int(a[2] - a[1])} | slot Y (red, gbuf, flush)->#2 {int(a[4] - a[2])} | slot Z (gather, prefetch issue) {int(a[7] - a[4])}'
+    print(f'g2 step {100 + s}: start {int(a[0] - tr[0, 0, 0])} MFMA+red {int(a[1] - a[0])} | barrier#1 {int(a[2] - a[1])} | slot Y (red, gbuf, flush)->#2 {int(a[4] - a[2])} | slot Z (gather, prefetch issue) {int(a[7] - a[4])}'
           + (f' | barrier#3 {int(tr[1, s + 1, 0] - a[7])}' if s < 3 else ''))
