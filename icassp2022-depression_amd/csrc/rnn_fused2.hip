@@ -25,7 +25,9 @@ using namespace depc;
 constexpr int FH = 256, FNC = 8, FKS2 = 4, FTHREADS = 768;
 constexpr int FLDHB = FH + 8;                 // bf16 elements per row of a split plane (528-byte rows: conflict-free b128 reads)
 constexpr int FPLANE = BT * FLDHB;            // bf16 elements per plane
-constexpr int F_RED = 12 * 3 * 256;           // floats: [wave][gate][lane][4]
+constexpr int F_RED = 12 * 3 * 256;           // floats: [wave][gate][half of the lane's four][lane][2] -- the gate threads read ONE half of a lane's
+                                              // fragment: as [lane][4] their 8-byte reads had a 16-byte stride, a 2-way bank conflict on 6-12 reads per
+                                              // thread at the start of the gate phase, when all eight gate waves read at once (-4 % on the launch)
 constexpr int OROW = 36;                      // floats per utterance row of gbuf / obuf (32 + 4: an unpadded row puts all 16 rows on one bank)
 constexpr int OARR = BT * OROW;               // one [16 utterances][32 units] array
 constexpr int F_GBUF = 3 * OARR;              // [gate][16 utterances][32 units]
@@ -277,7 +279,10 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         };
         auto put_red = [&]() {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(red + ((w * 3 + g) * 64 + lane) * 4) = acc[g];
+            for (int g = 0; g < 3; ++g) {
+                float* rb = red + (w * 3 + g) * 256 + lane * 2;
+                st2(rb, f2(acc[g][0], acc[g][1])); st2(rb + 128, f2(acc[g][2], acc[g][3]));
+            }
         };
         // ---- slot X
         if (act) matvec();
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         if (grp < 2 && act) {
             // branch-free over the two roles: the input-projection term is gi = A + B with
             //   layer 0: A = prefetched projection (gbuf), B = a zero pair ; layer 1: A, B = group 2's two K halves (b_ih inside)
-            const int e2 = lane * 4 + 2 * kh;             // this lane's pair inside a [64][4] fragment block
+            const int e2 = kh * 128 + lane * 2;           // this lane's pair inside a [2][64][2] fragment block
             if (DROP && grp == 0 && s >= 1) { const float2 mn = ld2(mbuf + j * OROW + ul); st1[0] = mn.x; st1[1] = mn.y; }      // this step's mask (group 2 drew it)
             // both K halves of the lane's pair come back from LDS (the own half too: selecting acc[g][2 kh + i] in registers
             // compiles to a dynamic-index select tree of ~150 instructions)
