@@ -65,15 +65,25 @@ constexpr int SARR = 16 * SROW;
 constexpr int TRACE_F = 2048, IBUF_F = 2304;         // float offsets into the workgroup's LDS (planes: [0, 2048))
 constexpr int obuf_slots(int KB) { return KB == 4 ? KB + 2 : KB + 1; }      // KB + 1 does for fp32 rows; the PK flush (KB = 4 only) works on step PAIRS and may lag one step
 constexpr size_t burst_lds_bytes(int KB) { return (size_t)(IBUF_F + KB * 6 * SARR + obuf_slots(KB) * 4 * SARR) * sizeof(float); }
+// AG (round 5): the all-gather form of the exchange.  Member c keeps the W_hh COLUMNS of its 32 hidden units (all 3H rows), every member
+// publishes its own 16 x 96 gate gradients dgh_t = (dr, dz, dn*r) ONCE, as the (hi, lo) bf16 planes the MFMAs read, in MFMA B-fragment order
+// (6 KB per member and step instead of 16 KB of fp32 partial dh; no sum over members at the consumer), and computes its own 32 columns of
+// dh_{t-1} = dgh_t W_hh completely: K = 3H = 768 split into four quarters over the four compute waves (wave w = the 192 k of source members
+// 2w, 2w+1: 6 k-steps x 2 output tiles x 3 products = the same 36 MFMAs per wave), the B fragments read STRAIGHT from the exchange buffer
+// into registers (12 wave-contiguous 1 KB loads per wave; no LDS staging), the four K-quarter partials summed through a double-buffered
+// LDS block `red' behind the step's only workgroup barrier.  LDS: red occupies [0, 4096) floats, so the trace / ring offsets move up.
+constexpr int AG_TRACE_F = 4096, AG_IBUF_F = 4352, AG_MEMBER_BYTES = 6 * 1024;
+constexpr size_t burst_lds_bytes_ag(int KB) { return (size_t)(AG_IBUF_F + KB * 6 * SARR + obuf_slots(KB) * 4 * SARR) * sizeof(float); }
 
 // SV16: the saved gates r, z, n are 16-bit fixed point (rnn_cluster_common.h).  A template parameter, not a kernel argument: as a
 // run-time switch the two load widths met in copies of the loaded registers and the service waves waited for every load they had
 // just issued (both settings 5-20 % slower than the kernel without the switch, profiles/r04_ab_pairs.txt).
 // BF (bf16-storage mode, dep_set_gemm_mode(3); implies SV16, burst kernel only): hn and the hidden sequence y are bf16 arrays (2-byte
 // elements at the same positions), and the gate gradients go out as the PKH image (only the hi rows of the PK image).
-template <int NTW, bool SPLIT, int KB, bool SV16 = false, bool BF = false>      // output tiles per wave = H/64
+template <int NTW, bool SPLIT, int KB, bool SV16 = false, bool BF = false, bool AG = false>      // output tiles per wave = H/64
 __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1(P2 p) {
     static_assert(!BF || (SV16 && KB > 0), "bf16 storage: 16-bit gates, burst kernel");
+    static_assert(!AG || (SPLIT && KB == 4 && NTW == 4 && !BF), "all-gather exchange: H = 256, split products, burst length 4");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 96, KCB = KS / 16, LDG = KS + LPAD;
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane (208-byte rows)
@@ -99,13 +109,25 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     constexpr bool BURST = KB > 0;
     constexpr int KBX = BURST ? KB : 1;
     const bool svc = BURST && tid >= CT;              // wave-uniform
-    float* ibuf = smem + IBUF_F;                      // [KB][6][16][SROW]: r, z, n, hn, h_{t-1}, dy of step k in slot k % KB
+    float* ibuf = smem + (AG ? AG_IBUF_F : IBUF_F);   // [KB][6][16][SROW]: r, z, n, hn, h_{t-1}, dy of step k in slot k % KB
     constexpr int OSL = obuf_slots(KBX);
     float* obuf = ibuf + KBX * 6 * SARR;              // [OSL][4][16][SROW]: dr, dz, dn, dn*r of step k in slot k % OSL
     f32x4 wr[SPLIT ? 1 : NTW][SPLIT ? 1 : KCB];
-    u32x4 wq[SPLIT ? NTW : 1][SPLIT ? 3 : 1][2];       // [tile][k-step = gate][hi, lo]
+    u32x4 wq[SPLIT ? NTW : 1][SPLIT ? 3 : 1][2];       // [tile][k-step = gate][hi, lo]   (AG: unused, wa below)
+    u32x4 wa[AG ? 2 : 1][AG ? 6 : 1][2];               // AG: [own output tile][k-step = (source member 2w + ks/3, gate ks%3)][hi, lo]
     if (!svc) {
-        if constexpr (SPLIT) {
+        if constexpr (AG) {
+            // the SAME packed image as the reduce-scatter kernel's ([K member][output tile][gate][plane][lane]); this member takes the
+            // two output tiles of its own 32 columns and, per wave, the K rows of source members 2w, 2w+1
+            const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        wa[i][ks][pl] = wpq[(size_t)((((2 * w + ks / 3) * NTT + 2 * c + i) * 3 + ks % 3) * 2 + pl) * 64 + lane];
+        } else if constexpr (SPLIT) {
             const u32x4* wpq = reinterpret_cast<const u32x4*>(p.wp);
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
@@ -269,10 +291,10 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                 for (int i = 0; i < 3; ++i) sreg[d][i] = svc_load1(W16, NT, k0 + d, i);
             }
     };
-    auto svc_put = [&](auto W16, int k0, int n) {     // registers -> ibuf slots of steps k0 .. k0+n-1
+    auto svc_put = [&](auto W16, int k0, int n, int dlo = 0) {     // registers -> ibuf slots of steps k0+dlo .. k0+n-1
 #pragma unroll
         for (int d = 0; d < KBX; ++d)
-            if (d < n) {
+            if (d >= dlo && d < n) {
                 float* dst = ibuf + ((k0 + d) % KBX) * 6 * SARR + sr * SROW + sp * 4;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -353,6 +375,19 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
                 if (trs) p.trace[32 + (k - 100) * 4 + 2] = (long long)__builtin_readcyclecounter();
                 bar_lds();                           // #1
                 if (trs) p.trace[32 + (k - 100) * 4 + 3] = (long long)__builtin_readcyclecounter();
+                if constexpr (AG) {
+                    // The all-gather step has ONE barrier, at its end, and the compute waves read ring slot (k+1) % KB right behind
+                    // barrier(k): step s may be written only between barrier(s - KB) (its slot's previous occupant consumed) and
+                    // barrier(s - 1).  For the burst requested at dirty step L = last (steps L+KB .. L+2KB-1) that is: the first
+                    // KB-1 behind barrier(L + KB - 2), the last one behind barrier(L + KB - 1).  No race window at all.
+                    if (jj == KBX - 2 && last >= 0) svc_put(W16, last + KBX, KBX - 1);
+                    if (jj == KBX - 1) {
+                        if (last >= 0) svc_put(W16, last + KBX, KBX, KBX - 1);
+                        else svc_put(W16, KBX, phi);         // the prologue's steps KB .. KB+phi-1 (their slots were consumed by barrier(phi-1))
+                    }
+                    if (k == T - 1) break;
+                    continue;
+                }
                 if (jj == KBX - 1) {
                     // last step of the burst: the ring slots of steps last .. k are consumed; the registers (requested at step
                     // `last', KB-1 steps ago) become steps last+KB .. k+KB
@@ -389,11 +424,95 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     float2 mk = masked ? draw(T - 1) : f2(1.f, 1.f);
     // debug stamps (DEP_TRACE=1, tools/trace_bwd.py): buffered in otherwise unused LDS, copied out after the sweep
     long long* trb = (p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
-    long long* trlb = reinterpret_cast<long long*>(smem + (BURST ? TRACE_F : 8192));
+    long long* trlb = reinterpret_cast<long long*>(smem + (AG ? AG_TRACE_F : BURST ? TRACE_F : 8192));
 #define BSTAMP(slot) do { if (trb && t <= 199 && t > 195) trlb[(199 - t) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
     if (trb) trlb[7] = (long long)__builtin_readcyclecounter();
     unsigned* trall = reinterpret_cast<unsigned*>(smem) + p.trall_off;      // DEP_TRACE: low 32 bits of the tick counter at the top of every step
+    if constexpr (AG) {
+        // ---- all-gather sweep (see AG_MEMBER_BYTES above).  Exchange buffer: [parity][tile][member][gate][plane][64 lanes][16 B]; this
+        // thread's pair (units ul, ul+1 of utterance j) is word `pw' of each of its member's six 1 KB blocks -- B-fragment order: lane
+        // (k-group ul / 8, utterance j), word (ul % 8) / 2 -- and a wave's 64 words are 256 contiguous bytes.
+        float* red = smem;                                  // [step parity][K quarter = wave][own tile][64 lanes][4]
+        const unsigned pw = (unsigned)(half + 2 * ((lp >> 4) & 1) + 4 * j + 64 * (lp >> 5) + 128 * jl);
+        const unsigned par_bytes = (unsigned)p.nbtp * NC * AG_MEMBER_BYTES;
+        const unsigned pub0 = (unsigned)(bt * NC + c) * AG_MEMBER_BYTES + pw * 4;
+        const unsigned ld0 = (unsigned)(bt * NC + 2 * w) * AG_MEMBER_BYTES + lane * 16;     // this wave's 12 blocks are contiguous: members 2w, 2w+1
+        unsigned* srcflags = tflags + 8 * w;                // the eight per-wave flags of source members 2w, 2w+1
+        const int rdo = (jl * 64 + (lp >> 4) * 16 + j) * 4 + 2 * half;      // own pair inside a K quarter's two accumulator tiles
+        for (int t = T - 1; t >= 0; --t) {
+            const int k = T - 1 - t;
+            BSTAMP(0);
+            if (trb && k < 360) trall[k] = (unsigned)__builtin_readcyclecounter();
+            const float* ib = ibuf + (k % KBX) * 6 * SARR + j * SROW + ul;
+            const float2 r = ld2(ib), z = ld2(ib + SARR), n = ld2(ib + 2 * SARR), hn = ld2(ib + 3 * SARR), hp = ld2(ib + 4 * SARR), dyi = ld2(ib + 5 * SARR);
+            const float2 d = f2(dhrec.x + dpl.x + dyi.x * mk.x, dhrec.y + dpl.y + dyi.y * mk.y);
+            float2 dn, dz, dr, dnr, dzt;
+            dn.x = d.x * (1.0f - z.x) * (1.0f - n.x * n.x); dn.y = d.y * (1.0f - z.y) * (1.0f - n.y * n.y);
+            dz.x = d.x * (hp.x - n.x) * z.x * (1.0f - z.x); dz.y = d.y * (hp.y - n.y) * z.y * (1.0f - z.y);
+            dr.x = dn.x * hn.x * r.x * (1.0f - r.x); dr.y = dn.y * hn.y * r.y * (1.0f - r.y);
+            dnr.x = dn.x * r.x; dnr.y = dn.y * r.y;
+            dzt.x = d.x * z.x; dzt.y = d.y * z.y;
+            const unsigned epoch = (unsigned)(k + 1);
+            if (t > 0) {      // publish first: the (hi, lo) pair words of dr, dz, dn*r -- what every member's MFMAs read
+                unsigned h0, l0, h1, l1, h2, l2;
+                split_pair(dr.x, dr.y, h0, l0); split_pair(dz.x, dz.y, h1, l1); split_pair(dnr.x, dnr.y, h2, l2);
+                const unsigned po = (unsigned)(t & 1) * par_bytes + pub0;
+                const unsigned wds[6] = {h0, l0, h1, l1, h2, l2};
+                if (fast) {           // same-XCD clusters: plain stores (that XCD's L2 is the coherence point)
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) __builtin_amdgcn_raw_buffer_store_b32(wds[e], rsrc, po + e * 1024, 0, 0);
+                } else {              // write-through
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) __builtin_amdgcn_raw_buffer_store_b32(wds[e], rsrc, po + e * 1024, 0, 16);
+                }
+            }
+            {
+                float* ob = obuf + (k % OSL) * 4 * SARR + j * SROW + ul;
+                st2(ob, dr); st2(ob + SARR, dz); st2(ob + 2 * SARR, dn); st2(ob + 3 * SARR, dnr);
+            }
+            dbr.x += dr.x; dbr.y += dr.y; dbz.x += dz.x; dbz.y += dz.y; dbn.x += dn.x; dbn.y += dn.y; dbh.x += dnr.x; dbh.y += dnr.y;
+            BSTAMP(1);
+            if (t == 0) { bar_lds(); break; }                // (the service waves' final flush reads obuf behind this barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's six stores are acknowledged
+            BSTAMP(2);
+            if (lane == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+            if (masked) mk = draw(t - 1);                    // next step's mask, in the shadow of the wait below
+            BSTAMP(3);
+            if (!wait_flags(srcflags, 8, epoch, p.status, 3)) return;
+            BSTAMP(4);
+            const unsigned lo_ = (unsigned)(t & 1) * par_bytes + ld0;
+            u32x4 gfr[6][2];
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    gfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo_ + (unsigned)(ks * 2 + pl) * 1024, 0, 16 /* sc1: served by L2 */);
+            __builtin_amdgcn_sched_barrier(0);               // all twelve requests first (hipcc otherwise sinks each load next to its MFMAs: twelve round trips in a row)
+            f32x4 acc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                const bf16x8 gh = __builtin_bit_cast(bf16x8, gfr[ks][0]), gl = __builtin_bit_cast(bf16x8, gfr[ks][1]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wa[i][ks][0]), wl = __builtin_bit_cast(bf16x8, wa[i][ks][1]);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh, acc[i], 0, 0, 0);
+                }
+            }
+            float* rw = red + ((k & 1) * 8 + w * 2) * 256 + lane * 4;
+            *reinterpret_cast<f32x4*>(rw) = acc[0]; *reinterpret_cast<f32x4*>(rw + 256) = acc[1];
+            BSTAMP(5);
+            bar_lds();
+            const float* rr = red + (k & 1) * 2048 + rdo;
+            float2 s = f2(0.f, 0.f);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) { const float2 v = ld2(rr + q4 * 512); s.x += v.x; s.y += v.y; }      // fixed order: deterministic
+            dhrec = f2(dzt.x + s.x, dzt.y + s.y);
+            BSTAMP(6);
+        }
+    } else
     for (int t = T - 1; t >= 0; --t) {
         const size_t row = (size_t)b * T + t;
         BSTAMP(0);
@@ -906,6 +1025,13 @@ bool dep_cluster_bwd_pk_ok(int H, int T) {
     return H <= 256 && T % 2 == 0 && kbv != 0 && kbv != 6 && !(x && x[0] == '1');
 }
 
+// DEP_BWD_AG: 1 = the all-gather exchange for the GRU-256 backward sweep, 0 = the reduce-scatter of fp32 partials
+bool dep_cluster_bwd_ag_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DEP_BWD_AG"); v = e ? (e[0] == '1' ? 1 : 0) : DEP_BWD_AG_DEFAULT; }
+    return v != 0;
+}
+
 int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
     DEP_CHECK_ARG(dep_cluster_ok(a.cell, a.H, a.B, a.dirs) && xbuf && xbuf_bytes >= dep_cluster_xbuf_bytes(a.cell, a.H, a.B, a.dirs));
     const int NC = a.H / 32, CH = dep_cluster_chunk(NC, 1, 256), nbt = dep_cdiv(a.B, BT);
@@ -944,7 +1070,10 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     const bool xpack = xhalf_env == 1 && a.H == 256 && a.B <= CH;
     p.xhalf = (xpack || (xhalf_env == 2 && a.H == 256 && a.B <= CH / 2)) ? 1 : 0;
     const int kb = (a.H >= 512 || xpack) ? 0 : kb_env;             // H = 512: 192 weight registers per compute wave leave no room for a second wave per SIMD
-    const size_t lds = xpack ? (size_t)49152 + 2048
+    // Round 5: the all-gather exchange (AG above).  DEP_BWD_AG=1 selects it for the H = 256 split-precision burst kernel.
+    const bool ag = dep_cluster_bwd_ag_on() && a.H == 256 && a.split && kb == 4 && !a.bf16st && !p.xhalf;
+    if (ag) p.wflags = 1;                             // the all-gather step publishes per compute wave (no drain barrier)
+    const size_t lds = ag ? burst_lds_bytes_ag(4) + 2048 : xpack ? (size_t)49152 + 2048
                              : (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
     p.trall_off = (int)((lds - 2048) / 4);
     static bool attr_b = false;
@@ -957,6 +1086,8 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         DEP_BWD_ATTR(2, false, 4); DEP_BWD_ATTR(4, false, 4); DEP_BWD_ATTR(2, true, 4); DEP_BWD_ATTR(4, true, 4);
         DEP_BWD_ATTR(2, false, 6); DEP_BWD_ATTR(4, false, 6); DEP_BWD_ATTR(2, true, 6); DEP_BWD_ATTR(4, true, 6);
         DEP_BWD_ATTR(8, false, 0); DEP_BWD_ATTR(8, true, 0);
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(burst_lds_bytes_ag(4) + 2048));
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true, 4, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(burst_lds_bytes_ag(4) + 2048));
 #undef DEP_BWD_ATTR1
 #undef DEP_BWD_ATTR
         attr_b = true;
@@ -980,7 +1111,9 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
             case 64: if (a.split) DEP_BWD_LAUNCH(1, true); else DEP_BWD_LAUNCH(1, false); break;
             case 128: if (a.split) DEP_BWD_LAUNCH(2, true); else DEP_BWD_LAUNCH(2, false); break;
             case 256:
-                if (a.bf16st) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, true>), grid, block, lds, a.stream, p);
+                if (ag && a.sv16) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, false, true>), grid, block, lds, a.stream, p);
+                else if (ag) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, false, false, true>), grid, block, lds, a.stream, p);
+                else if (a.bf16st) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, true>), grid, block, lds, a.stream, p);
                 else if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false);
                 break;
             default:                                  // 512: round-1 schedule only (kb == 0)
