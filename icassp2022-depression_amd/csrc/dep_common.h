@@ -162,7 +162,7 @@ struct dep_sweep_bwd_args {
     hipStream_t stream;
 };
 bool dep_cluster_bwd_pk_ok(int H, int T);
-#define DEP_BWD_AG_DEFAULT 0          /* the GRU-256 backward sweep's exchange: 0 = reduce-scatter of fp32 partials, 1 = all-gather of gate gradients (DEP_BWD_AG overrides) */
+#define DEP_BWD_AG_DEFAULT 1          /* the GRU-256 backward sweep's exchange: 0 = reduce-scatter of fp32 partials, 1 = all-gather of gate gradients (DEP_BWD_AG overrides) */
 bool dep_cluster_bwd_ag_on();
 bool dep_cluster_lstm_bwd_pk_ok(int T);
 bool dep_cluster_lstm_sv16_ok();

@@ -83,7 +83,7 @@ constexpr size_t burst_lds_bytes_ag(int KB) { return (size_t)(AG_IBUF_F + KB * 6
 template <int NTW, bool SPLIT, int KB, bool SV16 = false, bool BF = false, bool AG = false>      // output tiles per wave = H/64
 __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1(P2 p) {
     static_assert(!BF || (SV16 && KB > 0), "bf16 storage: 16-bit gates, burst kernel");
-    static_assert(!AG || (SPLIT && KB == 4 && NTW == 4 && !BF), "all-gather exchange: H = 256, split products, burst length 4");
+    static_assert(!AG || (SPLIT && KB == 4 && NTW == 4), "all-gather exchange: H = 256, split products, burst length 4");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 96, KCB = KS / 16, LDG = KS + LPAD;
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane (208-byte rows)
@@ -477,18 +477,23 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's six stores are acknowledged
             BSTAMP(2);
             if (lane == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
-            if (masked) mk = draw(t - 1);                    // next step's mask, in the shadow of the wait below
             BSTAMP(3);
-            if (!wait_flags(srcflags, 8, epoch, p.status, 3)) return;
-            BSTAMP(4);
+            // One vector poll of the eight per-wave flags of both source members, then all twelve requests; the Philox draw of the next
+            // step's dropout mask (layer 0 only, ~150 VALU instructions) goes behind the requests, into the loads' shadow.  Measured and
+            // dropped (profiles/r05_s2_allgather_poll_variants.txt): member-by-member poll + requests (the second poll returns behind the
+            // first six loads: +2 %), polling through the scalar path (s_load ... glc: the flags arrive thousands of ticks late, 2x slower).
             const unsigned lo_ = (unsigned)(t & 1) * par_bytes + ld0;
             u32x4 gfr[6][2];
+            if (!wait_flags(srcflags, 8, epoch, p.status, 3)) return;
+            BSTAMP(4);
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     gfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo_ + (unsigned)(ks * 2 + pl) * 1024, 0, 16 /* sc1: served by L2 */);
             __builtin_amdgcn_sched_barrier(0);               // all twelve requests first (hipcc otherwise sinks each load next to its MFMAs: twelve round trips in a row)
+            if (masked) mk = draw(t - 1);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[2] = {zero4(), zero4()};
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
@@ -1071,7 +1076,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.xhalf = (xpack || (xhalf_env == 2 && a.H == 256 && a.B <= CH / 2)) ? 1 : 0;
     const int kb = (a.H >= 512 || xpack) ? 0 : kb_env;             // H = 512: 192 weight registers per compute wave leave no room for a second wave per SIMD
     // Round 5: the all-gather exchange (AG above).  DEP_BWD_AG=1 selects it for the H = 256 split-precision burst kernel.
-    const bool ag = dep_cluster_bwd_ag_on() && a.H == 256 && a.split && kb == 4 && !a.bf16st && !p.xhalf;
+    const bool ag = dep_cluster_bwd_ag_on() && a.H == 256 && a.split && kb == 4 && !p.xhalf;
     if (ag) p.wflags = 1;                             // the all-gather step publishes per compute wave (no drain barrier)
     const size_t lds = ag ? burst_lds_bytes_ag(4) + 2048 : xpack ? (size_t)49152 + 2048
                              : (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
@@ -1088,6 +1093,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         DEP_BWD_ATTR(8, false, 0); DEP_BWD_ATTR(8, true, 0);
         (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(burst_lds_bytes_ag(4) + 2048));
         (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true, 4, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(burst_lds_bytes_ag(4) + 2048));
+        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true, 4, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(burst_lds_bytes_ag(4) + 2048));
 #undef DEP_BWD_ATTR1
 #undef DEP_BWD_ATTR
         attr_b = true;
@@ -1111,7 +1117,8 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
             case 64: if (a.split) DEP_BWD_LAUNCH(1, true); else DEP_BWD_LAUNCH(1, false); break;
             case 128: if (a.split) DEP_BWD_LAUNCH(2, true); else DEP_BWD_LAUNCH(2, false); break;
             case 256:
-                if (ag && a.sv16) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, false, true>), grid, block, lds, a.stream, p);
+                if (ag && a.bf16st) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, true, true>), grid, block, lds, a.stream, p);
+                else if (ag && a.sv16) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, false, true>), grid, block, lds, a.stream, p);
                 else if (ag) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, false, false, true>), grid, block, lds, a.stream, p);
                 else if (a.bf16st) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, true>), grid, block, lds, a.stream, p);
                 else if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false);

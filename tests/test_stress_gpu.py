@@ -28,6 +28,8 @@ CASES = [
     ('gru', 8, {'DEP_GEMM_MODE': 'f32'}, []),                    # exact-fp32 sweeps (different member kernels)
     ('gru', 8, {}, ['--H', '128']),                               # 32-unit-member forward kernel
     ('gru', 6, {'DEP_FUSED2_BWD': '1'}, []),                      # opt-in fused two-layer backward: same bits every run
+    ('gru', 8, {'DEP_BWD_AG': '0'}, []),                          # round 5: the default backward exchange is the all-gather of gate gradients; 0 = the reduce-scatter of fp32 partials
+    ('gru', 6, {'DEP_BWD_AG': '0'}, ['--load', '--load-phase', 'bwd']),
     ('gru', 8, {'DEP_BWD_BURST': '0'}, []),                       # round-1 backward schedule (no service waves)
     ('gru', 8, {'DEP_BWD_BURST': '6'}, ['--load', '--load-phase', 'bwd']),   # longer bursts, with a co-scheduled kernel
     ('gru', 6, {'DEP_BWD_BURST': '4', 'DEP_NUM_CUS': '200'}, ['--H', '128']),
@@ -112,6 +114,17 @@ def test_backward_burst_variants_pass_the_kernel_parity_suite(burst):
     """gru_bwd_cluster_r1<.., KB>: KB = 4 is the default; the round-1 schedule (0) and the longer bursts (6)
     stay parity-green -- the GRU part of the RNN-stack suite in a process with DEP_BWD_BURST set, against the oracle."""
     e = dict(os.environ, DEP_BWD_BURST=burst)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
+                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+
+
+def test_backward_reduce_scatter_exchange_passes_the_kernel_parity_suite():
+    """Round 5: gru_bwd_cluster_r1<.., AG = true> (all-gather of the members' gate gradients, column-sliced W_hh) is the default for
+    H = 256; DEP_BWD_AG=0 selects the reduce-scatter of fp32 partial dh it replaced, which stays parity-green: the GRU part of the
+    RNN-stack suite against the oracle."""
+    e = dict(os.environ, DEP_BWD_AG='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
