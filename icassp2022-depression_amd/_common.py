@@ -127,6 +127,7 @@ def predict(output, out=None):
         return p
     if out is not None:
         assert out.is_contiguous() and out.dtype == torch.int64 and out.numel() == probs.shape[0]
+        assert probs.is_contiguous() and probs.dtype == torch.float32 and probs.dim() == 2
         if probs.shape[0]:
             L.check(L.load().dep_argmax_count(probs.data_ptr(), None, 0, probs.shape[0], probs.shape[1], None, out.data_ptr(),
                                               L.stream()), 'dep_argmax_count')
@@ -168,6 +169,8 @@ def store_predictions(buf, at, output):
     if n and not o.is_cuda:
         buf[at:at + n] = o.reshape(-1)
     elif n:
+        assert 0 <= at and at + n <= buf.numel() and buf.dtype == torch.float32 and o.dtype == torch.float32 and o.is_contiguous() \
+            and buf.is_contiguous(), 'store_predictions: fp32 contiguous tensors, at + n <= len(buf)'
         L.check(L.load().dep_copy2d(o.data_ptr(), 1, buf.data_ptr() + 4 * at, 1, n, 1, L.stream()), 'dep_copy2d')
 
 
@@ -237,7 +240,7 @@ def _fingerprint(arr):
     flat = arr.reshape(-1)
     step = max(1, flat.size // 65536)
     s = float(np.asarray(flat[::step], dtype=np.float64).sum())
-    if arr.ndim >= 2 and arr.shape[0] > 0:
+    if arr.ndim >= 2 and arr.shape[0] > 0 and flat.size > 0:          # (zero-width rows have nothing to probe)
         rows = arr.reshape(arr.shape[0], -1)
         cols = (np.arange(rows.shape[0], dtype=np.int64) * 2654435761) % rows.shape[1]
         s2 = float(np.asarray(rows[np.arange(rows.shape[0]), cols], dtype=np.float64).sum())
@@ -268,6 +271,10 @@ class FeatureFeeder:
     def __init__(self, features, idxs, device, role='x'):
         self.idxs = np.asarray(idxs, dtype=np.int64).reshape(-1)
         self.device = device
+        n_rows = len(features)
+        if self.idxs.size and (self.idxs.min() < 0 or self.idxs.max() >= n_rows):      # the device gather does not range-check (index_select did)
+            bad = int(self.idxs.min()) if self.idxs.min() < 0 else int(self.idxs.max())
+            raise IndexError(f'index {bad} is out of bounds for a feature array of {n_rows} rows')
         self.Xd = device_features(features, device, role)
         self.contiguous = self.idxs.size > 0 and bool(np.all(np.diff(self.idxs) == 1))
         if self.Xd is not None:
@@ -333,7 +340,11 @@ class PairFeeder:
         # or editing a middle pair in place is seen unless it misses all probes (then: invalidate_device_features())
         def probe(e):
             a, t = np.asarray(e[0]).reshape(-1), np.asarray(e[1]).reshape(-1)
+            if a.size == 0 or t.size == 0:                # an empty modality array has nothing to probe
+                return 0.0
             return float(a[0]) + float(a[a.size // 2]) + float(t[0]) + float(t[t.size // 2])
+        if any(i < 0 or i >= n for i in self.idxs):       # the device gather does not range-check
+            raise IndexError(f'pair index out of bounds for a list of {n} pairs')
         key = (n, np.asarray(pairs[0][0]).shape, np.asarray(pairs[0][1]).shape, str(device),
                float(np.asarray(pairs[0][0], dtype=np.float64).sum() + np.asarray(pairs[-1][1], dtype=np.float64).sum()),
                float(sum(probe(e) for e in pairs)))

@@ -313,7 +313,14 @@ def loss_accumulate(loss, status, soft, acc):
 def gather_rows(src, idx, out=None):
     """src (N, ...) fp32 contiguous, idx (n,) int64 on the device -> (n, ...) rows (dep_gather_rows)."""
     n = idx.numel()
-    row = src[0].numel()
+    assert src.dtype == torch.float32 and src.dim() >= 1
+    row = int(src.numel() // src.shape[0]) if src.shape[0] else 0          # (an empty corpus has no src[0])
+    if n and src.shape[0] == 0:
+        raise IndexError('gather_rows: indices into an empty array')
+    if os.environ.get('DEP_DEBUG_BOUNDS', '0') == '1' and n:               # debug: the range check index_select used to make (one host sync)
+        lo_, hi_ = int(idx.min()), int(idx.max())
+        if lo_ < 0 or hi_ >= src.shape[0]:
+            raise IndexError(f'gather_rows: index {lo_ if lo_ < 0 else hi_} out of range for {src.shape[0]} rows')
     if out is None:
         out = torch.empty((n,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
     if n:
@@ -329,6 +336,8 @@ def concat2(a, b):
     """torch.cat((a, b), dim=1) of two (B, .) fp32 matrices as two strided copies (dep_copy2d)."""
     B, na = a.shape
     nb = b.shape[1]
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and b.shape[0] == B and (B == 0 or (a.stride(1) == 1 and b.stride(1) == 1)), \
+        'concat2: two fp32 matrices with unit inner stride and equal row counts'
     out = torch.empty(B, na + nb, dtype=torch.float32, device=a.device)
     if B:
         lib = load()
@@ -343,7 +352,7 @@ def argmax_count(probs, labels=None, count=None, want_pred=False):
     B, Cc = probs.shape
     pred = torch.empty(B, 1, dtype=torch.int64, device=probs.device) if want_pred else None
     if B:
-        assert probs.is_contiguous()
+        assert probs.is_contiguous() and probs.dtype == torch.float32
         i64 = 0
         if labels is not None:
             assert labels.is_cuda and labels.is_contiguous() and labels.dtype in (torch.int64, torch.int32)

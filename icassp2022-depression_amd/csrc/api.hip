@@ -159,6 +159,10 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
                 if (b1 > gb) gb = b1;
             }
     }
+    if (d->cell == DEP_CELL_GRU && d->dirs == 1 && d->training) {      // dW_ih + dW_hh of a layer as one launch (dep_gemm_tn_pair): two sets of partials
+        const size_t b2 = 2 * dep_gemm_workspace_bytes(1, 0, (int)(G * H), (int)H, (int)lo.BT);
+        if (b2 > gb) gb = b2;
+    }
     lo.gemm = w; lo.gemm_bytes = gb; w += al(gb / sizeof(float) + 64);
     // impl: 0 auto (cluster > tile-MFMA > generic), 1 generic, 2 tile-MFMA, 3 cluster (must be supported)
     const bool cok = d->cell == DEP_CELL_GRU ? dep_cluster_ok(d->cell, d->H, d->B, d->dirs) : dep_cluster_lstm_ok(d->H, d->B, d->dirs);
@@ -680,7 +684,16 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
             }
             rc = dep_multi_copy(D, src, nullptr, dst, cnt, s); if (rc) return rc;
         }
-        for (int dd = 0; dd < D; ++dd) {
+        bool paired = false;
+        if (pk_gru && !lo.bf16st && !stacked && D == 1 && Kl == H) {
+            // Round 5: dW_ih and dW_hh of this layer in ONE launch -- both read the PK gate gradients, [dr | dz] are the same bytes
+            // (gemm_bf16x3_tn_pair; bit-identical to the two calls below, which remain the path for every other configuration)
+            float* const* gl = dweights + (size_t)l * 4;
+            const int pr = dep_gemm_tn_pair(G * H, H, BTr, dgi, ldg, 2 * H, H, in, Kl, R + lo.y[l], H, T, -1, gl[0], Kl, gl[1], H, gws, gwsb, s);
+            if (pr < 0) return pr;
+            paired = pr == 1;
+        }
+        for (int dd = 0; dd < D && !paired; ++dd) {
             float* const* gl = dweights + (size_t)(l * D + dd) * 4;
             const float* dg = dgi + (size_t)dd * G * H;
             // dW_ih (G*H, Kl) = dG^T * in

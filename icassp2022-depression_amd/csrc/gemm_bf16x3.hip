@@ -222,8 +222,10 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
 // TERMS = 3: the split-precision product (default).  TERMS = 1: a_hi * b_hi only -- plain bf16 products with fp32 accumulation
 // (dep_set_gemm_mode(2), the "bf16" throughput mode of BASELINE configs[1]: a third of the MFMAs, no lo planes; relative error
 // per product ~4e-3, so it is a separately labelled mode with its own tolerance, never the parity path).
+// (the kernel's whole body as a device function of (parameters, block id, block count): gemm_bf16x3_pair below runs TWO contractions
+// in one launch by handing alternate workgroup slots to either)
 template <bool TA, bool TB, bool VEC, int BMT, int TERMS = 3, int FA = FMT_F32, int FB = FMT_F32>
-__global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p) {
+__device__ __forceinline__ void gemm_bf16x3_walk(const GemmP& p, const int block_id, const int block_count) {
     if (p.only_if && *p.only_if == 0) return;
     constexpr bool A_TR = TA, B_TR = !TB;
     constexpr int MI = BMT / 64;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
     const int half = lane >> 5, l31 = lane & 31;
 
     const int ntiles = p.gx * p.gy * p.splits;
-    const int x8 = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int x8 = block_id & 7, slot = block_id >> 3, slots = block_count >> 3;
     if (x8 < p.xcd_lo || x8 >= p.xcd_lo + p.xcd_n) return;
     const int xcd = x8 - p.xcd_lo;
     const int q = ntiles / p.xcd_n, r = ntiles % p.xcd_n;
@@ -352,6 +354,52 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p)
         if (!has_next) break;
         tile = next; m0 = nm0; n0 = nn0; kbeg = nkb; kend = nke; bz = nbz;
     }
+}
+
+template <bool TA, bool TB, bool VEC, int BMT, int TERMS = 3, int FA = FMT_F32, int FB = FMT_F32>
+__global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3(GemmP p) {
+    gemm_bf16x3_walk<TA, TB, VEC, BMT, TERMS, FA, FB>(p, blockIdx.x, gridDim.x);
+}
+
+// Round 5: dW_ih and dW_hh of a GRU layer as ONE launch.  Both are TN contractions over K = B T whose A operand is the
+// sweep's 4H-wide PK gate-gradient image -- columns [dr | dz] are the SAME bytes for both, only the third block differs (dn / dn*r) -- so two
+// launches fetched two thirds of A twice (PMC: 0.63 GB per launch, four launches per step).  Here the launch has twice the workgroups of one
+// contraction and slot 2i / 2i+1 of an XCD walk tile list i of problem 0 / problem 1: the two workgroups that need one (K chunk, M tile)
+// panel of A run next to each other in time and on one XCD, and the second one finds it in that L2.  No per-tile operand selection (round 3's
+// merged-tile attempt lost more to its uniform selects than the shared fetch saved): a workgroup belongs to ONE problem for its whole life.
+// Tile decomposition, K chunks and split-K order per problem are exactly those of the single launches: the results are bit-identical.
+template <bool VEC, int BMT, int FA, int FB>
+__global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3_tn_pair(GemmP p0, GemmP p1) {
+    const int x8 = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bid = ((slot >> 1) << 3) | x8, nblk = gridDim.x >> 1;
+    if (slot & 1) gemm_bf16x3_walk<true, false, VEC, BMT, 3, FA, FB>(p1, bid, nblk);
+    else gemm_bf16x3_walk<true, false, VEC, BMT, 3, FA, FB>(p0, bid, nblk);
+}
+
+// both problems' split-K partials in one launch (blockIdx.y = problem)
+__global__ void splitk_reduce2_pair(const float* __restrict__ part0, const float* __restrict__ part1, int splits, int M, int N,
+                                    float* C0, int ldc0, float* C1, int ldc1) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * N) return;
+    const float* part = blockIdx.y ? part1 : part0;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    const size_t MN = (size_t)M * N;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // the same four interleaved sums as splitk_reduce2: bit-identical
+    int z = 0;
+    for (; z + 15 < splits; z += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = part[(size_t)(z + k) * MN + idx];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) { s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; s3 += v[k + 3]; }
+    }
+    for (; z + 3 < splits; z += 4) {
+        s0 += part[(size_t)z * MN + idx]; s1 += part[(size_t)(z + 1) * MN + idx];
+        s2 += part[(size_t)(z + 2) * MN + idx]; s3 += part[(size_t)(z + 3) * MN + idx];
+    }
+    for (; z < splits; ++z) s0 += part[(size_t)z * MN + idx];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (blockIdx.y) C1[(size_t)m * ldc1 + n] = s; else C0[(size_t)m * ldc0 + n] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -792,7 +840,8 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     // (round 4: long-K projections -- cfg3's F = 1024 layer -- take the 256-row tile too; DEP_GEMM_NT256=0 restores 128 rows for every NT call)
     static int nt256 = -1;
     if (nt256 < 0) { const char* e = getenv("DEP_GEMM_NT256"); nt256 = (e && e[0] == '0') ? 0 : 1; }
-    const bool big = bm256 && M >= 512 && (!(!transA && transB) || (nt256 && K >= 512));
+    // (a pre-split A operand in the NT form has only the 128-row instantiation: the tile grid must follow -- ADVICE r4)
+    const bool big = bm256 && M >= 512 && (!(!transA && transB) || (nt256 && K >= 512)) && !(fa != FMT_F32 && !transA && transB);
     const int BMT = big ? 256 : 128;
     GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl, dep_gemm_predicate(), g_xcd_lo, g_xcd_n, transA ? g_skip_at : 0, transA ? g_skip_by : 0};
     // persistent launch: at most `persist` workgroups (a multiple of 8: one share per XCD), each walks a list of tiles
@@ -841,5 +890,30 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
         hipLaunchKernelGGL(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, dep_gemm_predicate(), part, splits, M, N, C, ldc, bias, beta);
         DEP_CHECK_LAUNCH();
     }
+    return DEP_OK;
+}
+
+// dW_ih + dW_hh of one GRU layer in one launch (gemm_bf16x3_tn_pair above).  A = the sweep's PK gate-gradient image for both (problem 1
+// reads it through the column skip), B0 = the layer's input, B1 = the layer's own output shifted one step; same (M, N, K, splits, kchunk).
+// The caller (dep_gemm_tn_pair, gemm.hip) has checked formats / alignment / sizes; returns DEP_OK after enqueueing both the walk and the reduce.
+int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A, int lda, int skip_at1, int skip_by1,
+                                   const float* B0, int ldb0, const float* B1, int ldb1, int seq_T1, int shift1,
+                                   float* C0, int ldc0, float* C1, int ldc1, int splits, int kchunk, float* part0, float* part1, hipStream_t s) {
+    DEP_CHECK_ARG(g_fmt_a == FMT_PK && g_fmt_b == FMT_F32 && M >= 512 && splits > 1 && part0 && part1);
+    DEP_CHECK_ARG(K % 2 == 0 && kchunk % 2 == 0 && dep_gemm_predicate() == nullptr && g_xcd_lo == 0 && g_xcd_n == 8);
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("DEP_GEMM_PERSIST"); persist = e ? atoi(e) : 768; if (persist < 8) persist = 8; persist = persist / 8 * 8; }
+    GemmP p0{M, N, K, A, lda, B0, ldb0, C0, ldc0, nullptr, 0.f, 0, 0, kchunk, splits, part0, dep_cdiv(N, BN), dep_cdiv(M, 256), 0, nullptr, 0, 8, 0, 0};
+    GemmP p1 = p0;
+    p1.B = B1; p1.ldb = ldb1; p1.C = C1; p1.ldc = ldc1; p1.seqT = seq_T1; p1.shiftB = shift1; p1.part = part1; p1.skip_at = skip_at1; p1.skip_by = skip_by1;
+    const int ntiles = p0.gx * p0.gy * splits;
+    const int cap = persist * 2 / 3 / 2;                          // two resident workgroups per CU with 256-row tiles, half of the slots per problem
+    const int per_xcd = (ntiles + 7) / 8;
+    dim3 g((per_xcd < cap / 8 ? per_xcd : cap / 8) * 8 * 2);
+    hipLaunchKernelGGL((gemm_bf16x3_tn_pair<true, 256, FMT_PK, FMT_F32>), g, dim3(NT), 0, s, p0, p1);
+    DEP_CHECK_LAUNCH();
+    const long n = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce2_pair, dim3(dep_cdiv(n, 256), 2), dim3(256), 0, s, part0, part1, splits, M, N, C0, ldc0, C1, ldc1);
+    DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

@@ -238,8 +238,10 @@ class LossSum:
     def __init__(self, device):
         self._acc = torch.zeros(3, dtype=torch.float64, device=device)       # [loss sum, max status word, max fallback word]
         self._reduce = False
+        self._value = None                                # result of the last item(), valid until the next add()
 
     def add(self, loss, model=None):
+        self._value = None
         v = loss._v.reshape(-1)
         self._reduce = self._reduce or loss._reduce
         loss._reduce = False                              # summed here, once
@@ -258,6 +260,12 @@ class LossSum:
         return self
 
     def item(self):
+        """EVERY rank must call item() at the same point of its loop (it is a collective whenever world_size > 1 -- the flags travel
+        even when the loss itself is already global); a rank-0-only call would wait for the others for ever.  The
+        accumulator is cleared: a second item() without an add() in between returns the same value again WITHOUT a collective, and a
+        LossSum reused for the next epoch starts from zero."""
+        if self._value is not None:
+            return self._value
         acc = self._acc
         if parallel.world_size() > 1:
             t = acc.clone()
@@ -267,11 +275,15 @@ class LossSum:
             acc = t if self._reduce else torch.stack((acc[0], t[1], t[2]))
             self._reduce = False
         v, bad, fell = (float(x) for x in acc.tolist())
+        self._acc.zero_()
         if fell != 0:
             L.note_fallback()                             # right results, but stop paying the hello time-out (every rank together)
         if bad != 0:
-            raise L.DepError('a recurrent sweep gave up waiting for a cluster member during this epoch (status %d on some rank): the GPU '
-                             'was shared with another kernel; DEP_FUSED2=0 DEP_CLUSTER16=0 selects the sweeps that tolerate it' % int(bad))
+            # (under data parallelism `bad` is the SUM of the ranks' status words: non-zero iff a sweep gave up on some rank, not a code)
+            raise L.DepError('a recurrent sweep gave up waiting for a cluster member during this epoch (status words summed over %d rank(s): %d): '
+                             'the GPU was shared with another kernel; DEP_FUSED2=0 DEP_CLUSTER16=0 selects the sweeps that tolerate it'
+                             % (parallel.world_size(), int(bad)))
+        self._value = v
         return v
 
 

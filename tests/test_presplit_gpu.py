@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp_path, tag, pk, B, T, F, dx, lstm=False):
+def _run(tmp_path, tag, pk, B, T, F, dx, lstm=False, env=None):
     out = str(tmp_path / f'{tag}_{pk}.npz')
     e = dict(os.environ, DEP_DGI_PK=str(pk))
+    e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, str(B), str(T), str(F)] + (['dx'] if dx else []) + (['lstm'] if lstm else []),
                        env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -28,6 +29,18 @@ def _run(tmp_path, tag, pk, B, T, F, dx, lstm=False):
 def test_pk_gate_gradients_leave_every_gradient_bit_identical(tmp_path, B, T, F, dx):
     a = _run(tmp_path, 'a', 0, B, T, F, dx)
     b = _run(tmp_path, 'b', 1, B, T, F, dx)
+    for k in a.files:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+
+
+# Round 5: dW_ih and dW_hh of a GRU layer whose input is as wide as its state (layer 1 always; layer 0 when F = H) are ONE launch over the
+# shared PK image (gemm_bf16x3_tn_pair).  Same tiles, K chunks and split-K order per contraction: every gradient bit-identical to the two
+# launches (DEP_DW_PAIR=0).  F = 64: only layer 1 pairs; F = 256: both; the benchmark's full shape once.
+@pytest.mark.parametrize('B,T,F,dx', [(416, 20, 64, False), (416, 22, 256, True), (512, 300, 256, False)])
+def test_paired_weight_gradient_launch_leaves_every_gradient_bit_identical(tmp_path, B, T, F, dx):
+    a = _run(tmp_path, 'a', 1, B, T, F, dx, env={'DEP_DW_PAIR': '0'})
+    b = _run(tmp_path, 'b', 1, B, T, F, dx, env={'DEP_DW_PAIR': '1'})
     for k in a.files:
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
