@@ -91,7 +91,7 @@ def launch_check(args):
 def build_workload(name, dev, rank, world):
     """Model, optimizer, synthetic HBM-resident batch and the train-step closure of one WORKLOADS entry."""
     import importlib
-    from icassp2022_depression_amd import nn, parallel
+    from icassp2022_depression_amd import _common, nn, parallel
     modname, cls, B, T, F, H = WORKLOADS[name]
     mod = importlib.import_module('icassp2022_depression_amd.' + modname)
     torch.manual_seed(0)
@@ -113,7 +113,7 @@ def build_workload(name, dev, rank, world):
             parallel.set_global_count(B * world)
             optimizer.zero_grad()
             tf, af = model.pretrained_feature((xa, xt))
-            model(torch.cat((tf, af), dim=1))
+            model(_common.concat_features(tf, af))          # dep_copy2d x 2, as the product loop (fuse_net_whole.train)
             loss = criterion(tf, af, y, model)
             loss.backward()
             optimizer.step()
@@ -253,8 +253,30 @@ def main():
     final_loss = loss.item()
     # which GRU forward produced the headline: the exclusive fused launch, or -- on a shared GPU -- its on-device fallback
     fbw = [int(w.item()) for w in (model.fallback_words() if hasattr(model, 'fallback_words') else [])]
-    fwd_path = None if not fbw else ('fallback (co-schedule-tolerant sweeps redid the forward)' if any(fbw) else
-                                     'exclusive fused two-layer launch' if L.load().dep_rnn_get_exclusive() else 'tolerant sweeps (dep_rnn_set_exclusive(0))')
+    stw = [int(w.item()) for w in (model.status_words() if hasattr(model, 'status_words') else [])]
+    PATHS = ['not a GRU stack', 'exclusive fused two-layer launch', 'tolerant sweeps (dep_rnn_set_exclusive(0))',
+             'fallback (co-schedule-tolerant sweeps redid the forward)']
+    my_path = 0 if not fbw else (3 if any(fbw) else (1 if L.load().dep_rnn_get_exclusive() else 2))
+    fwd_path = None if not fbw else PATHS[my_path]
+    # the line is rank 0's, the forward path / sweep status / transport are EVERY rank's -- a fallback or a raised
+    # status word on rank k must show in the N-GPU line.  One small all-gather outside the timed region.
+    per_rank = None
+    if world > 1:
+        import torch.distributed as dist
+        mine = torch.tensor([my_path, max(stw) if stw else 0, 1 if parallel.transport() == 'rccl-native' else 0], dtype=torch.int64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if dist.get_backend() != 'nccl':
+            mine = mine.cpu(); allr = [t.cpu() for t in allr]
+        dist.all_gather(allr, mine)
+        rows = [[int(v) for v in t.tolist()] for t in allr]
+        per_rank = {'gru_forward_path_by_rank': [PATHS[r[0]] for r in rows], 'sweep_status_by_rank': [r[1] for r in rows],
+                    'native_rccl_by_rank': [bool(r[2]) for r in rows]}
+        if len({r[0] for r in rows}) > 1:
+            fwd_path = 'MIXED over ranks: ' + '; '.join(f'rank {i}: {PATHS[r[0]]}' for i, r in enumerate(rows))
+        elif fbw:
+            fwd_path = PATHS[rows[0][0]] + f' (all {world} ranks)'
+        if any(r[1] for r in rows):
+            raise SystemExit(f'bench.py: a recurrent sweep raised its status word on some rank {[r[1] for r in rows]}: refusing to report the step')
 
     extras = not args.profile_run
     # exposed communication per rank: the same step with the gradient exchange switched off, timed like the
@@ -537,6 +559,15 @@ def main():
            'final_loss': round(final_loss, 6),
            'gru_forward_path': fwd_path,
            'roofline': roofline}
+    if world > 1:
+        # top level, not only config.backend: which transport carried the gradients, and why if it is not the C-ABI's own communicator
+        tr = parallel.transport()
+        out['comm_transport'] = tr
+        out['comm_transport_is_native_rccl'] = bool(per_rank and all(per_rank['native_rccl_by_rank']))
+        if tr != 'rccl-native':
+            out['comm_transport_reason'] = ('gloo dry run (ranks share the visible GPUs)' if args.backend == 'gloo'
+                                            else str(parallel._native.get('why') or 'native communicator not built on every rank'))
+        out['ranks'] = per_rank
     if eval_ms is not None:
         out['eval_forward'] = {'value': round(B / (eval_ms * 1e-3), 1), 'unit': 'utterances/s', 'ms_per_batch': round(eval_ms, 3),
                                'note': 'forward only (evaluate), rank 0, outside the headline region'}

@@ -259,3 +259,8 @@ def test_bench_two_rank_dry_run_on_one_gpu():
     assert len(ex['step_without_comm_ms_by_rank']) == 2 and len(ex['exposed_comm_ms_by_rank']) == 2
     assert all(t > 0 for t in ex['step_without_comm_ms_by_rank']) and d['extra']['other_workloads'] is None
     assert d['extra']['f32_exact'] is None and d['extra']['train_e2e'] is None and 'cpu_baseline' not in d       # rank-0-at-N=1 legs only
+    # round 5: the line explains itself -- every rank's forward path / sweep status, and the transport at top level
+    rk = d['ranks']
+    assert len(rk['gru_forward_path_by_rank']) == 2 and rk['sweep_status_by_rank'] == [0, 0] and rk['native_rccl_by_rank'] == [False, False]
+    assert d['comm_transport'] == 'torch.distributed' and d['comm_transport_is_native_rccl'] is False and 'gloo' in d['comm_transport_reason']
+    assert 'rank' in d['gru_forward_path']              # "... (all 2 ranks)" or "MIXED over ranks: ..."
