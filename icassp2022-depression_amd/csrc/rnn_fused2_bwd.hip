@@ -1,50 +1,65 @@
-// Two-layer GRU BPTT as ONE cluster-parallel launch (the backward twin of rnn_fused2.hip): layer 0 runs one step behind
-// layer 1, so the backward pass costs T + 1 dependent hand-offs instead of 2 T, and the gradient that flows from layer 1
-// into layer 0 (dX of layer 1: B x T x H, the former NN GEMM and its HBM round trip) never exists in HBM.
+// Two-layer GRU BPTT as ONE cluster-parallel launch (the backward twin of rnn_fused2.hip), round 5: ALL-GATHER form.
 //
-// Per 16-utterance tile a cluster of NC = 8 workgroups (one per CU, co-resident); member c owns hidden units [32c, 32c+32) of
-// both layers.  Twelve waves, three groups of four, each keeping the TRANSPOSED weight slice of the member's 96 gate rows
-// register-resident (96 VGPRs, (hi, lo) bf16 planes; wave = 4 of the 16 output column tiles, K = 96 = three 32-wide k-steps):
-//   group 0 : W_hh(l1)^T x [dr, dz, dn*r](l1, t)     -> partial dh1_{t-1}            (16 x 256, all columns)
-//   group 1 : W_ih(l1)^T x [dr, dz, dn  ](l1, t)     -> partial d(dropout(y0))_t     (what used to be dX of layer 1)
-//   group 2 : W_hh(l0)^T x [dr, dz, dn*r](l0, t+1)   -> partial dh0_t
-// Fused step u (0..T; layer 1 at t = T-1-u, layer 0 at t+1): [gate gradients of both layers on groups 0 / 2 (2 elements
-// per thread), written as bf16 planes] -> barrier -> [36 MFMAs per wave] -> the three partial blocks are published in
-// MFMA-fragment order (16-byte stores), drain, barrier, ONE flag per member -> [groups 0 / 2: poll the 8 flags, gather the own
-// 32 columns of every member's partials (reduce-scatter, summed in member order: deterministic) | group 1: owns every HBM
-// stream of the member: saved gates / h_{t-1} / dy of the next steps into LDS, dgi / dghn of this step out] -> barrier.
-// Exchange protocol, same-XCD fast path, parity double-buffered payload, bounded spins, sticky status: rnn_cluster_common.h.
+// Per 16-utterance tile a cluster of NC = 8 workgroups (one per CU, co-resident); member c owns hidden units [32c, 32c+32) of both
+// layers.  Twelve waves, three groups of four, each group keeping the 32 COLUMNS of one weight matrix that belong to the member's units
+// (all 3H = 768 rows, (hi, lo) bf16 planes, 96 VGPRs per wave: wave gw = the 192 rows of source members 2gw, 2gw+1 = six 32-wide k-steps):
+//   group 0 : [dr, dz, dn*r](l1, t)   x W_hh(l1)[:, own 32]  ->  dh1_{t-1}, own columns, COMPLETE     + layer 1's gate gradients
+//   group 1 : [dr, dz, dn  ](l1, t)   x W_ih(l1)[:, own 32]  ->  d(dropout(y0))_t = the gradient entering layer 0 at the member's OWN units
+//                                                                (the former dX GEMM of layer 1 and its HBM round trip) + every HBM stream
+//   group 2 : [dr, dz, dn*r](l0, t')  x W_hh(l0)[:, own 32]  ->  dh0_{t'-1}                            + layer 0's gate gradients
+// What travels between members is each member's own 16 x 32 gate gradients, ONCE, as the (hi, lo) bf16 words the MFMAs read, in
+// B-fragment order (layer 1: dr, dz, dn*r, dn = 8 KB, layer 0: 6 KB per member and step; the reduce-scatter form of rounds 2-4 published
+// three 16 KB blocks of fp32 partials per member and step and lost to the two per-layer sweeps).  Consumers read the fragments straight
+// from the exchange buffer into registers (rnn_cluster_bwd.hip, AG); the four K-quarter partials of a product meet in LDS (`red').
+// Group 1 works ONE STEP BEHIND: in fused step v it multiplies the layer-1 gate gradients of step v-1 -- complete and visible since the
+// barrier that ended step v-1, so it never polls -- and layer 0 runs TWO steps behind layer 1 (t0 = T+1-v).  That slack is what lets the
+// group own the member's HBM streams: its fragment requests go out first, the streams behind them, and everything it has in flight has
+// landed before the step's barrier -- no HBM access is ever in front of a wave that the cluster is waiting for.
+// Fused step v (0..T+1):  [groups 0 / 2: gate gradients (2 elements per thread) -> publish words -> acknowledged -> own flag (per wave)
+//   -> poll the 8 flags of the two source members -> 12 fragment loads (two rounds of six: registers) + 36 MFMAs -> partial to red]
+//   [group 1: fragments of step v-1 + 36 MFMAs -> red ; inputs of step v+1 HBM -> registers -> LDS, gate gradients of step v-1 LDS -> HBM]
+//   -> ONE barrier -> [K-quarter sums: dh1_rec (group 0), dh0_rec and the masked dy0 (group 2)].
+// Layer 1's exchange buffer is triple-buffered (group 1 reads step v-1 while step v+1 may already be written by a fast member), layer
+// 0's double-buffered.  Exchange protocol, same-XCD fast path, bounded spins, sticky status: rnn_cluster_common.h.
 #include "rnn_cluster_common.h"
 
 namespace {
 using namespace depc;
 
 constexpr int BH = 256, BNC = 8, BTHREADS = 768;
-constexpr int LDGB = 128 + 8;                 // bf16 elements per row of a gate-gradient plane: [dr | dz | dn*r | dn] + pad (272-byte rows)
-constexpr int GPLANE = BT * LDGB;             // one plane (hi or lo)
 constexpr int OROW = 36, OARR = BT * OROW;    // fp32 [16 utterances][32 units] arrays, rows padded (bank conflicts)
-constexpr int N_IBUF = 11, N_OBUF = 8;       // input arrays: l1 r,z,n,hn,h_{t-1},[dy] ; l0 r,z,n,hn,h_{t-1}  (10 without dy: five per wave half)
-constexpr int B_BLOCK = BNC * BT * BH;        // floats of one partial block of one tile: [src member][out tile][lane][4]
-constexpr int N_PBLK = 4 * 4 * 256;           // group 1's partial block on its way to the publishing waves: [wave][tile][lane][4]
-constexpr size_t B_LDS_BYTES = (size_t)(2 * GPLANE + (2 * N_IBUF + 2 * N_OBUF) * OARR + N_PBLK + 64) * sizeof(float);   // 2 layers x (hi+lo) planes = 4 GPLANE bf16 = 2 GPLANE floats
+constexpr int N_IBUF = 11, N_OBUF = 8;        // input arrays: l1 r,z,n,hn,h_{t-1},[dy] ; l0 r,z,n,hn,h_{t-1}  (10 without dy: five per wave half)
+constexpr unsigned L1_MEMBER = 8 * 1024, L0_MEMBER = 6 * 1024;      // bytes: [gate][plane][64 lanes][16 B] -- l1: dr, dz, dn*r, dn ; l0: dr, dz, dn*r
+constexpr int N_RED = 3 * 4 * 2 * 256;        // floats of one step parity: [group][K quarter = wave][own tile][64 lanes][4]
+constexpr int IARR = BT * 32;                 // an INPUT array in LDS: [16 utterances][32 units] unpadded -- written by LDS-DMA (a wave instruction fills 1 KB
+                                              // contiguously), 16-byte pieces XOR-swizzled by the row so that the gate threads' column reads spread over the banks
+constexpr size_t B_LDS_BYTES = (size_t)(2 * N_RED + 2 * N_IBUF * IARR + (2 * N_OBUF + 8 + 2) * OARR + 64) * sizeof(float);
 
 struct FB {
     int B, T, nbtp, b0;
-    const u32x4* wh1; const u32x4* wi1; const u32x4* wh0;          // transposed-slice images (pack_cluster_bwd_split format)
+    const u32x4* wh1; const u32x4* wi1; const u32x4* wh0;          // pack_cluster_bwd_split images ([K member][out tile][gate][plane][lane])
     const float* y1; const float* y0;                               // forward hidden sequences (h_{t-1})
     const float* sv1; const float* sv0; unsigned svstride;          // saved r | z | n | hn, svstride floats apart
     const float* dy; const float* dpooled; float pool_scale; const float* dhn1; const float* dhn0;
     float drop_p, drop_scale; uint64_t seed; uint32_t site;
     float* dgi1; float* dghn1; float* dgi0; float* dghn0;           // (B*T, 3H) / (B*T, H)
     float* dbpart1; float* dbpart0;                                 // [batch tile][4][H] bias-gradient partials
-    unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes; int nofast;
+    unsigned* status; unsigned* flags1; unsigned* flags0; unsigned* hello;      // per-wave epoch flags of the layer-1 / layer-0 publishers: [tile][member][4]
+    float* payload; unsigned payload_bytes; unsigned l0_off;        // layer 1's three buffers, then (at l0_off bytes) layer 0's two
+    int nofast;
+    // input streams as buffer resources (LDS-DMA): per layer ONE base below its y / saved-gate arrays, the arrays as byte offsets from it
+    const char* sb1; const char* sb0; unsigned sbytes1, sbytes0;
+    unsigned o_sv1, o_y1, o_sv0, o_y0;                              // saved gates r (then z, n, hn at + k svstride floats), forward sequence
 };
 
 // Registers: 3 waves per SIMD -> 168 VGPRs, 96 of them weights.  Per-thread indices are re-derived every step from a laundered
-// threadIdx.x (see rnn_fused2.hip), and the per-role persistent state shares six vector registers:
+// threadIdx.x (see rnn_fused2.hip), the fragments come in two rounds of six (24 registers), and the per-role persistent state shares
+// six vector registers:
 //   groups 0 / 2: st[0] = (dh_rec.xy, dpool.xy)  st[1] = (db_r.xy, db_z.xy)  st[2] = (db_n.xy, db_hn.xy)
 //                 st[3] = layer 0: (dy0.xy = masked gradient from layer 1, mask.xy) ; layer 1: (d*z .xy, -, -)
-//   group 1     : st[0..4] (st[0..5] with an external dy) = the prefetched input pieces of the step after next
+//   group 1     : nothing -- its input streams go HBM -> LDS directly (buffer_load ... lds), no staging registers (the first all-gather build
+//                 staged them in 20-24 VGPRs: 31-52 VGPR spills, weight fragments reloaded from scratch inside the MFMA chain)
+// The bias-gradient accumulators (8 more registers) live in LDS (dbl): one read-modify-write of four float2 per thread and step.
 template <bool DROP, bool HASDY>
 __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -56,70 +71,78 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = w >> 2, gw = w & 3;               // 0: layer-1 recurrent, 1: layer-1 input + HBM streams, 2: layer-0 recurrent
     const int shalf = gw >> 1;
-    unsigned short* dg1 = reinterpret_cast<unsigned short*>(smem);      // layer-1 planes: hi at +0, lo at +GPLANE
-    unsigned short* dg0 = dg1 + 2 * GPLANE;
-    float* ibuf = smem + 2 * GPLANE;                  // [2 step parities][11][16][36]: l1 r,z,n,hn,hp,dy ; l0 r,z,n,hn,hp
-    float* obuf = ibuf + 2 * N_IBUF * OARR;               // [2 step parities][8][16][36] : l1 dr,dz,dn,dn*r ; l0 dr,dz,dn,dn*r
-    float* pblk = obuf + 2 * N_OBUF * OARR;
+    float* red = smem;                                // [2 step parities][3 groups][4 K quarters][2 tiles][64][4]
+    float* ibuf = smem + 2 * N_RED;                   // [2 step parities][11][16][32, swizzled]: l1 r,z,n,hn,hp,dy ; l0 r,z,n,hn,hp
+    float* obuf = ibuf + 2 * N_IBUF * IARR;           // [2 step parities][8][16][36] : l1 dr,dz,dn,dn*r ; l0 dr,dz,dn,dn*r
+    float* dbl = obuf + 2 * N_OBUF * OARR;            // [2 layers][4][16][36]: bias-gradient accumulators of the gate threads
+    float* mbuf = dbl + 8 * OARR;                     // [2 step parities][16][36]: dropout mask values of the dy0 a step ends with (drawn by group 1)
     const int b0t = p.b0 + bt * BT;
 
-    u32x4 wq[4][3][2];                                // [out tile of the wave][k-step = gate][hi, lo]
+    u32x4 wq[2][6][2];                                // [own output tile][k-step = (source member 2gw + ks/3, gate ks%3)][hi, lo]
     {
         const u32x4* wimg = grp == 0 ? p.wh1 : (grp == 1 ? p.wi1 : p.wh0);
         const int lane = tid & 63;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks)
+            for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    wq[i][ks][pl] = wimg[(size_t)(((c * 16 + gw * 4 + i) * 3 + ks) * 2 + pl) * 64 + lane];
+                    wq[i][ks][pl] = wimg[(size_t)((((2 * gw + ks / 3) * 16 + 2 * c + i) * 3 + ks % 3) * 2 + pl) * 64 + lane];
     }
-    f32x4 st[6];
+    f32x4 st[4];                                      // (st[1], st[2] unused: the accumulators moved to LDS)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) st[i] = zero4();
+    for (int i = 0; i < 4; ++i) st[i] = zero4();
+    for (int i = tid; i < 8 * OARR; i += BTHREADS) dbl[i] = 0.f;
 
-    const unsigned pstride = (unsigned)p.nbtp * 3 * B_BLOCK;
-    const unsigned tile_base = (unsigned)bt * 3 * B_BLOCK;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
-    unsigned* myflag = p.flags + bt * BNC + c;
-    unsigned* tflags = p.flags + bt * BNC;
+    const unsigned par1 = (unsigned)p.nbtp * BNC * L1_MEMBER, par0 = (unsigned)p.nbtp * BNC * L0_MEMBER;      // bytes of one buffer
+    unsigned* tflags1 = p.flags1 + bt * BNC * 4;
+    unsigned* tflags0 = p.flags0 + bt * BNC * 4;
+    unsigned* myflag = (grp == 0 ? tflags1 : tflags0) + c * 4 + gw;
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * BNC, BNC, c, p.status);
     if (sx < 0) return;
     const bool fast = sx == 1;
 
-    // ---- group 1's streams.  Thread -> (utterance su, 16-byte piece sqd of the member's 32 units); wave half -> array of a pair.
-    // Inputs of fused step uu: layer 1 at t1 = T-1-uu (r, z, n, hn, h_{t1-1}, dy), layer 0 at t0 = T-uu (r, z, n, hn, h_{t0-1}).
+    // ---- group 1's input streams: HBM -> LDS by DMA.  Inputs of fused step uu: layer 1 at t1 = T-1-uu (r, z, n, hn, h_{t1-1}, dy), layer 0
+    // at t0 = T+1-uu (r, z, n, hn, h_{t0-1}).  One wave instruction moves 8 utterance rows x 128 bytes of one array (1 KB, contiguous in LDS):
+    // instruction id q -> array q / 2, row half q % 2; wave gw issues q = gw, gw + 4, ...  Lane -> (row lane / 8, LDS piece lane % 8), and it
+    // fetches the GLOBAL piece (lane % 8) ^ (row % 8): the swizzle the readers undo.  Rows past the batch re-read the last utterance (finite
+    // values in rows whose results are never stored); a step outside the sequence is written as zeros.
+    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.sb1, 0, p.sbytes1, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.sb0, 0, p.sbytes0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, HASDY ? 0xfffffff0u : 0u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* ldsp;
     auto stage = [&](int tv, int uu) {
-        const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
-        const bool uv = b0t + su < p.B;
-        const unsigned ro = ((unsigned)(b0t + su) * T) * BH + c * 32 + sqd * 4;
-        const int t1 = T - 1 - uu, t0 = T - uu;
-        const bool a1 = uv && t1 >= 0, a0 = uv && uu >= 1 && t0 >= 0;
-        constexpr int N1 = HASDY ? 6 : 5, NA = N1 + 5, NP = (NA + 1) / 2;    // arrays of layer 1, all arrays, pairs
+        constexpr int N1 = HASDY ? 6 : 5, NA = N1 + 5;
+        const int ln = tv & 63, rw = ln >> 3;
+        const int t1 = T - 1 - uu, t0 = T + 1 - uu;
 #pragma unroll
-        for (int pr = 0; pr < NP; ++pr) {
-            const int a = pr * 2 + shalf;                 // wave-uniform array id
-            const bool l1 = a < N1;
-            const int k = l1 ? a : a - N1;                // 0..3 saved gates, 4 h_{t-1}, 5 dy (layer 1 only)
-            const int t = l1 ? t1 : t0;
-            bool on = (l1 ? a1 : a0) && a < NA;
-            const float* src;
-            if (k < 4) src = (l1 ? p.sv1 : p.sv0) + (size_t)k * p.svstride + (ro + (unsigned)t * BH);
-            else if (k == 4) { src = (l1 ? p.y1 : p.y0) + (ro + (unsigned)(t - 1) * BH); on = on && t >= 1; }
-            else { src = p.dy + (ro + (unsigned)t * BH); on = on && HASDY; }
-            st[pr] = on ? ld4(src) : zero4();
+        for (int qi = 0; qi < (2 * NA + 3) / 4; ++qi) {
+            const int q = qi * 4 + gw;                    // wave-uniform
+            if (q < 2 * NA) {
+                const int a = q >> 1, hh = q & 1;
+                const bool l1 = a < N1;
+                const int k = l1 ? a : a - N1;            // 0..3 saved gates, 4 h_{t-1}, 5 dy (layer 1 only)
+                const int t = (l1 ? t1 : t0) - (k == 4 ? 1 : 0);
+                const bool on = (l1 ? t1 >= 0 : (uu >= 2 && t0 >= 0)) && t >= 0;
+                float* dst = ibuf + ((uu & 1) * N_IBUF + a) * IARR + hh * 256;
+                if (on) {
+                    const int row = hh * 8 + rw;
+                    int b = b0t + row; b = b < p.B ? b : p.B - 1;
+                    const unsigned vo = ((unsigned)b * (unsigned)T + (unsigned)t) * (BH * 4u) + (unsigned)c * 128u + (unsigned)(((ln & 7) ^ (rw & 7)) * 16);
+                    const unsigned so = k < 4 ? (l1 ? p.o_sv1 : p.o_sv0) + (unsigned)k * p.svstride * 4u : (k == 4 ? (l1 ? p.o_y1 : p.o_y0) : 0u);
+                    if (k == 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (ldsp)dst, 16, vo, 0, 0, 0);
+                    else if (l1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ldsp)dst, 16, vo, so, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ldsp)dst, 16, vo, so, 0, 0);
+                } else {
+                    *reinterpret_cast<f32x4*>(dst + ln * 4) = zero4();
+                }
+            }
         }
     };
-    auto put_ibuf = [&](int tv, int uu) {             // staged inputs of fused step uu -> ibuf[uu & 1]
-        const int rem = tv & 127, ro = (uu & 1) * N_IBUF * OARR + (rem >> 3) * OROW + (rem & 7) * 4;
-        constexpr int NA = (HASDY ? 6 : 5) + 5, NP = (NA + 1) / 2;
-#pragma unroll
-        for (int pr = 0; pr < NP; ++pr) {
-            const int a = pr * 2 + shalf;
-            if (a < NA) *reinterpret_cast<f32x4*>(ibuf + a * OARR + ro) = st[pr];
-        }
-    };
+    // an input pair of the gate threads: utterance row j, units (ul, ul+1) -> swizzled float offset inside an array
+    auto iswz = [](int j, int ul) { return j * 32 + (((ul >> 2) ^ (j & 7)) << 2) + (ul & 3); };
     auto flush = [&](int tv, int u) {                 // gate gradients of fused step u: LDS -> HBM
         const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
         if (b0t + su >= p.B) return;
@@ -129,20 +152,12 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             const int a = pr * 2 + shalf;                 // 0..3 layer 1 (dr, dz, dn, dn*r), 4..7 layer 0
             const bool l1 = a < 4;
             const int k = a & 3;
-            const int t = l1 ? T - 1 - u : T - u;
-            const bool on = l1 ? (u <= T - 1) : (u >= 1);
+            const int t = l1 ? T - 1 - u : T + 1 - u;
+            const bool on = l1 ? (u <= T - 1) : (u >= 2);
             float* base = k < 3 ? (l1 ? p.dgi1 : p.dgi0) : (l1 ? p.dghn1 : p.dghn0);
             const size_t off = k < 3 ? (size_t)(row0 + t) * (3 * BH) + k * BH : (size_t)(row0 + t) * BH;
             if (on) *reinterpret_cast<f32x4*>(base + off + c * 32 + sqd * 4) = ld4(obuf + ((u & 1) * N_OBUF + a) * OARR + su * OROW + sqd * 4);
         }
-    };
-    // inter-layer dropout on the gradient entering layer 0: same Philox draw as the forward's mask of y0 at (b, t, col)
-    auto draw = [&](int tv, int t) {
-        const int lt = tv & 255, lp = (lt >> 1) & 63, half = lt & 1;
-        const int col = c * 32 + (lt >> 7) * 16 + (lp >> 4) * 4 + 2 * half;
-        const size_t o = ((size_t)(b0t + (lp & 15)) * T + t) * BH + col;
-        const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
-        return f2(half ? m[2] : m[0], half ? m[3] : m[1]);
     };
     {   // initial recurrent gradient (dh_n) and the pooling gradient of the top layer
         const int lt = tid & 255, lp = (lt >> 1) & 63, half = lt & 1;
@@ -152,152 +167,162 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             if (dhn) { const float2 v = ld2(dhn + (size_t)b * BH + col); st[0][0] = v.x; st[0][1] = v.y; }
             if (grp == 0 && p.dpooled) { const float2 v = ld2(p.dpooled + (size_t)b * BH + col); st[0][2] = v.x * p.pool_scale; st[0][3] = v.y * p.pool_scale; }
         }
-        if (grp == 2) { st[3][2] = 1.f; st[3][3] = 1.f; }
     }
-    if (grp == 1) { stage(tid, 0); put_ibuf(tid, 0); stage(tid, 1); }
+    if (grp == 1) { stage(tid, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
 
-    for (int u = 0; u <= T; ++u) {
+    for (int v = 0; v <= T + 1; ++v) {
         int tv = tid;
         asm volatile("" : "+v"(tv));                  // launder: indices derived from tv are recomputed per step, not hoisted
         const int lane = tv & 63;
         const int lt = tv & 255, jl = lt >> 7, lp = (lt >> 1) & 63, half = lt & 1;
         const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;       // utterance row, unit pair (ul, ul+1) of the member's 32
-        const bool act = grp == 2 ? (u >= 1) : (u <= T - 1);
-        // ---- group 1's HBM streams go HERE, while nothing latency-critical uses the CU's memory pipeline (the others are in
-        // their gate math, then everybody in the MFMAs): the next step's inputs first, then the previous step's write-out (from
-        // the other obuf parity).  36 KB per step and CU is ~3400 cycles of the CU's ~10.7 B/clk share of HBM: issued beside
-        // the payload stores / flag polls / gather loads instead, these streams queue in front of them.  (Measured: without the
-        // streams this launch takes 1.07 ms, with the loads alone 1.47, the stores alone 1.31, both 1.9-2.1 -- wherever they are
-        // issued -- against 1.64 + 0.25 ms for the two per-layer sweeps plus the dX GEMM this launch removes: not adopted, opt-in.)
-        if (grp == 1) {
-            put_ibuf(tv, u + 1);                          // loads issued at the top of the PREVIOUS step: a whole step to land
-            stage(tv, u + 2);
-            if (u >= 1) flush(tv, u - 1);
-        }
-        // ---- gate gradients (groups 0 and 2; identical code, role-dependent LDS bases)
-        if (grp != 1 && act) {
-            const float* ib = ibuf + ((u & 1) * N_IBUF + (grp == 0 ? 0 : (HASDY ? 6 : 5))) * OARR + j * OROW + ul;
-            const float2 r = ld2(ib), z = ld2(ib + OARR), n = ld2(ib + 2 * OARR), hn = ld2(ib + 3 * OARR), hp = ld2(ib + 4 * OARR);
+        const bool act = grp == 0 ? (v <= T - 1) : (grp == 2 ? (v >= 2) : false);      // gate-gradient role: layer 1 at t = T-1-v, layer 0 at t = T+1-v
+        const unsigned epoch = (unsigned)v + 1u;
+        // ---- gate gradients (groups 0 and 2; identical code, role-dependent LDS bases), published at once
+        if (act) {
+            const float* ib = ibuf + ((v & 1) * N_IBUF + (grp == 0 ? 0 : (HASDY ? 6 : 5))) * IARR + iswz(j, ul);
+            const float2 r = ld2(ib), z = ld2(ib + IARR), n = ld2(ib + 2 * IARR), hn = ld2(ib + 3 * IARR), hp = ld2(ib + 4 * IARR);
             float2 dyv = f2(0.f, 0.f);
             if (grp == 2) dyv = f2(st[3][0], st[3][1]);   // layer 0: masked gradient from layer 1
-            if (HASDY && grp == 0) dyv = ld2(ib + 5 * OARR);
+            if (HASDY && grp == 0) dyv = ld2(ib + 5 * IARR);
             const float2 d = f2(st[0][0] + st[0][2] + dyv.x, st[0][1] + st[0][3] + dyv.y);
             float2 dn, dz, dr, dnr;
             dn.x = d.x * (1.0f - z.x) * (1.0f - n.x * n.x); dn.y = d.y * (1.0f - z.y) * (1.0f - n.y * n.y);
             dz.x = d.x * (hp.x - n.x) * z.x * (1.0f - z.x); dz.y = d.y * (hp.y - n.y) * z.y * (1.0f - z.y);
             dr.x = dn.x * hn.x * r.x * (1.0f - r.x); dr.y = dn.y * hn.y * r.y * (1.0f - r.y);
             dnr.x = dn.x * r.x; dnr.y = dn.y * r.y;
-            // d*z (the part of dh_{t-1} that bypasses the gates) waits for the gathered sum: layer 1 parks it in st[3].xy (unused
+            // d*z (the part of dh_{t-1} that bypasses the gates) waits for the K-quarter sum: layer 1 parks it in st[3].xy (unused
             // there), layer 0 in st[0].zw (its pooling-gradient slot, which must read zero again at the next gate phase)
             if (grp == 0) { st[3][0] = d.x * z.x; st[3][1] = d.y * z.y; } else { st[0][2] = d.x * z.x; st[0][3] = d.y * z.y; }
-            unsigned short* gh = (grp == 0 ? dg1 : dg0) + j * LDGB + ul;
-            unsigned h0, l0, h1, l1, h2, l2, h3, l3;
-            split_pair(dr.x, dr.y, h0, l0); split_pair(dz.x, dz.y, h1, l1); split_pair(dnr.x, dnr.y, h2, l2); split_pair(dn.x, dn.y, h3, l3);
-            *reinterpret_cast<unsigned*>(gh) = h0; *reinterpret_cast<unsigned*>(gh + GPLANE) = l0;
-            *reinterpret_cast<unsigned*>(gh + 32) = h1; *reinterpret_cast<unsigned*>(gh + GPLANE + 32) = l1;
-            *reinterpret_cast<unsigned*>(gh + 64) = h2; *reinterpret_cast<unsigned*>(gh + GPLANE + 64) = l2;
-            if (grp == 0) { *reinterpret_cast<unsigned*>(gh + 96) = h3; *reinterpret_cast<unsigned*>(gh + GPLANE + 96) = l3; }
-            float* ob = obuf + ((u & 1) * N_OBUF + (grp == 0 ? 0 : 4)) * OARR + j * OROW + ul;
-            st2(ob, dr); st2(ob + OARR, dz); st2(ob + 2 * OARR, dn); st2(ob + 3 * OARR, dnr);
-            st[1][0] += dr.x; st[1][1] += dr.y; st[1][2] += dz.x; st[1][3] += dz.y;
-            st[2][0] += dn.x; st[2][1] += dn.y; st[2][2] += dnr.x; st[2][3] += dnr.y;
-        }
-        bar_lds();                                        // #1: gate-gradient planes and the write-out arrays are in LDS
-        if (u == T) break;                                // layer 0's last step (t = 0) has no predecessor to publish for
-        // ---- partial products on the matrix cores, published in fragment order
-        const unsigned pbase = (unsigned)(u & 1) * pstride + tile_base;
-        if (grp == 2 ? (u >= 1) : true) {
-            const unsigned short* gsrc = (grp == 2 ? dg0 : dg1) + (lane & 15) * LDGB + (lane >> 4) * 8;
-            const int k2 = grp == 1 ? 96 : 64;            // third k-step: dn for the input path, dn*r for the recurrent one
-            f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+            // layer 1 always publishes (the gradient entering layer 0 needs every step's gates); layer 0 not at its last step (t = 0: v = T+1)
+            if (grp == 0 || v <= T) {
+                unsigned wd[8];
+                split_pair(dr.x, dr.y, wd[0], wd[1]); split_pair(dz.x, dz.y, wd[2], wd[3]); split_pair(dnr.x, dnr.y, wd[4], wd[5]);
+                split_pair(dn.x, dn.y, wd[6], wd[7]);
+                // this pair's word in each of the member's 1 KB blocks (B-fragment order: lane (k-group ul / 8, utterance j), word (ul % 8) / 2)
+                const unsigned pw = (unsigned)(half + 2 * ((lp >> 4) & 1) + 4 * j + 64 * (lp >> 5) + 128 * jl) * 4u;
+                const unsigned po = grp == 0 ? (unsigned)(v % 3) * par1 + (unsigned)(bt * BNC + c) * L1_MEMBER + pw
+                                             : p.l0_off + (unsigned)(v & 1) * par0 + (unsigned)(bt * BNC + c) * L0_MEMBER + pw;
+                if (fast) {
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                const int ko = ks == 2 ? k2 : ks * 32;
-                const bf16x8 gh = *reinterpret_cast<const bf16x8*>(gsrc + ko);
-                const bf16x8 gl = *reinterpret_cast<const bf16x8*>(gsrc + GPLANE + ko);
+                    for (int e = 0; e < 6; ++e) __builtin_amdgcn_raw_buffer_store_b32(wd[e], rsrc, po + e * 1024, 0, 0);
+                    if (grp == 0) { __builtin_amdgcn_raw_buffer_store_b32(wd[6], rsrc, po + 6 * 1024, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(wd[7], rsrc, po + 7 * 1024, 0, 0); }
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[i][ks][0]), wl = __builtin_bit_cast(bf16x8, wq[i][ks][1]);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh, acc[i], 0, 0, 0);
+                    for (int e = 0; e < 6; ++e) __builtin_amdgcn_raw_buffer_store_b32(wd[e], rsrc, po + e * 1024, 0, 16);
+                    if (grp == 0) { __builtin_amdgcn_raw_buffer_store_b32(wd[6], rsrc, po + 6 * 1024, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(wd[7], rsrc, po + 7 * 1024, 0, 16); }
                 }
             }
-            auto publish = [&](const f32x4& a, unsigned fo) {
-                u32x4 v;
-                v.x = __float_as_uint(a[0]); v.y = __float_as_uint(a[1]); v.z = __float_as_uint(a[2]); v.w = __float_as_uint(a[3]);
-                if (fast) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, fo * 4, 0, 0 /* plain: stays in this XCD's L2 */);
-                else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, fo * 4, 0, 16 /* sc1: write-through */);
-            };
-            if (grp == 1) {
-                // group 1 never stores to the payload itself: a publishing wave must wait for its stores' acknowledgement
-                // (vmcnt, which counts its HBM streams too).  Its block goes through LDS to the waves of groups 0 / 2.
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(pblk + ((gw * 4 + i) * 64 + lane) * 4) = acc[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) publish(acc[i], pbase + (unsigned)grp * B_BLOCK + (unsigned)((c * 16 + gw * 4 + i) * 64 + lane) * 4);
+            float* ob = obuf + ((v & 1) * N_OBUF + (grp == 0 ? 0 : 4)) * OARR + j * OROW + ul;
+            st2(ob, dr); st2(ob + OARR, dz); st2(ob + 2 * OARR, dn); st2(ob + 3 * OARR, dnr);
+            {   // bias-gradient accumulators (this thread's own four float2 slots)
+                float* da = dbl + (grp == 0 ? 0 : 4) * OARR + j * OROW + ul;
+                const float2 a0 = ld2(da), a1 = ld2(da + OARR), a2 = ld2(da + 2 * OARR), a3 = ld2(da + 3 * OARR);
+                st2(da, f2(a0.x + dr.x, a0.y + dr.y)); st2(da + OARR, f2(a1.x + dz.x, a1.y + dz.y));
+                st2(da + 2 * OARR, f2(a2.x + dn.x, a2.y + dn.y)); st2(da + 3 * OARR, f2(a3.x + dnr.x, a3.y + dnr.y));
             }
         }
-        bar_lds();                                        // #1b: group 1's block is in LDS
+        if (v == T + 1) { bar_lds(); break; }             // layer 0's last step (t = 0): nothing left to exchange
         if (grp != 1) {
-            // group 0 forwards tiles 0, 1 of each of group 1's waves, group 2 tiles 2, 3
-            const int i0 = grp == 0 ? 0 : 2;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const f32x4 a = ld4(pblk + ((gw * 4 + i0 + i) * 64 + lane) * 4);
-                u32x4 v;
-                v.x = __float_as_uint(a[0]); v.y = __float_as_uint(a[1]); v.z = __float_as_uint(a[2]); v.w = __float_as_uint(a[3]);
-                const unsigned fo = pbase + (unsigned)B_BLOCK + (unsigned)((c * 16 + gw * 4 + i0 + i) * 64 + lane) * 4;
-                if (fast) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, fo * 4, 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, fo * 4, 0, 16);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // payload stores acknowledged
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's words are acknowledged
+            if (act && lane == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         }
-        bar_lds();                                        // #2
-        if (tid == 0) { if (fast) st_local(myflag, (unsigned)u + 1u); else st_agent(myflag, (unsigned)u + 1u); }
+        // ---- the group's product: K quarter gw (source members 2gw, 2gw+1) x own 32 columns
+        //   group 0: layer 1, step v (needed while a layer-1 step follows) ; group 1: layer 1, step v-1 ; group 2: layer 0, step v
+        const bool mact = grp == 0 ? (v <= T - 2) : (grp == 1 ? (v >= 1 && v <= T) : (v >= 2 && v <= T));
+        if (mact) {
+            // (group 1's data is one step old and normally visible already -- its member's group 0 gathered the same step before the last
+            // barrier -- but group 0 does not gather at layer 1's LAST step: group 1 always checks the flags itself, one round trip off the
+            // critical path)
+            if (!wait_flags((grp == 2 ? tflags0 : tflags1) + 8 * gw, 8, grp == 1 ? epoch - 1u : epoch, p.status, 7)) return;
+            const unsigned mb = grp == 2 ? L0_MEMBER : L1_MEMBER;
+            const unsigned src0 = (grp == 2 ? p.l0_off + (unsigned)(v & 1) * par0 : (unsigned)((grp == 0 ? v : v - 1) % 3) * par1)
+                                  + (unsigned)(bt * BNC + 2 * gw) * mb + (unsigned)lane * 16u;
+            const unsigned g2 = grp == 1 ? 3u * 2048u : 2u * 2048u;      // third k-step of a member: dn for the input path, dn*r for the recurrent ones
+            f32x4 acc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {          // one source member per round: six 1 KB requests, then its 18 MFMAs
+                u32x4 gfr[3][2];
+                const unsigned so = src0 + (unsigned)rd * mb;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        gfr[g][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + (g == 2 ? g2 : (unsigned)g * 2048u) + (unsigned)pl * 1024u, 0, 16 /* sc1: served by L2 */);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const bf16x8 gh = __builtin_bit_cast(bf16x8, gfr[g][0]), gl = __builtin_bit_cast(bf16x8, gfr[g][1]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[i][rd * 3 + g][0]), wl = __builtin_bit_cast(bf16x8, wq[i][rd * 3 + g][1]);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gl, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, gh, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, gh, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            float* rw = red + ((((v & 1) * 3 + grp) * 4 + gw) * 2) * 256 + lane * 4;
+            *reinterpret_cast<f32x4*>(rw) = acc[0]; *reinterpret_cast<f32x4*>(rw + 256) = acc[1];
+        }
+        if (grp == 1) {
+            // group 1's HBM streams go out BEHIND its fragment requests and products (a wave's loads return in issue order; fragments and
+            // accumulators are dead by now: the register peak of this kernel is elsewhere) and have the rest of the step to land: next step's
+            // inputs by DMA, then the previous step's gate gradients
+            __builtin_amdgcn_sched_barrier(0);
+            stage(tv, v + 1);
+            if (v >= 1) flush(tv, v - 1);
+            if constexpr (DROP) {
+                // the dropout mask of the dy0 this step ends with (t = T - v; same Philox draw as the forward's mask of y0): ~150 VALU
+                // instructions that have no business on the gate threads' chain -- two of this group's waves draw the member's 128 blocks
+                if (shalf == 1 && v >= 1 && v <= T) {
+                    const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
+                    const size_t o = ((size_t)(b0t + su) * T + (T - v)) * BH + c * 32 + sqd * 4;
+                    *reinterpret_cast<f32x4*>(mbuf + (v & 1) * OARR + su * OROW + sqd * 4) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+                }
+            }
+        }
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA'd inputs of step v+1 are in LDS, the write-out is acknowledged: nothing of this group is in flight at the barrier
+        bar_lds();                                        // the step's ONE barrier: partials in red, next step's inputs in ibuf, this step's write-out read
+        // ---- K-quarter sums (fixed order: deterministic)
         if (grp != 1) {
-            // next step's dropout mask for layer 0, in the shadow of the wait
-            if (DROP && grp == 2 && u + 1 <= T) { const float2 m = draw(tv, T - (u + 1)); st[3][2] = m.x; st[3][3] = m.y; }
-            if (!wait_flags(tflags, BNC, (unsigned)u + 1u, p.status, 7)) return;
-            // reduce-scatter: this thread's two columns of every member's partial, summed in member order
-            const float* src = p.payload + pbase + ((unsigned)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
+            const float* rr = red + (v & 1) * N_RED + (jl * 64 + (lp >> 4) * 16 + j) * 4 + 2 * half;      // own pair inside a wave's two accumulator tiles
             if (grp == 0) {                               // dh1_{t-1}
-                if (u + 1 <= T - 1) {
-                    float2 part[8];
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) part[m] = ld2_agent(src + (size_t)m * (16 * 256));
+                if (v <= T - 2) {
                     float2 s = f2(0.f, 0.f);
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) { s.x += part[m].x; s.y += part[m].y; }
+                    for (int q4 = 0; q4 < 4; ++q4) { const float2 x = ld2(rr + q4 * 512); s.x += x.x; s.y += x.y; }
                     st[0][0] = st[3][0] + s.x; st[0][1] = st[3][1] + s.y;
                 }
-            } else {                                      // layer 0 of the next step: dy0 (from group 1's block) and dh0
-                // two rounds of eight loads (registers): first the recurrent partials -- the longer dependency chain --
-                float2 part[8];
-                if (u >= 1) {
+            } else {
+                if (v >= 2 && v <= T) {                   // dh0_{t-1}
+                    float2 s = f2(0.f, 0.f);
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) part[m] = ld2_agent(src + 2 * B_BLOCK + (size_t)m * (16 * 256));
-                    float2 q = f2(0.f, 0.f);
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) { q.x += part[m].x; q.y += part[m].y; }
-                    st[0][0] = st[0][2] + q.x; st[0][1] = st[0][3] + q.y; st[0][2] = 0.f; st[0][3] = 0.f;
+                    for (int q4 = 0; q4 < 4; ++q4) { const float2 x = ld2(rr + 2 * 2048 + q4 * 512); s.x += x.x; s.y += x.y; }
+                    st[0][0] = st[0][2] + s.x; st[0][1] = st[0][3] + s.y; st[0][2] = 0.f; st[0][3] = 0.f;
                 }
+                if (v >= 1 && v <= T) {                   // the gradient entering layer 0 at t = T - v (group 1's product), masked
+                    float2 s = f2(0.f, 0.f);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) part[m] = ld2_agent(src + B_BLOCK + (size_t)m * (16 * 256));
-                float2 s = f2(0.f, 0.f);
-#pragma unroll
-                for (int m = 0; m < 8; ++m) { s.x += part[m].x; s.y += part[m].y; }
-                st[3][0] = s.x * st[3][2]; st[3][1] = s.y * st[3][3];
+                    for (int q4 = 0; q4 < 4; ++q4) { const float2 x = ld2(rr + 2048 + q4 * 512); s.x += x.x; s.y += x.y; }
+                    if constexpr (DROP) { const float2 m = ld2(mbuf + (v & 1) * OARR + j * OROW + ul); s.x *= m.x; s.y *= m.y; }
+                    st[3][0] = s.x; st[3][1] = s.y;
+                }
             }
         }
-        bar_lds();                                        // #3: next step's inputs are in LDS, this step's write-out left it
     }
-    if (grp == 1) flush(tid, T);                          // layer 0's last step
+    if (grp == 1) { flush(tid, T); flush(tid, T + 1); }   // layer 0's last two steps (t = 1, 0) are still in LDS
     if (grp != 1) {
         // bias-gradient partials [batch tile][4][H]: sum over the 16 utterance rows = lanes that differ in bits 1..4
-        float2 a[4] = {f2(st[1][0], st[1][1]), f2(st[1][2], st[1][3]), f2(st[2][0], st[2][1]), f2(st[2][2], st[2][3])};
+        float2 a[4];
+        {
+            const int lt0 = tid & 255, lp0 = (lt0 >> 1) & 63, j0 = lp0 & 15, ul0 = (lt0 >> 7) * 16 + (lp0 >> 4) * 4 + 2 * (lt0 & 1);
+            const float* da = dbl + (grp == 0 ? 0 : 4) * OARR + j0 * OROW + ul0;
+            const bool rowok = b0t + j0 < p.B;            // (rows past the batch carried a copy of the last utterance: not part of the sums)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = rowok ? ld2(da + k * OARR) : f2(0.f, 0.f);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -316,7 +341,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
 size_t dep_fused2_bwd_xbuf_bytes(int B) {
     const int CH = dep_cluster_chunk(BNC, 1, 256);
     const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
-    return PAYLOAD_OFF + (size_t)2 * nbtp * 3 * B_BLOCK * sizeof(float) + 4096;
+    return PAYLOAD_OFF + (size_t)nbtp * BNC * (3 * L1_MEMBER + 2 * L0_MEMBER) + 4096;
 }
 
 int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
@@ -331,10 +356,23 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
     p.drop_p = a.drop_p; p.drop_scale = drop ? 1.0f / (1.0f - a.drop_p) : 1.0f; p.seed = a.seed; p.site = a.site;
     p.dgi1 = a.dgi1; p.dghn1 = a.dghn1; p.dgi0 = a.dgi0; p.dghn0 = a.dghn0; p.dbpart1 = a.dbpart1; p.dbpart0 = a.dbpart0;
     DEP_CHECK_ARG(a.dbpart_rows >= nbt && a.wh1 && a.wi1 && a.wh0 && a.dgi1 && a.dgi0 && a.dghn1 && a.dghn0);
-    const size_t pay = (size_t)2 * nbtp_max * 3 * B_BLOCK * sizeof(float);
-    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * BNC <= 256 && pay < (1ull << 32));
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
-    p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
+    static_assert(DEP_HDR_SLOTS >= 2, "the fused backward keeps layer 0's flags in header slot 1");
+    p.status = (unsigned*)xbuf; p.flags1 = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.flags0 = (unsigned*)(hdr_base(xbuf, 1) + FLAG_OFF);
+    p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
+    p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.nofast = nofast_env();
+    {   // the input streams' buffer resources: per layer one base below its arrays, 32-bit offsets
+        const size_t arr = (size_t)a.B * a.T * BH * sizeof(float);
+        auto span = [&](const float* y, const float* sv, const char*& base, unsigned& bytes, unsigned& oy, unsigned& osv) {
+            const char* cy = (const char*)y; const char* cs = (const char*)sv;
+            base = cy < cs ? cy : cs;
+            const char* e1 = cy + arr; const char* e2 = cs + (size_t)3 * a.svstride * sizeof(float) + arr;
+            const size_t n = (size_t)((e1 > e2 ? e1 : e2) - base);
+            oy = (unsigned)(cy - base); osv = (unsigned)(cs - base); bytes = (unsigned)n;
+            return n < 0xfffffff0ull;
+        };
+        DEP_CHECK_ARG(span(a.y1, a.sv1, p.sb1, p.sbytes1, p.o_y1, p.o_sv1) && span(a.y0, a.sv0, p.sb0, p.sbytes0, p.o_y0, p.o_sv0));
+        DEP_CHECK_ARG(arr < 0xfffffff0ull);           // (an external dy is addressed from its own base)
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B_LDS_BYTES);
@@ -347,8 +385,12 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
-        // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
+        const size_t pay = (size_t)p.nbtp * BNC * (3 * L1_MEMBER + 2 * L0_MEMBER);
+        DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * BNC <= 256 && pay < (1ull << 32));
+        p.payload_bytes = (unsigned)pay; p.l0_off = (unsigned)((size_t)3 * p.nbtp * BNC * L1_MEMBER);
+        // flags / hello words only (both layers' slots): the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
+        { const int rc_h = hdr_prepare(xbuf, 1, false, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(BNC * p.nbtp), blk(BTHREADS);
         if (drop) { if (a.dy) hipLaunchKernelGGL((gru2_bwd_fused<true, true>), grid, blk, B_LDS_BYTES, a.stream, p);
                     else hipLaunchKernelGGL((gru2_bwd_fused<true, false>), grid, blk, B_LDS_BYTES, a.stream, p); }
