@@ -183,7 +183,7 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     lo.wih_img = w; if (lo.fused2) w += al(G * H * H);
     lo.gi2 = lo.dghn2 = lo.dbpart2 = 0;
     if (lo.fused2 && d->training) {
-        lo.gi2 = w; w += al(lo.BT * G * H);
+        lo.gi2 = w; w += al(lo.BT * (G + 1) * H);      // (room for the 4H-wide [dr | dz | dn | dn*r] rows, like lo.gi)
         lo.dghn2 = w; w += al(lo.BT * H);
         lo.dbpart2 = w; w += al((size_t)lo.nwg * 4 * H);
     }
@@ -194,8 +194,9 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
         static int sv_env = -1, fb_env = -1;
         if (sv_env < 0) { const char* e = getenv("DEP_SV16"); sv_env = (e && e[0] == '0') ? 0 : 1; }
         if (fb_env < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fb_env = (e && e[0] == '1') ? 1 : 0; }
+        (void)fb_env;                                  // (round 5: the all-gather fused backward reads the 16-bit gates too)
         lo.sv16 = sv_env && d->training && lo.cluster &&
-                  (d->cell == DEP_CELL_GRU ? (!fb_env && !lo.cluster16_bwd && (lo.fused2 || !lo.cluster16)) : dep_cluster_lstm_sv16_ok());
+                  (d->cell == DEP_CELL_GRU ? (!lo.cluster16_bwd && (lo.fused2 || !lo.cluster16)) : dep_cluster_lstm_sv16_ok());
         // bf16-STORAGE mode (dep_set_gemm_mode(3); a labelled throughput mode, never the parity path): only where every kernel of the
         // stack has the variant -- the fused 2-layer GRU forward and the burst backward with the 4H-wide gate-gradient rows.  Other
         // stacks run mode 3 exactly like mode 2 (single bf16 products, fp32 storage).
@@ -532,16 +533,33 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     const int BTr = (int)lo.BT;
     void* gws = W + lo.gemm; const size_t gwsb = lo.gemm_bytes;
     int rc;
-    // The fused two-layer backward (rnn_fused2_bwd.hip) is parity-tested but NOT the default: its 36 KB of HBM streams per step
-    // and CU (saved gates in, gate gradients out, both layers at once) queue in front of the exchange traffic and it measures
-    // 1.9-2.2 ms against 1.64 + 0.25 ms for the two per-layer sweeps + the dX GEMM it removes.  DEP_FUSED2_BWD=1.
-    static int fused_bwd_off = -1;
-    if (fused_bwd_off < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fused_bwd_off = (e && e[0] == '1') ? 0 : 1; }
-    if (lo.fused2 && !fused_bwd_off && sweep_split_mode()) {
-        // both layers in one launch: layer 0 one step behind layer 1; layer 1's dX (the gradient into layer 0) stays on chip
+    // The fused two-layer backward (rnn_fused2_bwd.hip; round 5: all-gather form): both layers' BPTT in ONE launch, layer 1's dX -- the gradient
+    // entering layer 0 -- formed in-kernel.  It writes the same gate-gradient arrays as the per-layer sweeps (4H-wide rows, PK image when the
+    // contractions take it), so everything behind the sweeps -- bias finish, dW GEMMs (paired), layer 0's dX, the gradient ranges -- is the
+    // per-layer loop below with the sweep launches and layer 1's dX GEMM left out.  DEP_FUSED2_BWD=1 / 0.
+    static int fused_bwd_on = -1;
+    if (fused_bwd_on < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fused_bwd_on = e ? ((e[0] == '1') ? 1 : 0) : DEP_FUSED2_BWD_DEFAULT; }
+    const bool fused = lo.fused2 && fused_bwd_on && sweep_split_mode() && !lo.bf16st && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && L == 2 && D == 1;
+    static int pk_env = -1;
+    if (pk_env < 0) { const char* e = getenv("DEP_DGI_PK"); pk_env = (e && e[0] == '0') ? 0 : 1; }
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    // may layer l's gate gradients be the PK image?  Only when all contractions that read them really run the three-term kernel on its vector path.
+    auto pk_gru_ok = [&](int l, bool has_dxl, const float* dxl_probe) {
+        const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
+        const int Kl = l == 0 ? d->F : D * H;
+        return pk_env && lo.dg4 && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && sweep_split_mode() && (dep_get_gemm_mode() == 1 || lo.bf16st) &&
+               (fused || dep_cluster_bwd_pk_ok(H, T)) && (T % 2 == 0) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(weights[(size_t)l * 4]) &&
+               al16(dweights[(size_t)l * 4]) && al16(dweights[(size_t)l * 4 + 1]) &&
+               dep_gemm_uses_bf16x3(G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(3 * H, H, BTr, T) &&
+               (!has_dxl || (dep_gemm_uses_bf16x3(BTr, Kl, G * H, 0) && al16(dxl_probe)));
+    };
+    bool fused_pk = false;
+    if (fused) {
         const float* const* w0 = weights; const float* const* w1 = weights + 4;
         float* const* g0 = dweights; float* const* g1 = dweights + 4;
         for (int k = 0; k < 4; ++k) DEP_CHECK_ARG(w0[k] && w1[k] && g0[k] && g1[k]);
+        const bool sv16 = lo.sv16 && sweep_split_mode();
+        fused_pk = sv16 && pk_gru_ok(1, false, nullptr) && pk_gru_ok(0, dx != nullptr, dx);      // one kernel writes both layers: both or neither
         rc = dep_pack_cluster_bwd_split(w1[0], W + lo.wih_img, H, s); if (rc) return rc;
         dep_fused2_bwd_args f{};
         f.B = B; f.T = T;
@@ -551,41 +569,20 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         f.dy = dy; f.dpooled = dpooled; f.pool_scale = d->pool == DEP_POOL_MEAN ? 1.0f / (float)T : 1.0f;
         f.dhn1 = dh_n ? dh_n + (size_t)B * H : nullptr; f.dhn0 = dh_n;
         f.drop_p = lo.drop ? d->dropout_p : 0.f; f.seed = d->seed; f.site = DEP_SITE_RNN0;
-        f.dgi1 = W + lo.gi; f.dghn1 = W + lo.dghn; f.dgi0 = W + lo.gi2; f.dghn0 = W + lo.dghn2;
+        f.dgi1 = W + lo.gi; f.dgi0 = W + lo.gi2;
+        f.dghn1 = lo.dg4 ? f.dgi1 + 3 * H : W + lo.dghn; f.dghn0 = lo.dg4 ? f.dgi0 + 3 * H : W + lo.dghn2;
+        f.lddg = lo.dg4 ? 4 * H : 3 * H; f.lddghn = lo.dg4 ? 4 * H : H;
         f.dbpart1 = W + lo.dbpart; f.dbpart0 = W + lo.dbpart2; f.dbpart_rows = lo.nwg; f.stream = s;
+        f.sv16 = sv16 ? 1 : 0; f.dg_pk = fused_pk ? 1 : 0;
         rc = dep_launch_fused2_bwd(f, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
-        for (int l = 1; l >= 0; --l) {
-            const float* const* wl = l ? w1 : w0; float* const* gl = l ? g1 : g0;
-            const float* dg = l ? f.dgi1 : f.dgi0; const float* dgh = l ? f.dghn1 : f.dghn0;
-            const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[0] : R + lo.y[0]);
-            const int Kl = l == 0 ? d->F : H;
-            dep_sweep_bwd_args a{};
-            a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = 1; a.impl = d->impl; a.dbpart = l ? f.dbpart1 : f.dbpart0; a.dbpart_rows = lo.nwg; a.stream = s;
-            float* dbi[2] = {gl[2], nullptr}; float* dbh[2] = {gl[3], nullptr};
-            rc = dep_finish_db(a, dbi, dbh); if (rc) return rc;
-            if (l == 0 && dx) {
-                rc = dep_gemm_internal(0, 0, BTr, Kl, G * H, dg, G * H, wl[0], Kl, dx, Kl, nullptr, 0.f, 0, 0, nullptr, 0, s);
-                if (rc) return rc;
-            }
-            rc = dep_gemm_internal(1, 0, G * H, Kl, BTr, dg, G * H, in, Kl, gl[0], Kl, nullptr, 0.f, 0, 0, gws, gwsb, s); if (rc) return rc;
-            const float* yl = R + lo.y[l];
-            rc = dep_gemm_internal(1, 0, 2 * H, H, BTr, dg, G * H, yl, H, gl[1], H, nullptr, 0.f, T, -1, gws, gwsb, s); if (rc) return rc;
-            rc = dep_gemm_internal(1, 0, H, H, BTr, dgh, H, yl, H, gl[1] + (size_t)2 * H * H, H, nullptr, 0.f, T, -1, gws, gwsb, s);
-            if (rc) return rc;
-            if (gs && gs->comm && gs->range_ptr[l] && gs->range_count[l] > 0) {
-                rc = dep_comm_enqueue_after((dep_comm*)gs->comm, gs->range_ptr[l], gs->range_count[l], s, (hipStream_t)gs->comm_stream);
-                if (rc) return rc;
-            }
-        }
-        return DEP_OK;
     }
     float* pending_ptr = nullptr; long pending_n = 0;      // data parallel: a finished layer's gradient range waiting for the next sweep to be enqueued
-    if (lo.cluster && !lo.cluster16_bwd) { rc = dep_cluster_reset_flags(W + lo.xbuf, s); if (rc) return rc; }      // every layer's header slot in one memset (the status words stay)
+    if (lo.cluster && !lo.cluster16_bwd && !fused) { rc = dep_cluster_reset_flags(W + lo.xbuf, s); if (rc) return rc; }      // every layer's header slot in one memset (the status words stay)
     for (int l = L - 1; l >= 0; --l) {
         const bool top = l == L - 1;
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
         const int Kl = l == 0 ? d->F : D * H;
-        float* dgi = W + lo.gi;
+        float* dgi = (fused && l == 0) ? W + lo.gi2 : W + lo.gi;       // (the fused launch left both layers' gate gradients behind)
         dep_sweep_bwd_args a{};
         a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.impl = d->impl;
         // must match the image dep_rnn_forward packed: the precision mode may not change between a forward and its backward
@@ -603,22 +600,16 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         a.dh_n = dh_n ? dh_n + (size_t)l * D * B * H : nullptr;
         a.sv0 = R + lo.sv[l][0]; a.sv1 = R + lo.sv[l][1]; a.sv2 = R + lo.sv[l][2]; a.sv3 = R + lo.sv[l][3];
         const int ldg = lo.dg4 ? 4 * H : D * G * H;                  // row stride of the gate-gradient array
-        float* dghn = lo.dg4 ? dgi + 3 * H : W + lo.dghn;
+        float* dghn = lo.dg4 ? dgi + 3 * H : ((fused && l == 0) ? W + lo.dghn2 : W + lo.dghn);
         a.dgi = dgi; a.dghn = dghn; a.lddg = lo.dg4 ? ldg : 0; a.lddghn = lo.dg4 ? ldg : 0;
-        a.dbpart = W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
+        a.dbpart = (fused && l == 0) ? W + lo.dbpart2 : W + lo.dbpart; a.dbpart_rows = D * lo.nwg; a.stream = s;
         a.hdr_slot = l < DEP_HDR_SLOTS ? l : 0; a.hdr_clean = l < DEP_HDR_SLOTS;
         // Round 4: the sweep writes the gate gradients as the PK image (rows (t even, t + 1) = (hi, lo) bf16 pairs of both steps,
         // gemm_bf16x3.hip) -- the three contractions that read them (dX, dW_ih, dW_hh) then stage them without converting; same
         // bytes, same bits.  Only when all three really run the three-term kernel on its vector path.
-        static int pk_env = -1;
-        if (pk_env < 0) { const char* e = getenv("DEP_DGI_PK"); pk_env = (e && e[0] == '0') ? 0 : 1; }
-        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        float* dxl_probe = l == 0 ? dx : W + lo.dx[l & 1];
-        const bool pk_gru = pk_env && lo.dg4 && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && a.split && (dep_get_gemm_mode() == 1 || lo.bf16st) &&
-                        dep_cluster_bwd_pk_ok(H, T) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(weights[(size_t)l * 4]) &&
-                        al16(dweights[(size_t)l * 4]) && al16(dweights[(size_t)l * 4 + 1]) &&
-                        dep_gemm_uses_bf16x3(G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(3 * H, H, BTr, T) &&
-                        (!dxl_probe || (dep_gemm_uses_bf16x3(BTr, Kl, G * H, 0) && al16(dxl_probe)));
+        a.split = (lo.cluster && !lo.cluster16_bwd && sweep_split_mode()) ? 1 : 0;
+        float* dxl_probe = l == 0 ? dx : (fused ? nullptr : W + lo.dx[l & 1]);
+        const bool pk_gru = fused ? fused_pk : (a.split && pk_gru_ok(l, dxl_probe != nullptr, dxl_probe));
         // the BiLSTM cluster sweep (both directions in one launch, direction-stacked contractions): same image, same conditions
         bool pk_lstm = pk_env && lo.cluster && d->cell == DEP_CELL_LSTM && D == 2 && lo.wstack[l] != 0 && a.split && dep_get_gemm_mode() == 1 &&
                        dep_cluster_lstm_bwd_pk_ok(T) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(W + lo.dwstack) &&
@@ -635,10 +626,12 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         const int fmt_a = lo.bf16st ? 2 : 1;                       // FMT_PKH / FMT_PK (gemm_bf16x3.hip)
         a.sv16 = (lo.sv16 && sweep_split_mode() && lo.cluster && (d->cell == DEP_CELL_LSTM || !lo.cluster16_bwd)) ? 1 : 0;
         struct FmtGuard { bool on; ~FmtGuard() { if (on) dep_gemm_set_operand_formats(0, 0); } } fmt_guard{pk};
-        rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
-           : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
-           : lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
-        if (rc) return rc;
+        if (!fused) {
+            rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
+               : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
+               : lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
+            if (rc) return rc;
+        }
         if (pending_ptr) {
             // the layer above's gradient range: the event recorded here completes with this sweep, the all-reduce then runs
             // beside this layer's GEMMs.  A cluster sweep needs every one of its workgroups resident (one per CU, most of a CU's
@@ -657,7 +650,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         rc = dep_finish_db(a, dbi, dbh);
         if (rc) return rc;
         if (pk) dep_gemm_set_operand_formats(fmt_a, 0);           // A = the PK gate gradients in dX, dW_ih and dW_hh below (reset by fmt_guard)
-        float* dxl = l == 0 ? dx : W + lo.dx[l & 1];
+        float* dxl = l == 0 ? dx : (fused ? nullptr : W + lo.dx[l & 1]);      // (fused: the gradient entering layer 0 never left the chip)
         // dX (B*T, Kl) (+)= dG * W_ih first: it is the only product the next layer's sweep waits for
         const bool stacked = D == 2 && lo.wstack[l] != 0;
         if (dxl && stacked) {
@@ -729,7 +722,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         // so that it travels over xGMI beside that layer's weight-gradient GEMMs and never beside a sweep.  The bottom layer's
         // range has nothing left to hide behind and goes out at once.
         if (gs && gs->comm && gs->range_ptr[l] && gs->range_count[l] > 0) {
-            if (l > 0 && !comm_beside_sweeps()) { pending_ptr = gs->range_ptr[l]; pending_n = gs->range_count[l]; }
+            if (l > 0 && !comm_beside_sweeps() && !fused) { pending_ptr = gs->range_ptr[l]; pending_n = gs->range_count[l]; }
             else {
                 rc = dep_comm_enqueue_after((dep_comm*)gs->comm, gs->range_ptr[l], gs->range_count[l], s, (hipStream_t)gs->comm_stream);
                 if (rc) return rc;

@@ -171,6 +171,7 @@ struct dep_sweep_bwd_args {
 bool dep_cluster_bwd_pk_ok(int H, int T);
 #define DEP_BWD_AG_DEFAULT 1          /* the GRU-256 backward sweep's exchange: 0 = reduce-scatter of fp32 partials, 1 = all-gather of gate gradients (DEP_BWD_AG overrides) */
 bool dep_cluster_bwd_ag_on();
+#define DEP_FUSED2_BWD_DEFAULT 0      /* both GRU layers' BPTT as one all-gather launch (rnn_fused2_bwd.hip); DEP_FUSED2_BWD overrides */
 bool dep_cluster_lstm_bwd_pk_ok(int T);
 bool dep_cluster_lstm_sv16_ok();
 int dep_launch_sweep_bwd(const dep_sweep_bwd_args& a);
@@ -225,6 +226,9 @@ struct dep_fused2_bwd_args {
     const float* dy; const float* dpooled; float pool_scale; const float* dhn1; const float* dhn0;
     float drop_p; uint64_t seed; uint32_t site;
     float* dgi1; float* dghn1; float* dgi0; float* dghn0; float* dbpart1; float* dbpart0; int dbpart_rows;
+    int lddg, lddghn;        // row strides of dgi / dghn: 3H / H, or 4H / 4H with dghn = dgi + 3H (one (B*T, 4H) array [dr | dz | dn | dn*r] per layer)
+    int sv16;                // saved gates r, z, n are 16-bit fixed point (must match the forward that wrote them)
+    int dg_pk;               // dgi1 / dgi0 are (B*T, 4H) arrays [dr | dz | dn | dn*r] written as the PK image of gemm_bf16x3.hip (needs sv16, T even); dghn unused
     hipStream_t stream;
 };
 size_t dep_fused2_bwd_xbuf_bytes(int B);

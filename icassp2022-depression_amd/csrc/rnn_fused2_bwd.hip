@@ -31,9 +31,22 @@ constexpr int OROW = 36, OARR = BT * OROW;    // fp32 [16 utterances][32 units] 
 constexpr int N_IBUF = 11, N_OBUF = 8;        // input arrays: l1 r,z,n,hn,h_{t-1},[dy] ; l0 r,z,n,hn,h_{t-1}  (10 without dy: five per wave half)
 constexpr unsigned L1_MEMBER = 8 * 1024, L0_MEMBER = 6 * 1024;      // bytes: [gate][plane][64 lanes][16 B] -- l1: dr, dz, dn*r, dn ; l0: dr, dz, dn*r
 constexpr int N_RED = 3 * 4 * 2 * 256;        // floats of one step parity: [group][K quarter = wave][own tile][64 lanes][4]
-constexpr int IARR = BT * 32;                 // an INPUT array in LDS: [16 utterances][32 units] unpadded -- written by LDS-DMA (a wave instruction fills 1 KB
+constexpr int IARR = BT * 32;                 // an fp32 INPUT array in LDS: [16 utterances][32 units] unpadded -- written by LDS-DMA (a wave instruction fills 1 KB
                                               // contiguously), 16-byte pieces XOR-swizzled by the row so that the gate threads' column reads spread over the banks
-constexpr size_t B_LDS_BYTES = (size_t)(2 * N_RED + 2 * N_IBUF * IARR + (2 * N_OBUF + 8 + 2) * OARR + 64) * sizeof(float);
+// SV16: the saved gates r, z, n arrive as 16-bit fixed point (rnn_cluster_common.h): half-size arrays, ONE DMA instruction each, decoded by the gate threads.
+// PK: the gate gradients leave as the 4H-wide PK image of gemm_bf16x3.hip ((hi, lo) bf16 pairs of two consecutive steps in two rows): a third write-out
+// slot, flushed every other step.
+constexpr int gate_arr(bool sv16) { return sv16 ? IARR / 2 : IARR; }
+constexpr int ipar_floats(bool sv16, bool hasdy) { return 2 * 3 * gate_arr(sv16) + IARR * ((hasdy ? 3 : 2) + 2); }     // floats of one step parity of ibuf
+// float offset of input array a (l1: r, z, n, hn, hp, [dy] ; l0: r, z, n, hn, hp) inside a parity
+constexpr int iarr_off(int a, bool sv16, bool hasdy) {
+    const int n1 = hasdy ? 6 : 5, l1sz = 3 * gate_arr(sv16) + IARR * (hasdy ? 3 : 2);
+    const int k = a < n1 ? a : a - n1;
+    return (a < n1 ? 0 : l1sz) + (k < 3 ? k * gate_arr(sv16) : 3 * gate_arr(sv16) + (k - 3) * IARR);
+}
+constexpr size_t fb_lds_bytes(bool sv16, bool hasdy, bool pk) {
+    return (size_t)(2 * N_RED + 2 * ipar_floats(sv16, hasdy) + ((pk ? 3 : 2) * N_OBUF + 8 + 2) * OARR + 64) * sizeof(float);
+}
 
 struct FB {
     int B, T, nbtp, b0;
@@ -42,7 +55,8 @@ struct FB {
     const float* sv1; const float* sv0; unsigned svstride;          // saved r | z | n | hn, svstride floats apart
     const float* dy; const float* dpooled; float pool_scale; const float* dhn1; const float* dhn0;
     float drop_p, drop_scale; uint64_t seed; uint32_t site;
-    float* dgi1; float* dghn1; float* dgi0; float* dghn0;           // (B*T, 3H) / (B*T, H)
+    float* dgi1; float* dghn1; float* dgi0; float* dghn0;           // (B*T, 3H) / (B*T, H); PK: dgi1 / dgi0 are the (B*T, 4H) images, dghn unused
+    int lddg, lddghn;                                               // row strides of the fp32 arrays (3H / H, or 4H / 4H)
     float* dbpart1; float* dbpart0;                                 // [batch tile][4][H] bias-gradient partials
     unsigned* status; unsigned* flags1; unsigned* flags0; unsigned* hello;      // per-wave epoch flags of the layer-1 / layer-0 publishers: [tile][member][4]
     float* payload; unsigned payload_bytes; unsigned l0_off;        // layer 1's three buffers, then (at l0_off bytes) layer 0's two
@@ -60,8 +74,10 @@ struct FB {
 //   group 1     : nothing -- its input streams go HBM -> LDS directly (buffer_load ... lds), no staging registers (the first all-gather build
 //                 staged them in 20-24 VGPRs: 31-52 VGPR spills, weight fragments reloaded from scratch inside the MFMA chain)
 // The bias-gradient accumulators (8 more registers) live in LDS (dbl): one read-modify-write of four float2 per thread and step.
-template <bool DROP, bool HASDY>
+template <bool DROP, bool HASDY, bool SV16, bool PK>
 __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
+    static_assert(!PK || SV16, "the PK write-out's third slot needs the LDS the 16-bit gates free");
+    constexpr int IPAR = ipar_floats(SV16, HASDY), OSL = PK ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
@@ -73,8 +89,8 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     const int shalf = gw >> 1;
     float* red = smem;                                // [2 step parities][3 groups][4 K quarters][2 tiles][64][4]
     float* ibuf = smem + 2 * N_RED;                   // [2 step parities][11][16][32, swizzled]: l1 r,z,n,hn,hp,dy ; l0 r,z,n,hn,hp
-    float* obuf = ibuf + 2 * N_IBUF * IARR;           // [2 step parities][8][16][36] : l1 dr,dz,dn,dn*r ; l0 dr,dz,dn,dn*r
-    float* dbl = obuf + 2 * N_OBUF * OARR;            // [2 layers][4][16][36]: bias-gradient accumulators of the gate threads
+    float* obuf = ibuf + 2 * IPAR;                    // [OSL step slots][8][16][36] : l1 dr,dz,dn,dn*r ; l0 dr,dz,dn,dn*r
+    float* dbl = obuf + OSL * N_OBUF * OARR;          // [2 layers][4][16][36]: bias-gradient accumulators of the gate threads
     float* mbuf = dbl + 8 * OARR;                     // [2 step parities][16][36]: dropout mask values of the dy0 a step ends with (drawn by group 1)
     const int b0t = p.b0 + bt * BT;
 
@@ -115,26 +131,30 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     typedef __attribute__((address_space(3))) void* ldsp;
     auto stage = [&](int tv, int uu) {
         constexpr int N1 = HASDY ? 6 : 5, NA = N1 + 5;
-        const int ln = tv & 63, rw = ln >> 3;
+        const int ln = tv & 63;
         const int t1 = T - 1 - uu, t0 = T + 1 - uu;
+        int q = 0;                                        // instruction counter: compile-time after unrolling; wave gw takes q % 4 == gw
 #pragma unroll
-        for (int qi = 0; qi < (2 * NA + 3) / 4; ++qi) {
-            const int q = qi * 4 + gw;                    // wave-uniform
-            if (q < 2 * NA) {
-                const int a = q >> 1, hh = q & 1;
-                const bool l1 = a < N1;
-                const int k = l1 ? a : a - N1;            // 0..3 saved gates, 4 h_{t-1}, 5 dy (layer 1 only)
-                const int t = (l1 ? t1 : t0) - (k == 4 ? 1 : 0);
-                const bool on = (l1 ? t1 >= 0 : (uu >= 2 && t0 >= 0)) && t >= 0;
-                float* dst = ibuf + ((uu & 1) * N_IBUF + a) * IARR + hh * 256;
+        for (int a = 0; a < NA; ++a) {
+            const bool l1 = a < N1;
+            const int k = l1 ? a : a - N1;                // 0..3 saved gates, 4 h_{t-1}, 5 dy (layer 1 only)
+            const bool g16 = SV16 && k < 3;               // a 16-bit array: 16 rows x 64 bytes = ONE instruction (lane -> row lane / 4, piece lane % 4)
+            const int t = (l1 ? t1 : t0) - (k == 4 ? 1 : 0);
+            const bool on = (l1 ? t1 >= 0 : (uu >= 2 && t0 >= 0)) && t >= 0;
+#pragma unroll
+            for (int hh = 0; hh < (g16 ? 1 : 2); ++hh, ++q) {
+                if ((q & 3) != gw) continue;              // wave-uniform
+                float* dst = ibuf + (uu & 1) * IPAR + iarr_off(a, SV16, HASDY) + hh * 256;
                 if (on) {
-                    const int row = hh * 8 + rw;
+                    const int row = g16 ? (ln >> 2) : hh * 8 + (ln >> 3);
                     int b = b0t + row; b = b < p.B ? b : p.B - 1;
-                    const unsigned vo = ((unsigned)b * (unsigned)T + (unsigned)t) * (BH * 4u) + (unsigned)c * 128u + (unsigned)(((ln & 7) ^ (rw & 7)) * 16);
+                    const unsigned e = ((unsigned)b * (unsigned)T + (unsigned)t) * BH + (unsigned)c * 32u;      // first element of the member's 32
+                    const unsigned vo = g16 ? e * 2u + (unsigned)(((ln & 3) ^ ((row >> 1) & 3)) * 16) : e * 4u + (unsigned)(((ln & 7) ^ (row & 7)) * 16);
                     const unsigned so = k < 4 ? (l1 ? p.o_sv1 : p.o_sv0) + (unsigned)k * p.svstride * 4u : (k == 4 ? (l1 ? p.o_y1 : p.o_y0) : 0u);
-                    if (k == 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (ldsp)dst, 16, vo, 0, 0, 0);
-                    else if (l1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ldsp)dst, 16, vo, so, 0, 0);
-                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ldsp)dst, 16, vo, so, 0, 0);
+                    // aux 2 = nt: one-touch streams must not displace the exchange buffer from this XCD's L2
+                    if (k == 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (ldsp)dst, 16, vo, 0, 0, 2);
+                    else if (l1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ldsp)dst, 16, vo, so, 0, 2);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ldsp)dst, 16, vo, so, 0, 2);
                 } else {
                     *reinterpret_cast<f32x4*>(dst + ln * 4) = zero4();
                 }
@@ -143,6 +163,8 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     };
     // an input pair of the gate threads: utterance row j, units (ul, ul+1) -> swizzled float offset inside an array
     auto iswz = [](int j, int ul) { return j * 32 + (((ul >> 2) ^ (j & 7)) << 2) + (ul & 3); };
+    // ... and of a 16-bit array (one word = the pair): 16 words per row, pieces of four words swizzled by row / 2
+    auto iswz16 = [](int j, int ul) { return j * 16 + (((ul >> 3) ^ ((j >> 1) & 3)) << 2) + ((ul & 7) >> 1); };
     auto flush = [&](int tv, int u) {                 // gate gradients of fused step u: LDS -> HBM
         const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
         if (b0t + su >= p.B) return;
@@ -155,8 +177,34 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             const int t = l1 ? T - 1 - u : T + 1 - u;
             const bool on = l1 ? (u <= T - 1) : (u >= 2);
             float* base = k < 3 ? (l1 ? p.dgi1 : p.dgi0) : (l1 ? p.dghn1 : p.dghn0);
-            const size_t off = k < 3 ? (size_t)(row0 + t) * (3 * BH) + k * BH : (size_t)(row0 + t) * BH;
-            if (on) *reinterpret_cast<f32x4*>(base + off + c * 32 + sqd * 4) = ld4(obuf + ((u & 1) * N_OBUF + a) * OARR + su * OROW + sqd * 4);
+            const size_t off = k < 3 ? (size_t)(row0 + t) * p.lddg + k * BH : (size_t)(row0 + t) * p.lddghn;
+            if (on) *reinterpret_cast<f32x4*>(base + off + c * 32 + sqd * 4) = ld4(obuf + ((u % OSL) * N_OBUF + a) * OARR + su * OROW + sqd * 4);
+        }
+    };
+    // PK: the step pair (ua, ua + 1), ua even, of both layers = rows (t_even + 1, t_even): row t_even takes bf16hi(x[t_even]) | bf16hi(x[t_even+1]) << 16
+    // per column, row t_even + 1 the residual pairs -- exactly what the GEMM staging's split would form (rnn_cluster_bwd.hip svc_flush_pk)
+    __amdgpu_buffer_rsrc_t rso1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgi1, 0, (unsigned)((size_t)p.B * T * 4 * BH * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rso0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgi0, 0, (unsigned)((size_t)p.B * T * 4 * BH * 4), 0x00020000);
+    auto flush_pk = [&](int tv, int ua) {
+        const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
+        if (b0t + su >= p.B) return;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const int a = pr * 2 + shalf;                 // 0..3 layer 1 (dr, dz, dn, dn*r), 4..7 layer 0
+            const bool l1 = a < 4;
+            const int k = a & 3;
+            const bool on = l1 ? (ua + 1 <= T - 1) : (ua >= 2);
+            const int te = l1 ? T - 2 - ua : T - ua;      // the even row of the pair = the LATER step's time index
+            if (on) {
+                const f32x4 xo = ld4(obuf + ((ua % 3) * N_OBUF + a) * OARR + su * OROW + sqd * 4);            // step ua     = row te + 1
+                const f32x4 xe = ld4(obuf + (((ua + 1) % 3) * N_OBUF + a) * OARR + su * OROW + sqd * 4);      // step ua + 1 = row te
+                u32x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { unsigned hh, ll; split_pair(xe[e], xo[e], hh, ll); h[e] = hh; l[e] = ll; }
+                const unsigned go = (((unsigned)(b0t + su) * (unsigned)T + (unsigned)te) * 4u * BH + (unsigned)k * BH + (unsigned)c * 32u + (unsigned)sqd * 4u) * 4u;
+                if (l1) { __builtin_amdgcn_raw_buffer_store_b128(h, rso1, go, 0, 2 /* nt */); __builtin_amdgcn_raw_buffer_store_b128(l, rso1, go + 4u * BH * 4u, 0, 2); }
+                else { __builtin_amdgcn_raw_buffer_store_b128(h, rso0, go, 0, 2 /* nt */); __builtin_amdgcn_raw_buffer_store_b128(l, rso0, go + 4u * BH * 4u, 0, 2); }
+            }
         }
     };
     {   // initial recurrent gradient (dh_n) and the pooling gradient of the top layer
@@ -181,11 +229,21 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         const unsigned epoch = (unsigned)v + 1u;
         // ---- gate gradients (groups 0 and 2; identical code, role-dependent LDS bases), published at once
         if (act) {
-            const float* ib = ibuf + ((v & 1) * N_IBUF + (grp == 0 ? 0 : (HASDY ? 6 : 5))) * IARR + iswz(j, ul);
-            const float2 r = ld2(ib), z = ld2(ib + IARR), n = ld2(ib + 2 * IARR), hn = ld2(ib + 3 * IARR), hp = ld2(ib + 4 * IARR);
+            constexpr int GA = gate_arr(SV16);
+            const float* il = ibuf + (v & 1) * IPAR + (grp == 0 ? 0 : iarr_off(HASDY ? 6 : 5, SV16, HASDY));      // this layer's arrays: r, z, n | hn, hp, [dy]
+            float2 r, z, n;
+            if constexpr (SV16) {
+                const unsigned* iw = reinterpret_cast<const unsigned*>(il) + iswz16(j, ul);
+                r = unpack_unorm2(iw[0]); z = unpack_unorm2(iw[GA]); n = unpack_snorm2(iw[2 * GA]);
+            } else {
+                const float* ig = il + iswz(j, ul);
+                r = ld2(ig); z = ld2(ig + GA); n = ld2(ig + 2 * GA);
+            }
+            const float* ib = il + 3 * GA + iswz(j, ul);
+            const float2 hn = ld2(ib), hp = ld2(ib + IARR);
             float2 dyv = f2(0.f, 0.f);
             if (grp == 2) dyv = f2(st[3][0], st[3][1]);   // layer 0: masked gradient from layer 1
-            if (HASDY && grp == 0) dyv = ld2(ib + 5 * IARR);
+            if (HASDY && grp == 0) dyv = ld2(ib + 2 * IARR);
             const float2 d = f2(st[0][0] + st[0][2] + dyv.x, st[0][1] + st[0][3] + dyv.y);
             float2 dn, dz, dr, dnr;
             dn.x = d.x * (1.0f - z.x) * (1.0f - n.x * n.x); dn.y = d.y * (1.0f - z.y) * (1.0f - n.y * n.y);
@@ -214,7 +272,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
                     if (grp == 0) { __builtin_amdgcn_raw_buffer_store_b32(wd[6], rsrc, po + 6 * 1024, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(wd[7], rsrc, po + 7 * 1024, 0, 16); }
                 }
             }
-            float* ob = obuf + ((v & 1) * N_OBUF + (grp == 0 ? 0 : 4)) * OARR + j * OROW + ul;
+            float* ob = obuf + ((v % OSL) * N_OBUF + (grp == 0 ? 0 : 4)) * OARR + j * OROW + ul;
             st2(ob, dr); st2(ob + OARR, dz); st2(ob + 2 * OARR, dn); st2(ob + 3 * OARR, dnr);
             {   // bias-gradient accumulators (this thread's own four float2 slots)
                 float* da = dbl + (grp == 0 ? 0 : 4) * OARR + j * OROW + ul;
@@ -272,7 +330,8 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             // inputs by DMA, then the previous step's gate gradients
             __builtin_amdgcn_sched_barrier(0);
             stage(tv, v + 1);
-            if (v >= 1) flush(tv, v - 1);
+            if constexpr (PK) { if (v >= 2 && !(v & 1)) flush_pk(tv, v - 2); }
+            else { if (v >= 1) flush(tv, v - 1); }
             if constexpr (DROP) {
                 // the dropout mask of the dy0 this step ends with (t = T - v; same Philox draw as the forward's mask of y0): ~150 VALU
                 // instructions that have no business on the gate threads' chain -- two of this group's waves draw the member's 128 blocks
@@ -312,7 +371,10 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             }
         }
     }
-    if (grp == 1) { flush(tid, T); flush(tid, T + 1); }   // layer 0's last two steps (t = 1, 0) are still in LDS
+    if (grp == 1) {                                       // layer 0's last two steps (t = 1, 0) are still in LDS
+        if constexpr (PK) flush_pk(tid, T);
+        else { flush(tid, T); flush(tid, T + 1); }
+    }
     if (grp != 1) {
         // bias-gradient partials [batch tile][4][H]: sum over the 16 utterance rows = lanes that differ in bits 1..4
         float2 a[4];
@@ -355,6 +417,8 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
     const bool drop = a.drop_p > 0.f;
     p.drop_p = a.drop_p; p.drop_scale = drop ? 1.0f / (1.0f - a.drop_p) : 1.0f; p.seed = a.seed; p.site = a.site;
     p.dgi1 = a.dgi1; p.dghn1 = a.dghn1; p.dgi0 = a.dgi0; p.dghn0 = a.dghn0; p.dbpart1 = a.dbpart1; p.dbpart0 = a.dbpart0;
+    p.lddg = a.lddg ? a.lddg : 3 * BH; p.lddghn = a.lddghn ? a.lddghn : BH;
+    DEP_CHECK_ARG(!a.dg_pk || (p.lddg == 4 * BH && a.dghn1 == a.dgi1 + 3 * BH && a.dghn0 == a.dgi0 + 3 * BH));
     DEP_CHECK_ARG(a.dbpart_rows >= nbt && a.wh1 && a.wi1 && a.wh0 && a.dgi1 && a.dgi0 && a.dghn1 && a.dghn0);
     static_assert(DEP_HDR_SLOTS >= 2, "the fused backward keeps layer 0's flags in header slot 1");
     p.status = (unsigned*)xbuf; p.flags1 = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.flags0 = (unsigned*)(hdr_base(xbuf, 1) + FLAG_OFF);
@@ -373,12 +437,15 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
         DEP_CHECK_ARG(span(a.y1, a.sv1, p.sb1, p.sbytes1, p.o_y1, p.o_sv1) && span(a.y0, a.sv0, p.sb0, p.sbytes0, p.o_y0, p.o_sv0));
         DEP_CHECK_ARG(arr < 0xfffffff0ull);           // (an external dy is addressed from its own base)
     }
+    const bool sv16 = a.sv16 != 0, pk = a.dg_pk != 0;
+    DEP_CHECK_ARG(!pk || (sv16 && a.T % 2 == 0 && (size_t)a.B * a.T * 4 * BH * 4 < 0xfffffff0ull));      // PK: 16-bit gates (LDS), whole step pairs, 32-bit offsets into the image
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B_LDS_BYTES);
+#define FB_ATTR(D, Y, S, P) (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<D, Y, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(S, Y, P))
+#define FB_ATTR4(S, P) FB_ATTR(true, true, S, P); FB_ATTR(true, false, S, P); FB_ATTR(false, true, S, P); FB_ATTR(false, false, S, P)
+        FB_ATTR4(false, false); FB_ATTR4(true, false); FB_ATTR4(true, true);
+#undef FB_ATTR4
+#undef FB_ATTR
         attr = true;
     }
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
@@ -392,10 +459,12 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
         { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
         { const int rc_h = hdr_prepare(xbuf, 1, false, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(BNC * p.nbtp), blk(BTHREADS);
-        if (drop) { if (a.dy) hipLaunchKernelGGL((gru2_bwd_fused<true, true>), grid, blk, B_LDS_BYTES, a.stream, p);
-                    else hipLaunchKernelGGL((gru2_bwd_fused<true, false>), grid, blk, B_LDS_BYTES, a.stream, p); }
-        else      { if (a.dy) hipLaunchKernelGGL((gru2_bwd_fused<false, true>), grid, blk, B_LDS_BYTES, a.stream, p);
-                    else hipLaunchKernelGGL((gru2_bwd_fused<false, false>), grid, blk, B_LDS_BYTES, a.stream, p); }
+#define FB_GO(D, Y, S, P) hipLaunchKernelGGL((gru2_bwd_fused<D, Y, S, P>), grid, blk, fb_lds_bytes(S, Y, P), a.stream, p)
+#define FB_GO4(S, P) do { if (drop) { if (a.dy) FB_GO(true, true, S, P); else FB_GO(true, false, S, P); } \
+                          else      { if (a.dy) FB_GO(false, true, S, P); else FB_GO(false, false, S, P); } } while (0)
+        if (pk) FB_GO4(true, true); else if (sv16) FB_GO4(true, false); else FB_GO4(false, false);
+#undef FB_GO4
+#undef FB_GO
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
