@@ -27,7 +27,6 @@ namespace {
 using namespace depc;
 
 constexpr int BH = 256, BNC = 8, BTHREADS = 768;
-constexpr int OROW = 36, OARR = BT * OROW;    // fp32 [16 utterances][32 units] arrays, rows padded (bank conflicts)
 constexpr int N_IBUF = 11, N_OBUF = 8;        // input arrays: l1 r,z,n,hn,h_{t-1},[dy] ; l0 r,z,n,hn,h_{t-1}  (10 without dy: five per wave half)
 constexpr unsigned L1_MEMBER = 8 * 1024, L0_MEMBER = 6 * 1024;      // bytes: [gate][plane][64 lanes][16 B] -- l1: dr, dz, dn*r, dn ; l0: dr, dz, dn*r
 constexpr int N_RED = 3 * 4 * 2 * 256;        // floats of one step parity: [group][K quarter = wave][own tile][64 lanes][4]
@@ -44,8 +43,12 @@ constexpr int iarr_off(int a, bool sv16, bool hasdy) {
     const int k = a < n1 ? a : a - n1;
     return (a < n1 ? 0 : l1sz) + (k < 3 ? k * gate_arr(sv16) : 3 * gate_arr(sv16) + (k - 3) * IARR);
 }
+// Prefetch distance of the input streams (fused steps): 2 where the LDS has room for a third input slot (16-bit gates, no external dy) -- the DMA
+// requests then go out AFTER the step's critical fragment loads were issued and land during the NEXT step's gate phase, when nothing latency-critical
+// uses the CU's memory pipeline (a CU returns loads in issue order across its waves: an HBM request in flight holds every later L2 hit back).
+constexpr int pf_dist(bool sv16, bool hasdy) { return (sv16 && !hasdy) ? 2 : 1; }
 constexpr size_t fb_lds_bytes(bool sv16, bool hasdy, bool pk) {
-    return (size_t)(2 * N_RED + 2 * ipar_floats(sv16, hasdy) + ((pk ? 3 : 2) * N_OBUF + 8 + 2) * OARR + 64) * sizeof(float);
+    return (size_t)(2 * N_RED + (pf_dist(sv16, hasdy) + 1) * ipar_floats(sv16, hasdy) + ((pk ? 3 : 2) * N_OBUF + 8 + 2) * IARR + 64) * sizeof(float);
 }
 
 struct FB {
@@ -64,6 +67,7 @@ struct FB {
     // input streams as buffer resources (LDS-DMA): per layer ONE base below its y / saved-gate arrays, the arrays as byte offsets from it
     const char* sb1; const char* sb0; unsigned sbytes1, sbytes0;
     unsigned o_sv1, o_y1, o_sv0, o_y0;                              // saved gates r (then z, n, hn at + k svstride floats), forward sequence
+    int dbg;                                                        // timing experiments (DEP_FBWD_DBG; results are garbage): 1 = no input streams, 2 = no write-out
 };
 
 // Registers: 3 waves per SIMD -> 168 VGPRs, 96 of them weights.  Per-thread indices are re-derived every step from a laundered
@@ -77,7 +81,7 @@ struct FB {
 template <bool DROP, bool HASDY, bool SV16, bool PK>
 __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     static_assert(!PK || SV16, "the PK write-out's third slot needs the LDS the 16-bit gates free");
-    constexpr int IPAR = ipar_floats(SV16, HASDY), OSL = PK ? 3 : 2;
+    constexpr int IPAR = ipar_floats(SV16, HASDY), OSL = PK ? 3 : 2, PF = pf_dist(SV16, HASDY), ISL = PF + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
@@ -89,9 +93,10 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     const int shalf = gw >> 1;
     float* red = smem;                                // [2 step parities][3 groups][4 K quarters][2 tiles][64][4]
     float* ibuf = smem + 2 * N_RED;                   // [2 step parities][11][16][32, swizzled]: l1 r,z,n,hn,hp,dy ; l0 r,z,n,hn,hp
-    float* obuf = ibuf + 2 * IPAR;                    // [OSL step slots][8][16][36] : l1 dr,dz,dn,dn*r ; l0 dr,dz,dn,dn*r
-    float* dbl = obuf + OSL * N_OBUF * OARR;          // [2 layers][4][16][36]: bias-gradient accumulators of the gate threads
-    float* mbuf = dbl + 8 * OARR;                     // [2 step parities][16][36]: dropout mask values of the dy0 a step ends with (drawn by group 1)
+    float* obuf = ibuf + ISL * IPAR;                  // [OSL step slots][8][16][32, swizzled] : l1 dr,dz,dn,dn*r ; l0 dr,dz,dn,dn*r
+    float* dbl = obuf + OSL * N_OBUF * IARR;          // [2 layers][4][16][32, swizzled]: bias-gradient accumulators of the gate threads
+    float* mbuf = dbl + 8 * IARR;                     // [2 step parities][16][32, swizzled]: dropout mask values of the dy0 a step ends with (drawn by group 1)
+    unsigned* sig = reinterpret_cast<unsigned*>(mbuf + 2 * IARR);      // count of critical waves that have issued their last fragment requests (monotonic)
     const int b0t = p.b0 + bt * BT;
 
     u32x4 wq[2][6][2];                                // [own output tile][k-step = (source member 2gw + ks/3, gate ks%3)][hi, lo]
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     f32x4 st[4];                                      // (st[1], st[2] unused: the accumulators moved to LDS)
 #pragma unroll
     for (int i = 0; i < 4; ++i) st[i] = zero4();
-    for (int i = tid; i < 8 * OARR; i += BTHREADS) dbl[i] = 0.f;
+    for (int i = tid; i < 8 * IARR; i += BTHREADS) dbl[i] = 0.f;
+    if (tid == 0) *sig = 0u;
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
     const unsigned par1 = (unsigned)p.nbtp * BNC * L1_MEMBER, par0 = (unsigned)p.nbtp * BNC * L0_MEMBER;      // bytes of one buffer
@@ -144,8 +150,8 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
 #pragma unroll
             for (int hh = 0; hh < (g16 ? 1 : 2); ++hh, ++q) {
                 if ((q & 3) != gw) continue;              // wave-uniform
-                float* dst = ibuf + (uu & 1) * IPAR + iarr_off(a, SV16, HASDY) + hh * 256;
-                if (on) {
+                float* dst = ibuf + (uu % ISL) * IPAR + iarr_off(a, SV16, HASDY) + hh * 256;
+                if (on && !(p.dbg & 1)) {
                     const int row = g16 ? (ln >> 2) : hh * 8 + (ln >> 3);
                     int b = b0t + row; b = b < p.B ? b : p.B - 1;
                     const unsigned e = ((unsigned)b * (unsigned)T + (unsigned)t) * BH + (unsigned)c * 32u;      // first element of the member's 32
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             const bool on = l1 ? (u <= T - 1) : (u >= 2);
             float* base = k < 3 ? (l1 ? p.dgi1 : p.dgi0) : (l1 ? p.dghn1 : p.dghn0);
             const size_t off = k < 3 ? (size_t)(row0 + t) * p.lddg + k * BH : (size_t)(row0 + t) * p.lddghn;
-            if (on) *reinterpret_cast<f32x4*>(base + off + c * 32 + sqd * 4) = ld4(obuf + ((u % OSL) * N_OBUF + a) * OARR + su * OROW + sqd * 4);
+            if (on) *reinterpret_cast<f32x4*>(base + off + c * 32 + sqd * 4) = ld4(obuf + ((u % OSL) * N_OBUF + a) * IARR + su * 32 + ((sqd ^ (su & 7)) << 2));
         }
     };
     // PK: the step pair (ua, ua + 1), ua even, of both layers = rows (t_even + 1, t_even): row t_even takes bf16hi(x[t_even]) | bf16hi(x[t_even+1]) << 16
@@ -196,8 +202,9 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             const bool on = l1 ? (ua + 1 <= T - 1) : (ua >= 2);
             const int te = l1 ? T - 2 - ua : T - ua;      // the even row of the pair = the LATER step's time index
             if (on) {
-                const f32x4 xo = ld4(obuf + ((ua % 3) * N_OBUF + a) * OARR + su * OROW + sqd * 4);            // step ua     = row te + 1
-                const f32x4 xe = ld4(obuf + (((ua + 1) % 3) * N_OBUF + a) * OARR + su * OROW + sqd * 4);      // step ua + 1 = row te
+                const int so_ = su * 32 + ((sqd ^ (su & 7)) << 2);
+                const f32x4 xo = ld4(obuf + ((ua % 3) * N_OBUF + a) * IARR + so_);            // step ua     = row te + 1
+                const f32x4 xe = ld4(obuf + (((ua + 1) % 3) * N_OBUF + a) * IARR + so_);      // step ua + 1 = row te
                 u32x4 h, l;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { unsigned hh, ll; split_pair(xe[e], xo[e], hh, ll); h[e] = hh; l[e] = ll; }
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             if (grp == 0 && p.dpooled) { const float2 v = ld2(p.dpooled + (size_t)b * BH + col); st[0][2] = v.x * p.pool_scale; st[0][3] = v.y * p.pool_scale; }
         }
     }
-    if (grp == 1) { stage(tid, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (grp == 1) { stage(tid, 0); if (PF == 2) stage(tid, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
 
     for (int v = 0; v <= T + 1; ++v) {
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         // ---- gate gradients (groups 0 and 2; identical code, role-dependent LDS bases), published at once
         if (act) {
             constexpr int GA = gate_arr(SV16);
-            const float* il = ibuf + (v & 1) * IPAR + (grp == 0 ? 0 : iarr_off(HASDY ? 6 : 5, SV16, HASDY));      // this layer's arrays: r, z, n | hn, hp, [dy]
+            const float* il = ibuf + (v % ISL) * IPAR + (grp == 0 ? 0 : iarr_off(HASDY ? 6 : 5, SV16, HASDY));      // this layer's arrays: r, z, n | hn, hp, [dy]
             float2 r, z, n;
             if constexpr (SV16) {
                 const unsigned* iw = reinterpret_cast<const unsigned*>(il) + iswz16(j, ul);
@@ -272,13 +279,13 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
                     if (grp == 0) { __builtin_amdgcn_raw_buffer_store_b32(wd[6], rsrc, po + 6 * 1024, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(wd[7], rsrc, po + 7 * 1024, 0, 16); }
                 }
             }
-            float* ob = obuf + ((v % OSL) * N_OBUF + (grp == 0 ? 0 : 4)) * OARR + j * OROW + ul;
-            st2(ob, dr); st2(ob + OARR, dz); st2(ob + 2 * OARR, dn); st2(ob + 3 * OARR, dnr);
+            float* ob = obuf + ((v % OSL) * N_OBUF + (grp == 0 ? 0 : 4)) * IARR + iswz(j, ul);
+            st2(ob, dr); st2(ob + IARR, dz); st2(ob + 2 * IARR, dn); st2(ob + 3 * IARR, dnr);
             {   // bias-gradient accumulators (this thread's own four float2 slots)
-                float* da = dbl + (grp == 0 ? 0 : 4) * OARR + j * OROW + ul;
-                const float2 a0 = ld2(da), a1 = ld2(da + OARR), a2 = ld2(da + 2 * OARR), a3 = ld2(da + 3 * OARR);
-                st2(da, f2(a0.x + dr.x, a0.y + dr.y)); st2(da + OARR, f2(a1.x + dz.x, a1.y + dz.y));
-                st2(da + 2 * OARR, f2(a2.x + dn.x, a2.y + dn.y)); st2(da + 3 * OARR, f2(a3.x + dnr.x, a3.y + dnr.y));
+                float* da = dbl + (grp == 0 ? 0 : 4) * IARR + iswz(j, ul);
+                const float2 a0 = ld2(da), a1 = ld2(da + IARR), a2 = ld2(da + 2 * IARR), a3 = ld2(da + 3 * IARR);
+                st2(da, f2(a0.x + dr.x, a0.y + dr.y)); st2(da + IARR, f2(a1.x + dz.x, a1.y + dz.y));
+                st2(da + 2 * IARR, f2(a2.x + dn.x, a2.y + dn.y)); st2(da + 3 * IARR, f2(a3.x + dnr.x, a3.y + dnr.y));
             }
         }
         if (v == T + 1) { bar_lds(); break; }             // layer 0's last step (t = 0): nothing left to exchange
@@ -286,6 +293,8 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's words are acknowledged
             if (act && lane == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         }
+        // (prefetch distance 2: the inputs of step v+1 and the last write-out were requested late in step v-1 and had this group's whole idle time to land)
+        if (PF == 2 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ---- the group's product: K quarter gw (source members 2gw, 2gw+1) x own 32 columns
         //   group 0: layer 1, step v (needed while a layer-1 step follows) ; group 1: layer 1, step v-1 ; group 2: layer 0, step v
         const bool mact = grp == 0 ? (v <= T - 2) : (grp == 1 ? (v >= 1 && v <= T) : (v >= 2 && v <= T));
@@ -308,6 +317,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl)
                         gfr[g][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + (g == 2 ? g2 : (unsigned)g * 2048u) + (unsigned)pl * 1024u, 0, 16 /* sc1: served by L2 */);
+                if (rd == 1 && grp != 1 && lane == 0) atomicAdd(sig, 1u);       // this critical wave's last requests are in the CU's queue
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
@@ -324,25 +334,33 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             float* rw = red + ((((v & 1) * 3 + grp) * 4 + gw) * 2) * 256 + lane * 4;
             *reinterpret_cast<f32x4*>(rw) = acc[0]; *reinterpret_cast<f32x4*>(rw + 256) = acc[1];
         }
+        else if (grp != 1 && lane == 0) atomicAdd(sig, 1u);               // (no product this step: nothing of this wave will be in the queue)
         if (grp == 1) {
-            // group 1's HBM streams go out BEHIND its fragment requests and products (a wave's loads return in issue order; fragments and
-            // accumulators are dead by now: the register peak of this kernel is elsewhere) and have the rest of the step to land: next step's
-            // inputs by DMA, then the previous step's gate gradients
+            // group 1's HBM streams: next inputs by DMA, then the finished gate gradients.  They go out once the eight critical waves of this
+            // member have ISSUED their last fragment requests (an LDS counter: no memory traffic to watch it): an HBM access in the CU's queue
+            // holds back every load issued behind it for its whole round trip.  With prefetch distance 2 they then land in the next step's gate
+            // phase; with distance 1 they must land before this step's barrier.
             __builtin_amdgcn_sched_barrier(0);
-            stage(tv, v + 1);
-            if constexpr (PK) { if (v >= 2 && !(v & 1)) flush_pk(tv, v - 2); }
-            else { if (v >= 1) flush(tv, v - 1); }
+            {
+                const unsigned want = 8u * ((unsigned)v + 1u);
+                for (int spin = 0; spin < 20000 && *reinterpret_cast<volatile unsigned*>(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
+            }
+            stage(tv, v + PF);
+            if (!(p.dbg & 2)) {
+                if constexpr (PK) { if (v >= 2 && !(v & 1)) flush_pk(tv, v - 2); }
+                else { if (v >= 1) flush(tv, v - 1); }
+            }
             if constexpr (DROP) {
                 // the dropout mask of the dy0 this step ends with (t = T - v; same Philox draw as the forward's mask of y0): ~150 VALU
                 // instructions that have no business on the gate threads' chain -- two of this group's waves draw the member's 128 blocks
                 if (shalf == 1 && v >= 1 && v <= T) {
                     const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
                     const size_t o = ((size_t)(b0t + su) * T + (T - v)) * BH + c * 32 + sqd * 4;
-                    *reinterpret_cast<f32x4*>(mbuf + (v & 1) * OARR + su * OROW + sqd * 4) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+                    *reinterpret_cast<f32x4*>(mbuf + (v & 1) * IARR + su * 32 + ((sqd ^ (su & 7)) << 2)) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
                 }
             }
         }
-        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA'd inputs of step v+1 are in LDS, the write-out is acknowledged: nothing of this group is in flight at the barrier
+        if (PF == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // distance 1: the DMA'd inputs of step v+1 must be in LDS at this barrier
         bar_lds();                                        // the step's ONE barrier: partials in red, next step's inputs in ibuf, this step's write-out read
         // ---- K-quarter sums (fixed order: deterministic)
         if (grp != 1) {
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
                     float2 s = f2(0.f, 0.f);
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) { const float2 x = ld2(rr + 2048 + q4 * 512); s.x += x.x; s.y += x.y; }
-                    if constexpr (DROP) { const float2 m = ld2(mbuf + (v & 1) * OARR + j * OROW + ul); s.x *= m.x; s.y *= m.y; }
+                    if constexpr (DROP) { const float2 m = ld2(mbuf + (v & 1) * IARR + iswz(j, ul)); s.x *= m.x; s.y *= m.y; }
                     st[3][0] = s.x; st[3][1] = s.y;
                 }
             }
@@ -380,10 +398,10 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         float2 a[4];
         {
             const int lt0 = tid & 255, lp0 = (lt0 >> 1) & 63, j0 = lp0 & 15, ul0 = (lt0 >> 7) * 16 + (lp0 >> 4) * 4 + 2 * (lt0 & 1);
-            const float* da = dbl + (grp == 0 ? 0 : 4) * OARR + j0 * OROW + ul0;
+            const float* da = dbl + (grp == 0 ? 0 : 4) * IARR + j0 * 32 + (((ul0 >> 2) ^ (j0 & 7)) << 2) + (ul0 & 3);
             const bool rowok = b0t + j0 < p.B;            // (rows past the batch carried a copy of the last utterance: not part of the sums)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = rowok ? ld2(da + k * OARR) : f2(0.f, 0.f);
+            for (int k = 0; k < 4; ++k) a[k] = rowok ? ld2(da + k * IARR) : f2(0.f, 0.f);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -424,6 +442,7 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
     p.status = (unsigned*)xbuf; p.flags1 = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.flags0 = (unsigned*)(hdr_base(xbuf, 1) + FLAG_OFF);
     p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.nofast = nofast_env();
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DEP_FBWD_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     {   // the input streams' buffer resources: per layer one base below its arrays, 32-bit offsets
         const size_t arr = (size_t)a.B * a.T * BH * sizeof(float);
         auto span = [&](const float* y, const float* sv, const char*& base, unsigned& bytes, unsigned& oy, unsigned& osv) {

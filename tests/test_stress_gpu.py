@@ -27,7 +27,8 @@ CASES = [
     ('gru', 8, {}, ['--load', '--H', '128']),
     ('gru', 8, {'DEP_GEMM_MODE': 'f32'}, []),                    # exact-fp32 sweeps (different member kernels)
     ('gru', 8, {}, ['--H', '128']),                               # 32-unit-member forward kernel
-    ('gru', 6, {'DEP_FUSED2_BWD': '1'}, []),                      # opt-in fused two-layer backward: same bits every run
+    ('gru', 6, {'DEP_FUSED2_BWD': '0'}, []),                      # round 5: the fused two-layer (all-gather) backward is the default; 0 = the two per-layer sweeps + dX GEMM
+    ('gru', 6, {'DEP_FUSED2_BWD': '0'}, ['--load', '--load-phase', 'bwd']),
     ('gru', 8, {'DEP_BWD_AG': '0'}, []),                          # round 5: the default backward exchange is the all-gather of gate gradients; 0 = the reduce-scatter of fp32 partials
     ('gru', 6, {'DEP_BWD_AG': '0'}, ['--load', '--load-phase', 'bwd']),
     ('gru', 8, {'DEP_BWD_BURST': '0'}, []),                       # round-1 backward schedule (no service waves)
@@ -99,10 +100,11 @@ def test_shared_gpu_mode_runs_the_tolerant_forward_and_passes_the_parity_suite()
     assert ' passed' in r.stdout
 
 
-def test_opt_in_fused_backward_passes_the_kernel_parity_suite():
-    """rnn_fused2_bwd.hip (both GRU layers' BPTT in one launch) is not the default path but stays
-    parity-green: the whole RNN-stack suite, run in a process with DEP_FUSED2_BWD=1, against the oracle."""
-    e = dict(os.environ, DEP_FUSED2_BWD='1')
+def test_per_layer_backward_sweeps_pass_the_kernel_parity_suite():
+    """Round 5: rnn_fused2_bwd.hip (both GRU layers' BPTT in one all-gather launch) is the default for the 2-layer GRU-256 stack;
+    DEP_FUSED2_BWD=0 selects the two per-layer sweeps + layer 1's dX GEMM it replaced, which stay parity-green: the GRU part of the
+    RNN-stack suite against the oracle (the other shapes run the per-layer kernels in either mode)."""
+    e = dict(os.environ, DEP_FUSED2_BWD='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
