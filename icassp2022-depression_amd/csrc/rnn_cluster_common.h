@@ -153,6 +153,13 @@ __device__ __forceinline__ bool wait_flags(unsigned* tflags, int NC, unsigned ep
     }
 }
 
+// An LDS counter that the streaming waves of the fused kernels watch ("the critical waves have issued their fragment requests").  The
+// accesses MUST be LDS instructions: through a generic pointer hipcc emits flat_load / flat_atomic, which travel the VECTOR memory path
+// -- the poll then queues behind the very HBM traffic it is there to schedule around (and its s_waitcnt vmcnt(0) waits for all of it).
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+__device__ __forceinline__ void sig_raise(unsigned* sig) { __hip_atomic_fetch_add((lds_u32*)sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned sig_read(unsigned* sig) { return __hip_atomic_load((lds_u32*)sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // Non-temporal access to the sweeps' ONE-TOUCH HBM streams (round 4).  tools/micro/l2wb.hip + PMC: stream stores (and, less so, loads)
 // that allocate in the XCD's L2 evict the exchange payload -- rewritten in place every other step -- before its next rewrite, and
 // every eviction is a write-back to HBM plus fabric traffic in front of the hand-off; with the nt bit the payload stays.

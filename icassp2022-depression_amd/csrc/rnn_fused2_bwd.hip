@@ -317,7 +317,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl)
                         gfr[g][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + (g == 2 ? g2 : (unsigned)g * 2048u) + (unsigned)pl * 1024u, 0, 16 /* sc1: served by L2 */);
-                if (rd == 1 && grp != 1 && lane == 0) atomicAdd(sig, 1u);       // this critical wave's last requests are in the CU's queue
+                if (rd == 1 && grp != 1 && lane == 0) sig_raise(sig);       // this critical wave's last requests are in the CU's queue
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             float* rw = red + ((((v & 1) * 3 + grp) * 4 + gw) * 2) * 256 + lane * 4;
             *reinterpret_cast<f32x4*>(rw) = acc[0]; *reinterpret_cast<f32x4*>(rw + 256) = acc[1];
         }
-        else if (grp != 1 && lane == 0) atomicAdd(sig, 1u);               // (no product this step: nothing of this wave will be in the queue)
+        else if (grp != 1 && lane == 0) sig_raise(sig);               // (no product this step: nothing of this wave will be in the queue)
         if (grp == 1) {
             // group 1's HBM streams: next inputs by DMA, then the finished gate gradients.  They go out once the eight critical waves of this
             // member have ISSUED their last fragment requests (an LDS counter: no memory traffic to watch it): an HBM access in the CU's queue
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             __builtin_amdgcn_sched_barrier(0);
             {
                 const unsigned want = 8u * ((unsigned)v + 1u);
-                for (int spin = 0; spin < 20000 && *reinterpret_cast<volatile unsigned*>(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
+                for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
             }
             stage(tv, v + PF);
             if (!(p.dbg & 2)) {
