@@ -480,6 +480,11 @@ def main():
     # gates recomputed") = 4H bytes in fp32.  The DESIGN bytes count what this implementation chose to move instead (saved
     # gate tensors, the materialised input projection and its gradient), DESIGN.md section 4.
     sweep_flops = 2.0 * B * T * (G * H) * H * dirs * layers_per_launch
+    fused_gru = dom.startswith('gru') and layers_per_launch > 1.5
+    if fused_gru:
+        # a fused two-layer GRU launch carries a THIRD product of the same size beside the two recurrences: layer 1's input projection
+        # W_ih(l1) dropout(h0) in the forward, the gradient entering layer 0, dgi(l1) W_ih(l1), in the backward (the former projection / dX GEMMs)
+        sweep_flops *= 1.5
     fusion = args.workload == 'fusion'
     design_per_ut = ({'gru_fwd_sweep': 18 * H, 'lstm_fwd_sweep': 44 * H} if fusion else
                      {'gru_fwd_sweep': 34 * H, 'gru_bwd_sweep': 32 * H, 'lstm_fwd_sweep': 84 * H, 'lstm_bwd_sweep': 88 * H})[dom]      # (round 4: GRU saved gates r, z, n are 2 bytes each: backward 38H -> 32H)
@@ -489,6 +494,10 @@ def main():
         # the fused two-layer forward: layer 0's input projection in (12H), both layers' h (8H) and saved gates (2 x (6H + 4H)) out, the
         # dropped copy of layer 0's h (4H); layer 1's projection never exists in HBM
         design_bytes = float(44 * H) * B * T              # (round 4: 16-bit r, z, n: 56H -> 44H)
+    if dom == 'gru_bwd_sweep' and layers_per_launch > 1.5:
+        # the fused two-layer backward (round 5): per layer r, z, n (2 bytes each) + hn + h_{t-1} in (14H), the 4H-wide PK gate gradients out (16H);
+        # layer 1's dX / layer 0's dy never exist in HBM
+        design_bytes = float(60 * H) * B * T
     compulsory_bytes = float(compulsory_per_ut) * B * T * layers_per_launch
     split = L.get_gemm_mode() == 1                           # the cluster sweeps follow the GEMM precision mode
     mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS

@@ -29,10 +29,11 @@ CASES = [
     ('gru', 8, {}, ['--H', '128']),                               # 32-unit-member forward kernel
     ('gru', 6, {'DEP_FUSED2_BWD': '0'}, []),                      # round 5: the fused two-layer (all-gather) backward is the default; 0 = the two per-layer sweeps + dX GEMM
     ('gru', 6, {'DEP_FUSED2_BWD': '0'}, ['--load', '--load-phase', 'bwd']),
-    ('gru', 8, {'DEP_BWD_AG': '0'}, []),                          # round 5: the default backward exchange is the all-gather of gate gradients; 0 = the reduce-scatter of fp32 partials
-    ('gru', 6, {'DEP_BWD_AG': '0'}, ['--load', '--load-phase', 'bwd']),
-    ('gru', 8, {'DEP_BWD_BURST': '0'}, []),                       # round-1 backward schedule (no service waves)
-    ('gru', 8, {'DEP_BWD_BURST': '6'}, ['--load', '--load-phase', 'bwd']),   # longer bursts, with a co-scheduled kernel
+    ('gru', 8, {'DEP_BWD_AG': '0', 'DEP_FUSED2_BWD': '0'}, []),                          # round 5: the default backward exchange is the all-gather of gate gradients; 0 = the reduce-scatter of fp32 partials
+    ('gru', 6, {'DEP_BWD_AG': '0', 'DEP_FUSED2_BWD': '0'}, ['--load', '--load-phase', 'bwd']),
+    ('gru', 6, {'DEP_FWD_DF': '1'}, []),                          # opt-in direct-fragment fused forward
+    ('gru', 8, {'DEP_BWD_BURST': '0', 'DEP_FUSED2_BWD': '0'}, []),                       # round-1 backward schedule (no service waves)
+    ('gru', 8, {'DEP_BWD_BURST': '6', 'DEP_FUSED2_BWD': '0'}, ['--load', '--load-phase', 'bwd']),   # longer bursts, with a co-scheduled kernel
     ('gru', 6, {'DEP_BWD_BURST': '4', 'DEP_NUM_CUS': '200'}, ['--H', '128']),
     ('gru', 6, {}, ['--H', '64']),                                # two members per tile
     ('gru', 4, {}, ['--H', '512', '--T', '100']),                 # sixteen members per tile, two chunks of 256 utterances
@@ -115,7 +116,7 @@ def test_per_layer_backward_sweeps_pass_the_kernel_parity_suite():
 def test_backward_burst_variants_pass_the_kernel_parity_suite(burst):
     """gru_bwd_cluster_r1<.., KB>: KB = 4 is the default; the round-1 schedule (0) and the longer bursts (6)
     stay parity-green -- the GRU part of the RNN-stack suite in a process with DEP_BWD_BURST set, against the oracle."""
-    e = dict(os.environ, DEP_BWD_BURST=burst)
+    e = dict(os.environ, DEP_BWD_BURST=burst, DEP_FUSED2_BWD='0')      # (the per-layer sweeps: the fused backward is the default since round 5)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -126,7 +127,18 @@ def test_backward_reduce_scatter_exchange_passes_the_kernel_parity_suite():
     """Round 5: gru_bwd_cluster_r1<.., AG = true> (all-gather of the members' gate gradients, column-sliced W_hh) is the default for
     H = 256; DEP_BWD_AG=0 selects the reduce-scatter of fp32 partial dh it replaced, which stays parity-green: the GRU part of the
     RNN-stack suite against the oracle."""
-    e = dict(os.environ, DEP_BWD_AG='0')
+    e = dict(os.environ, DEP_BWD_AG='0', DEP_FUSED2_BWD='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
+                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+
+
+def test_direct_fragment_forward_passes_the_kernel_parity_suite():
+    """Round 5: gru2_fwd_df (rnn_fused2.hip; the fused forward reading its exchanged h as MFMA fragments straight from the exchange buffer,
+    opt-in DEP_FWD_DF=1 -- measured slower than the gather form, profiles/r05_s8_*) stays parity-green: the GRU part of the RNN-stack
+    suite against the oracle."""
+    e = dict(os.environ, DEP_FWD_DF='1')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -13,7 +13,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CATS = (('gru2_fwd_fused', 'gru_fwd_sweep'), ('gru_fwd_cluster', 'gru_fwd_sweep'), ('gru_bwd_cluster', 'gru_bwd_sweep'),
+CATS = (('gru2_fwd_fused', 'gru_fwd_sweep'), ('gru2_fwd_df', 'gru_fwd_sweep'), ('gru_fwd_cluster', 'gru_fwd_sweep'), ('gru2_bwd_fused', 'gru_bwd_sweep'),
+        ('gru_bwd_cluster', 'gru_bwd_sweep'),
         ('lstm_fwd_cluster', 'lstm_fwd_sweep'), ('lstm_bwd_cluster', 'lstm_bwd_sweep'))
 
 
