@@ -48,7 +48,7 @@ constexpr int iarr_off(int a, bool sv16, bool hasdy) {
 // uses the CU's memory pipeline (a CU returns loads in issue order across its waves: an HBM request in flight holds every later L2 hit back).
 constexpr int pf_dist(bool sv16, bool hasdy) { return (sv16 && !hasdy) ? 2 : 1; }
 constexpr size_t fb_lds_bytes(bool sv16, bool hasdy, bool pk) {
-    return (size_t)(2 * N_RED + (pf_dist(sv16, hasdy) + 1) * ipar_floats(sv16, hasdy) + ((pk ? 3 : 2) * N_OBUF + 8 + 2) * IARR + 64) * sizeof(float);
+    return (size_t)(2 * N_RED + (pf_dist(sv16, hasdy) + 1) * ipar_floats(sv16, hasdy) + ((pk ? 3 : 2) * N_OBUF + 8 + 2) * IARR + 64 + 192) * sizeof(float);      // (+192: DEP_TRACE stamps)
 }
 
 struct FB {
@@ -67,6 +67,7 @@ struct FB {
     // input streams as buffer resources (LDS-DMA): per layer ONE base below its y / saved-gate arrays, the arrays as byte offsets from it
     const char* sb1; const char* sb0; unsigned sbytes1, sbytes0;
     unsigned o_sv1, o_y1, o_sv0, o_y0;                              // saved gates r (then z, n, hn at + k svstride floats), forward sequence
+    long long* trace;                                               // DEP_TRACE=1: stamps of workgroup 0 (tools/trace_fbwd.py), else nullptr
     int dbg;                                                        // timing experiments (DEP_FBWD_DBG; results are garbage): 1 = no input streams, 2 = no write-out
 };
 
@@ -78,7 +79,8 @@ struct FB {
 //   group 1     : nothing -- its input streams go HBM -> LDS directly (buffer_load ... lds), no staging registers (the first all-gather build
 //                 staged them in 20-24 VGPRs: 31-52 VGPR spills, weight fragments reloaded from scratch inside the MFMA chain)
 // The bias-gradient accumulators (8 more registers) live in LDS (dbl): one read-modify-write of four float2 per thread and step.
-template <bool DROP, bool HASDY, bool SV16, bool PK>
+#define BSTMP(slot) do { if (TRACE && trl && v >= 100 && v < 104) trl[(v - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+template <bool DROP, bool HASDY, bool SV16, bool PK, bool TRACE = false>
 __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     static_assert(!PK || SV16, "the PK write-out's third slot needs the LDS the 16-bit gates free");
     constexpr int IPAR = ipar_floats(SV16, HASDY), OSL = PK ? 3 : 2, PF = pf_dist(SV16, HASDY), ISL = PF + 1;
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     for (int i = 0; i < 4; ++i) st[i] = zero4();
     for (int i = tid; i < 8 * IARR; i += BTHREADS) dbl[i] = 0.f;
     if (tid == 0) *sig = 0u;
+    if (TRACE && tid < 192) reinterpret_cast<float*>(sig + 64)[tid] = 0.f;
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
     const unsigned par1 = (unsigned)p.nbtp * BNC * L1_MEMBER, par0 = (unsigned)p.nbtp * BNC * L0_MEMBER;      // bytes of one buffer
@@ -135,7 +138,24 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.sb0, 0, p.sbytes0, 0x00020000);
     __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, HASDY ? 0xfffffff0u : 0u, 0x00020000);
     typedef __attribute__((address_space(3))) void* ldsp;
-    auto stage = [&](int tv, int uu) {
+    // per-lane parts of the DMA addresses (row of the utterance's step 0, the member's columns, the swizzled piece): computed BEFORE the issue
+    // signal is awaited -- behind it only the requests themselves remain.  [0]: 16-bit arrays (lane -> row lane / 4), [1], [2]: the two row
+    // halves of an fp32 array (lane -> row 8 hh + lane / 8).  The step's time index travels in the scalar offset.
+    auto stage_prep = [&](int tv, unsigned (&vo)[3]) {
+        const int ln = tv & 63;
+        { const int row = ln >> 2; int b = b0t + row; b = b < p.B ? b : p.B - 1;
+          vo[0] = ((unsigned)b * (unsigned)T * BH + (unsigned)c * 32u) * 2u + (unsigned)(((ln & 3) ^ ((row >> 1) & 3)) * 16); }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int row = hh * 8 + (ln >> 3); int b = b0t + row; b = b < p.B ? b : p.B - 1;
+            vo[1 + hh] = ((unsigned)b * (unsigned)T * BH + (unsigned)c * 32u) * 4u + (unsigned)(((ln & 7) ^ (row & 7)) * 16);
+        }
+    };
+    // (GW = this wave's index as a compile-time value: the instruction list of a wave is then straight-line code.  Walking all 14-16 candidate
+    // slots with a wave-uniform test each cost ~400 scalar instructions per step -- 1200 ticks on a SIMD that three MFMA-issuing waves share --
+    // and this group is the one the step's barrier waits for.)
+    auto stage_w = [&](auto GW, int tv, int uu, const unsigned (&vo)[3]) {
+        constexpr int gwc = decltype(GW)::value;
         constexpr int N1 = HASDY ? 6 : 5, NA = N1 + 5;
         const int ln = tv & 63;
         const int t1 = T - 1 - uu, t0 = T + 1 - uu;
@@ -149,22 +169,28 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             const bool on = (l1 ? t1 >= 0 : (uu >= 2 && t0 >= 0)) && t >= 0;
 #pragma unroll
             for (int hh = 0; hh < (g16 ? 1 : 2); ++hh, ++q) {
-                if ((q & 3) != gw) continue;              // wave-uniform
+                if ((q & 3) != gwc) continue;             // compile-time
                 float* dst = ibuf + (uu % ISL) * IPAR + iarr_off(a, SV16, HASDY) + hh * 256;
                 if (on && !(p.dbg & 1)) {
-                    const int row = g16 ? (ln >> 2) : hh * 8 + (ln >> 3);
-                    int b = b0t + row; b = b < p.B ? b : p.B - 1;
-                    const unsigned e = ((unsigned)b * (unsigned)T + (unsigned)t) * BH + (unsigned)c * 32u;      // first element of the member's 32
-                    const unsigned vo = g16 ? e * 2u + (unsigned)(((ln & 3) ^ ((row >> 1) & 3)) * 16) : e * 4u + (unsigned)(((ln & 7) ^ (row & 7)) * 16);
-                    const unsigned so = k < 4 ? (l1 ? p.o_sv1 : p.o_sv0) + (unsigned)k * p.svstride * 4u : (k == 4 ? (l1 ? p.o_y1 : p.o_y0) : 0u);
+                    const unsigned so = (k < 4 ? (l1 ? p.o_sv1 : p.o_sv0) + (unsigned)k * p.svstride * 4u : (k == 4 ? (l1 ? p.o_y1 : p.o_y0) : 0u))
+                                        + (unsigned)t * (g16 ? BH * 2u : BH * 4u);
+                    const unsigned v_ = g16 ? vo[0] : vo[1 + hh];
                     // aux 2 = nt: one-touch streams must not displace the exchange buffer from this XCD's L2
-                    if (k == 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (ldsp)dst, 16, vo, 0, 0, 2);
-                    else if (l1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ldsp)dst, 16, vo, so, 0, 2);
-                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ldsp)dst, 16, vo, so, 0, 2);
+                    if (k == 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (ldsp)dst, 16, v_, so, 0, 2);
+                    else if (l1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (ldsp)dst, 16, v_, so, 0, 2);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (ldsp)dst, 16, v_, so, 0, 2);
                 } else {
                     *reinterpret_cast<f32x4*>(dst + ln * 4) = zero4();
                 }
             }
+        }
+    };
+    auto stage = [&](int tv, int uu, const unsigned (&vo)[3]) {
+        switch (gw) {
+            case 0: stage_w(std::integral_constant<int, 0>{}, tv, uu, vo); break;
+            case 1: stage_w(std::integral_constant<int, 1>{}, tv, uu, vo); break;
+            case 2: stage_w(std::integral_constant<int, 2>{}, tv, uu, vo); break;
+            default: stage_w(std::integral_constant<int, 3>{}, tv, uu, vo); break;
         }
     };
     // an input pair of the gate threads: utterance row j, units (ul, ul+1) -> swizzled float offset inside an array
@@ -191,27 +217,33 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     // per column, row t_even + 1 the residual pairs -- exactly what the GEMM staging's split would form (rnn_cluster_bwd.hip svc_flush_pk)
     __amdgpu_buffer_rsrc_t rso1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgi1, 0, (unsigned)((size_t)p.B * T * 4 * BH * 4), 0x00020000);
     __amdgpu_buffer_rsrc_t rso0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgi0, 0, (unsigned)((size_t)p.B * T * 4 * BH * 4), 0x00020000);
-    auto flush_pk = [&](int tv, int ua) {
+    struct PkOut { u32x4 h[4], l[4]; unsigned go[4]; unsigned on; };
+    auto flush_pk_prep = [&](int tv, int ua, PkOut& o) {      // LDS reads + the (hi, lo) split: no memory traffic, done while the issue signal is awaited
         const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
-        if (b0t + su >= p.B) return;
+        o.on = 0u;
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
             const int a = pr * 2 + shalf;                 // 0..3 layer 1 (dr, dz, dn, dn*r), 4..7 layer 0
             const bool l1 = a < 4;
             const int k = a & 3;
-            const bool on = l1 ? (ua + 1 <= T - 1) : (ua >= 2);
+            const bool on = (b0t + su < p.B) && (l1 ? (ua + 1 <= T - 1) : (ua >= 2));
             const int te = l1 ? T - 2 - ua : T - ua;      // the even row of the pair = the LATER step's time index
-            if (on) {
-                const int so_ = su * 32 + ((sqd ^ (su & 7)) << 2);
-                const f32x4 xo = ld4(obuf + ((ua % 3) * N_OBUF + a) * IARR + so_);            // step ua     = row te + 1
-                const f32x4 xe = ld4(obuf + (((ua + 1) % 3) * N_OBUF + a) * IARR + so_);      // step ua + 1 = row te
-                u32x4 h, l;
+            const int so_ = su * 32 + ((sqd ^ (su & 7)) << 2);
+            const f32x4 xo = ld4(obuf + ((ua % 3) * N_OBUF + a) * IARR + so_);            // step ua     = row te + 1
+            const f32x4 xe = ld4(obuf + (((ua + 1) % 3) * N_OBUF + a) * IARR + so_);      // step ua + 1 = row te
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { unsigned hh, ll; split_pair(xe[e], xo[e], hh, ll); h[e] = hh; l[e] = ll; }
-                const unsigned go = (((unsigned)(b0t + su) * (unsigned)T + (unsigned)te) * 4u * BH + (unsigned)k * BH + (unsigned)c * 32u + (unsigned)sqd * 4u) * 4u;
-                if (l1) { __builtin_amdgcn_raw_buffer_store_b128(h, rso1, go, 0, 2 /* nt */); __builtin_amdgcn_raw_buffer_store_b128(l, rso1, go + 4u * BH * 4u, 0, 2); }
-                else { __builtin_amdgcn_raw_buffer_store_b128(h, rso0, go, 0, 2 /* nt */); __builtin_amdgcn_raw_buffer_store_b128(l, rso0, go + 4u * BH * 4u, 0, 2); }
-            }
+            for (int e = 0; e < 4; ++e) { unsigned hh, ll; split_pair(xe[e], xo[e], hh, ll); o.h[pr][e] = hh; o.l[pr][e] = ll; }
+            o.go[pr] = (((unsigned)(b0t + su) * (unsigned)T + (unsigned)te) * 4u * BH + (unsigned)k * BH + (unsigned)c * 32u + (unsigned)sqd * 4u) * 4u;
+            o.on |= on ? (1u << pr) : 0u;
+            __builtin_amdgcn_sched_barrier(0);            // one array at a time: all eight LDS reads in flight at once cost 32 registers this kernel does not have
+        }
+    };
+    auto flush_pk_issue = [&](const PkOut& o) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            if (!((o.on >> pr) & 1u)) continue;
+            if (pr * 2 + shalf < 4) { __builtin_amdgcn_raw_buffer_store_b128(o.h[pr], rso1, o.go[pr], 0, 2 /* nt */); __builtin_amdgcn_raw_buffer_store_b128(o.l[pr], rso1, o.go[pr] + 4u * BH * 4u, 0, 2); }
+            else { __builtin_amdgcn_raw_buffer_store_b128(o.h[pr], rso0, o.go[pr], 0, 2 /* nt */); __builtin_amdgcn_raw_buffer_store_b128(o.l[pr], rso0, o.go[pr] + 4u * BH * 4u, 0, 2); }
         }
     };
     {   // initial recurrent gradient (dh_n) and the pooling gradient of the top layer
@@ -223,8 +255,11 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             if (grp == 0 && p.dpooled) { const float2 v = ld2(p.dpooled + (size_t)b * BH + col); st[0][2] = v.x * p.pool_scale; st[0][3] = v.y * p.pool_scale; }
         }
     }
-    if (grp == 1) { stage(tid, 0); if (PF == 2) stage(tid, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (grp == 1) { unsigned vo0[3]; stage_prep(tid, vo0); stage(tid, 0, vo0); if (PF == 2) stage(tid, 1, vo0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
+    // debug stamps (DEP_TRACE=1): thread 0 (group 0), 256 (group 1), 512 (group 2) of workgroup 0, fused steps 100..103, buffered behind sig
+    long long* trl = nullptr;
+    if (TRACE && p.trace && blockIdx.x == 0 && (tid & 255) == 0) trl = reinterpret_cast<long long*>(sig + 64) + grp * 32;
 
     for (int v = 0; v <= T + 1; ++v) {
         int tv = tid;
@@ -234,6 +269,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;       // utterance row, unit pair (ul, ul+1) of the member's 32
         const bool act = grp == 0 ? (v <= T - 1) : (grp == 2 ? (v >= 2) : false);      // gate-gradient role: layer 1 at t = T-1-v, layer 0 at t = T+1-v
         const unsigned epoch = (unsigned)v + 1u;
+        BSTMP(0);
         // ---- gate gradients (groups 0 and 2; identical code, role-dependent LDS bases), published at once
         if (act) {
             constexpr int GA = gate_arr(SV16);
@@ -289,8 +325,10 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             }
         }
         if (v == T + 1) { bar_lds(); break; }             // layer 0's last step (t = 0): nothing left to exchange
+        BSTMP(1);
         if (grp != 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's words are acknowledged
+            BSTMP(2);
             if (act && lane == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
         }
         // (prefetch distance 2: the inputs of step v+1 and the last write-out were requested late in step v-1 and had this group's whole idle time to land)
@@ -303,6 +341,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             // barrier -- but group 0 does not gather at layer 1's LAST step: group 1 always checks the flags itself, one round trip off the
             // critical path)
             if (!wait_flags((grp == 2 ? tflags0 : tflags1) + 8 * gw, 8, grp == 1 ? epoch - 1u : epoch, p.status, 7)) return;
+            BSTMP(3);
             const unsigned mb = grp == 2 ? L0_MEMBER : L1_MEMBER;
             const unsigned src0 = (grp == 2 ? p.l0_off + (unsigned)(v & 1) * par0 : (unsigned)((grp == 0 ? v : v - 1) % 3) * par1)
                                   + (unsigned)(bt * BNC + 2 * gw) * mb + (unsigned)lane * 16u;
@@ -333,23 +372,17 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             }
             float* rw = red + ((((v & 1) * 3 + grp) * 4 + gw) * 2) * 256 + lane * 4;
             *reinterpret_cast<f32x4*>(rw) = acc[0]; *reinterpret_cast<f32x4*>(rw + 256) = acc[1];
+            BSTMP(4);
         }
         else if (grp != 1 && lane == 0) sig_raise(sig);               // (no product this step: nothing of this wave will be in the queue)
         if (grp == 1) {
             // group 1's HBM streams: next inputs by DMA, then the finished gate gradients.  They go out once the eight critical waves of this
             // member have ISSUED their last fragment requests (an LDS counter: no memory traffic to watch it): an HBM access in the CU's queue
             // holds back every load issued behind it for its whole round trip.  With prefetch distance 2 they then land in the next step's gate
-            // phase; with distance 1 they must land before this step's barrier.
+            // phase; with distance 1 they must land before this step's barrier.  Everything that can be prepared -- the mask draw, the write-out's
+            // LDS reads and (hi, lo) split, the DMA addresses -- happens BEFORE the signal is awaited (the phase trace showed this group as the
+            // step's long pole: 1400-2600 ticks of issue work behind a signal that came 3500-4000 ticks into the step).
             __builtin_amdgcn_sched_barrier(0);
-            {
-                const unsigned want = 8u * ((unsigned)v + 1u);
-                for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
-            }
-            stage(tv, v + PF);
-            if (!(p.dbg & 2)) {
-                if constexpr (PK) { if (v >= 2 && !(v & 1)) flush_pk(tv, v - 2); }
-                else { if (v >= 1) flush(tv, v - 1); }
-            }
             if constexpr (DROP) {
                 // the dropout mask of the dy0 this step ends with (t = T - v; same Philox draw as the forward's mask of y0): ~150 VALU
                 // instructions that have no business on the gate threads' chain -- two of this group's waves draw the member's 128 blocks
@@ -359,9 +392,37 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
                     *reinterpret_cast<f32x4*>(mbuf + (v & 1) * IARR + su * 32 + ((sqd ^ (su & 7)) << 2)) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
                 }
             }
+            unsigned vo[3];
+            stage_prep(tv, vo);
+            auto wait_signal = [&]() {
+                const unsigned want = 8u * ((unsigned)v + 1u);
+                for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
+            };
+            bool pk_done = false;
+            if constexpr (PK) {
+                if (v >= 2 && !(v & 1) && !(p.dbg & 2)) {         // two separate code paths: the prepared write-out's 36 registers live only in this one
+                    PkOut po;
+                    flush_pk_prep(tv, v - 2, po);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wait_signal();
+                    BSTMP(5);
+                    stage(tv, v + PF, vo);
+                    flush_pk_issue(po);
+                    pk_done = true;
+                }
+            }
+            if (!pk_done) {
+                __builtin_amdgcn_sched_barrier(0);
+                wait_signal();
+                BSTMP(5);
+                stage(tv, v + PF, vo);
+                if constexpr (!PK) { if (!(p.dbg & 2) && v >= 1) flush(tv, v - 1); }
+            }
         }
         if (PF == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // distance 1: the DMA'd inputs of step v+1 must be in LDS at this barrier
+        BSTMP(6);
         bar_lds();                                        // the step's ONE barrier: partials in red, next step's inputs in ibuf, this step's write-out read
+        BSTMP(7);
         // ---- K-quarter sums (fixed order: deterministic)
         if (grp != 1) {
             const float* rr = red + (v & 1) * N_RED + (jl * 64 + (lp >> 4) * 16 + j) * 4 + 2 * half;      // own pair inside a wave's two accumulator tiles
@@ -389,8 +450,9 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             }
         }
     }
+    if (TRACE && trl) { long long* o = p.trace + grp * 32; for (int i = 0; i < 32; ++i) o[i] = trl[i]; }
     if (grp == 1) {                                       // layer 0's last two steps (t = 1, 0) are still in LDS
-        if constexpr (PK) flush_pk(tid, T);
+        if constexpr (PK) { PkOut po; flush_pk_prep(tid, T, po); flush_pk_issue(po); }
         else { flush(tid, T); flush(tid, T + 1); }
     }
     if (grp != 1) {
@@ -442,6 +504,7 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
     p.status = (unsigned*)xbuf; p.flags1 = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.flags0 = (unsigned*)(hdr_base(xbuf, 1) + FLAG_OFF);
     p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.nofast = nofast_env();
+    p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DEP_FBWD_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     {   // the input streams' buffer resources: per layer one base below its arrays, 32-bit offsets
         const size_t arr = (size_t)a.B * a.T * BH * sizeof(float);
@@ -463,6 +526,8 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
 #define FB_ATTR(D, Y, S, P) (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<D, Y, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(S, Y, P))
 #define FB_ATTR4(S, P) FB_ATTR(true, true, S, P); FB_ATTR(true, false, S, P); FB_ATTR(false, true, S, P); FB_ATTR(false, false, S, P)
         FB_ATTR4(false, false); FB_ATTR4(true, false); FB_ATTR4(true, true);
+        (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<true, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(true, false, true));
+        (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(true, false, true));
 #undef FB_ATTR4
 #undef FB_ATTR
         attr = true;
@@ -481,7 +546,11 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
 #define FB_GO(D, Y, S, P) hipLaunchKernelGGL((gru2_bwd_fused<D, Y, S, P>), grid, blk, fb_lds_bytes(S, Y, P), a.stream, p)
 #define FB_GO4(S, P) do { if (drop) { if (a.dy) FB_GO(true, true, S, P); else FB_GO(true, false, S, P); } \
                           else      { if (a.dy) FB_GO(false, true, S, P); else FB_GO(false, false, S, P); } } while (0)
-        if (pk) FB_GO4(true, true); else if (sv16) FB_GO4(true, false); else FB_GO4(false, false);
+        if (p.trace && pk && !a.dy) {                 // DEP_TRACE=1: the stamped variant (tools/trace_fbwd.py)
+            if (drop) hipLaunchKernelGGL((gru2_bwd_fused<true, false, true, true, true>), grid, blk, fb_lds_bytes(true, false, true), a.stream, p);
+            else hipLaunchKernelGGL((gru2_bwd_fused<false, false, true, true, true>), grid, blk, fb_lds_bytes(true, false, true), a.stream, p);
+        }
+        else if (pk) FB_GO4(true, true); else if (sv16) FB_GO4(true, false); else FB_GO4(false, false);
 #undef FB_GO4
 #undef FB_GO
         DEP_CHECK_LAUNCH();
