@@ -356,7 +356,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl)
                         gfr[g][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + (g == 2 ? g2 : (unsigned)g * 2048u) + (unsigned)pl * 1024u, 0, 16 /* sc1: served by L2 */);
-                if (rd == 1 && grp != 1 && lane == 0) sig_raise(sig);       // this critical wave's last requests are in the CU's queue
+                if (rd == 1 && grp != 1 && lane == 0) sig_raise(sig);       // this critical wave's last requests are in the CU's queue (raised after the FIRST round instead: +6 %, the second round then queues behind the streams)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {

@@ -4,7 +4,7 @@
 out=${1:-gpurun_out/soak.txt}
 {
 echo "# tests/stress_handoff.py on the final kernels (one MI355X, full-size stacks: B=512, T=300 unless noted; every iteration bit for bit against the"
-echo "# first one (--two-refs: or against the fallback path's reference), status word read after every step).  Round 4 kernels: PK gate gradients,"
+echo "# first one (--two-refs: or against the fallback path's reference), status word read after every step).  Round 5 kernels: fused all-gather backward, paired dW launch, PK gate gradients,"
 echo "# 16-bit saved gates (GRU), non-temporal streams, straight-line forward write-out."
 run() { note=$1; shift; python tests/stress_handoff.py "$@" 2>/dev/null | grep '^{' | tail -1 | python -c "
 import json,sys
