@@ -26,7 +26,7 @@ torch.cuda.synchronize()
 off = L.load().dep_rnn_workspace_xbuf_offset(C.byref(rnn.desc))
 tr = rnn.workspace[(off + 6400) // 4:(off + 6400) // 4 + 64].view(torch.int64).cpu().numpy().reshape(4, 8)
 names = ['gate grads + LDS + barrier', 'prefetch issue + MFMA', 'payload stores + drain', 'barrier + flag', 'poll', 'gather + sum']
-if os.environ.get('DEP_BWD_AG', '0') == '1':      # the all-gather step (rnn_cluster_bwd.hip, AG): one barrier, at the end
+if os.environ.get('DEP_BWD_AG', '1') != '0':      # the all-gather step (default since round 5) (rnn_cluster_bwd.hip, AG): one barrier, at the end
     names = ['ring read + gate grads + publish issue', 'publish acknowledged', 'flag + mask draw', 'poll (2 source members)',
              '12 fragment loads + 36 MFMAs + red write', 'barrier + K-quarter sum']
 for s in range(4):
