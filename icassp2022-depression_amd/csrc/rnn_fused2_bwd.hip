@@ -68,6 +68,7 @@ struct FB {
     const char* sb1; const char* sb0; unsigned sbytes1, sbytes0;
     unsigned o_sv1, o_y1, o_sv0, o_y0;                              // saved gates r (then z, n, hn at + k svstride floats), forward sequence
     long long* trace;                                               // DEP_TRACE=1: stamps of workgroup 0 (tools/trace_fbwd.py), else nullptr
+    int pktop;                                                      // 1: pair write-out at the top of the step (default), 0: behind the issue signal (DEP_FBWD_PKTOP)
     int dbg;                                                        // timing experiments (DEP_FBWD_DBG; results are garbage): 1 = no input streams, 2 = no write-out
 };
 
@@ -333,6 +334,15 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         }
         // (prefetch distance 2: the inputs of step v+1 and the last write-out were requested late in step v-1 and had this group's whole idle time to land)
         if (PF == 2 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PK) {
+            // The pair write-out (32 KB per member every other step) goes out HERE, at the top of the step, not behind the issue signal: the
+            // critical waves are in their gate phase (LDS only) for the next ~1300 ticks, and this group's own fragment requests queue behind its
+            // stores for a round trip it can afford (its product is due at the step's barrier, ~5000 ticks away).  Behind the signal the request
+            // queue pushed back for ~2000 ticks on every even step while the critical waves stood at the barrier (profiles/r05_final_trace_bwd.txt).
+            if (grp == 1 && v >= 2 && !(v & 1) && !(p.dbg & 2) && p.pktop) { PkOut po; flush_pk_prep(tv, v - 2, po); flush_pk_issue(po); }
+        }
+        // (The DMA REQUESTS at the top of the step as well -- distance 1, no signal -- measured 1.06 -> 1.27 ms: HBM loads in the CU's queue hold back the
+        // critical waves' polls and fragment loads for their whole round trip; posted stores do not.)
         // ---- the group's product: K quarter gw (source members 2gw, 2gw+1) x own 32 columns
         //   group 0: layer 1, step v (needed while a layer-1 step follows) ; group 1: layer 1, step v-1 ; group 2: layer 0, step v
         const bool mact = grp == 0 ? (v <= T - 2) : (grp == 1 ? (v >= 1 && v <= T) : (v >= 2 && v <= T));
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             };
             bool pk_done = false;
             if constexpr (PK) {
-                if (v >= 2 && !(v & 1) && !(p.dbg & 2)) {         // two separate code paths: the prepared write-out's 36 registers live only in this one
+                if (v >= 2 && !(v & 1) && !(p.dbg & 2) && !p.pktop) {         // two separate code paths: the prepared write-out's 36 registers live only in this one
                     PkOut po;
                     flush_pk_prep(tv, v - 2, po);
                     __builtin_amdgcn_sched_barrier(0);
@@ -505,6 +515,7 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
     p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.nofast = nofast_env();
     p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
+    { static int pt = -1; if (pt < 0) { const char* e = getenv("DEP_FBWD_PKTOP"); pt = (e && e[0] == '0') ? 0 : 1; } p.pktop = pt; }
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DEP_FBWD_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     {   // the input streams' buffer resources: per layer one base below its arrays, 32-bit offsets
         const size_t arr = (size_t)a.B * a.T * BH * sizeof(float);
