@@ -539,7 +539,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     // per-layer loop below with the sweep launches and layer 1's dX GEMM left out.  DEP_FUSED2_BWD=1 / 0.
     static int fused_bwd_on = -1;
     if (fused_bwd_on < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fused_bwd_on = e ? ((e[0] == '1') ? 1 : 0) : DEP_FUSED2_BWD_DEFAULT; }
-    const bool fused = lo.fused2 && fused_bwd_on && sweep_split_mode() && !lo.bf16st && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && L == 2 && D == 1;
+    const bool fused = lo.fused2 && fused_bwd_on && sweep_split_mode() && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && L == 2 && D == 1;
     static int pk_env = -1;
     if (pk_env < 0) { const char* e = getenv("DEP_DGI_PK"); pk_env = (e && e[0] == '0') ? 0 : 1; }
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -573,7 +573,11 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         f.dghn1 = lo.dg4 ? f.dgi1 + 3 * H : W + lo.dghn; f.dghn0 = lo.dg4 ? f.dgi0 + 3 * H : W + lo.dghn2;
         f.lddg = lo.dg4 ? 4 * H : 3 * H; f.lddghn = lo.dg4 ? 4 * H : H;
         f.dbpart1 = W + lo.dbpart; f.dbpart0 = W + lo.dbpart2; f.dbpart_rows = lo.nwg; f.stream = s;
-        f.sv16 = sv16 ? 1 : 0; f.dg_pk = fused_pk ? 1 : 0;
+        if (lo.bf16st && !fused_pk) {
+            dep_set_error("dep_rnn_backward: bf16-storage mode needs the pre-split gate-gradient path (aligned operands, DEP_DGI_PK not 0, contractions above the split threshold)");
+            return DEP_ERR_ARG;
+        }
+        f.sv16 = sv16 ? 1 : 0; f.dg_pk = fused_pk ? 1 : 0; f.bf16st = lo.bf16st ? 1 : 0;
         rc = dep_launch_fused2_bwd(f, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
     }
     float* pending_ptr = nullptr; long pending_n = 0;      // data parallel: a finished layer's gradient range waiting for the next sweep to be enqueued

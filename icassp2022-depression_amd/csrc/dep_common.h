@@ -229,6 +229,7 @@ struct dep_fused2_bwd_args {
     float* dgi1; float* dghn1; float* dgi0; float* dghn0; float* dbpart1; float* dbpart0; int dbpart_rows;
     int lddg, lddghn;        // row strides of dgi / dghn: 3H / H, or 4H / 4H with dghn = dgi + 3H (one (B*T, 4H) array [dr | dz | dn | dn*r] per layer)
     int sv16;                // saved gates r, z, n are 16-bit fixed point (must match the forward that wrote them)
+    int bf16st;              // bf16-storage mode (dep_set_gemm_mode(3)): y and hn are bf16 arrays, the gate gradients the PKH image (needs sv16 and dg_pk)
     int dg_pk;               // dgi1 / dgi0 are (B*T, 4H) arrays [dr | dz | dn | dn*r] written as the PK image of gemm_bf16x3.hip (needs sv16, T even); dghn unused
     hipStream_t stream;
 };

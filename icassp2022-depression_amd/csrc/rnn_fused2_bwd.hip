@@ -35,20 +35,23 @@ constexpr int IARR = BT * 32;                 // an fp32 INPUT array in LDS: [16
 // SV16: the saved gates r, z, n arrive as 16-bit fixed point (rnn_cluster_common.h): half-size arrays, ONE DMA instruction each, decoded by the gate threads.
 // PK: the gate gradients leave as the 4H-wide PK image of gemm_bf16x3.hip ((hi, lo) bf16 pairs of two consecutive steps in two rows): a third write-out
 // slot, flushed every other step.
+// BF (bf16-storage mode, dep_set_gemm_mode(3); implies SV16 and PK): hn and the hidden sequences are bf16 arrays too (half-size in LDS, one DMA instruction
+// each, decoded by the gate threads), and only the hi rows of the PK image are written (PKH).
 constexpr int gate_arr(bool sv16) { return sv16 ? IARR / 2 : IARR; }
-constexpr int ipar_floats(bool sv16, bool hasdy) { return 2 * 3 * gate_arr(sv16) + IARR * ((hasdy ? 3 : 2) + 2); }     // floats of one step parity of ibuf
-// float offset of input array a (l1: r, z, n, hn, hp, [dy] ; l0: r, z, n, hn, hp) inside a parity
-constexpr int iarr_off(int a, bool sv16, bool hasdy) {
-    const int n1 = hasdy ? 6 : 5, l1sz = 3 * gate_arr(sv16) + IARR * (hasdy ? 3 : 2);
+constexpr int hid_arr(bool bf) { return bf ? IARR / 2 : IARR; }
+constexpr int ipar_floats(bool sv16, bool hasdy, bool bf = false) { return 2 * (3 * gate_arr(sv16) + 2 * hid_arr(bf)) + (hasdy ? IARR : 0); }     // floats of one step slot of ibuf
+// float offset of input array a (l1: r, z, n, hn, hp, [dy] ; l0: r, z, n, hn, hp) inside a slot
+constexpr int iarr_off(int a, bool sv16, bool hasdy, bool bf = false) {
+    const int n1 = hasdy ? 6 : 5, l1sz = 3 * gate_arr(sv16) + 2 * hid_arr(bf) + (hasdy ? IARR : 0);
     const int k = a < n1 ? a : a - n1;
-    return (a < n1 ? 0 : l1sz) + (k < 3 ? k * gate_arr(sv16) : 3 * gate_arr(sv16) + (k - 3) * IARR);
+    return (a < n1 ? 0 : l1sz) + (k < 3 ? k * gate_arr(sv16) : 3 * gate_arr(sv16) + (k - 3 < 2 ? (k - 3) * hid_arr(bf) : 2 * hid_arr(bf)));
 }
 // Prefetch distance of the input streams (fused steps): 2 where the LDS has room for a third input slot (16-bit gates, no external dy) -- the DMA
 // requests then go out AFTER the step's critical fragment loads were issued and land during the NEXT step's gate phase, when nothing latency-critical
 // uses the CU's memory pipeline (a CU returns loads in issue order across its waves: an HBM request in flight holds every later L2 hit back).
 constexpr int pf_dist(bool sv16, bool hasdy) { return (sv16 && !hasdy) ? 2 : 1; }
-constexpr size_t fb_lds_bytes(bool sv16, bool hasdy, bool pk) {
-    return (size_t)(2 * N_RED + (pf_dist(sv16, hasdy) + 1) * ipar_floats(sv16, hasdy) + ((pk ? 3 : 2) * N_OBUF + 8 + 2) * IARR + 64 + 192) * sizeof(float);      // (+192: DEP_TRACE stamps)
+constexpr size_t fb_lds_bytes(bool sv16, bool hasdy, bool pk, bool bf = false) {
+    return (size_t)(2 * N_RED + (pf_dist(sv16, hasdy) + 1) * ipar_floats(sv16, hasdy, bf) + ((pk ? 3 : 2) * N_OBUF + 8 + 2) * IARR + 64 + 192) * sizeof(float);      // (+192: DEP_TRACE stamps)
 }
 
 struct FB {
@@ -81,10 +84,11 @@ struct FB {
 //                 staged them in 20-24 VGPRs: 31-52 VGPR spills, weight fragments reloaded from scratch inside the MFMA chain)
 // The bias-gradient accumulators (8 more registers) live in LDS (dbl): one read-modify-write of four float2 per thread and step.
 #define BSTMP(slot) do { if (TRACE && trl && v >= 100 && v < 104) trl[(v - 100) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
-template <bool DROP, bool HASDY, bool SV16, bool PK, bool TRACE = false>
+template <bool DROP, bool HASDY, bool SV16, bool PK, bool TRACE = false, bool BF = false>
 __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
     static_assert(!PK || SV16, "the PK write-out's third slot needs the LDS the 16-bit gates free");
-    constexpr int IPAR = ipar_floats(SV16, HASDY), OSL = PK ? 3 : 2, PF = pf_dist(SV16, HASDY), ISL = PF + 1;
+    static_assert(!BF || (SV16 && PK), "bf16 storage: 16-bit gates, PKH image");
+    constexpr int IPAR = ipar_floats(SV16, HASDY, BF), OSL = PK ? 3 : 2, PF = pf_dist(SV16, HASDY), ISL = PF + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T;
     const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
@@ -165,13 +169,13 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         for (int a = 0; a < NA; ++a) {
             const bool l1 = a < N1;
             const int k = l1 ? a : a - N1;                // 0..3 saved gates, 4 h_{t-1}, 5 dy (layer 1 only)
-            const bool g16 = SV16 && k < 3;               // a 16-bit array: 16 rows x 64 bytes = ONE instruction (lane -> row lane / 4, piece lane % 4)
+            const bool g16 = (SV16 && k < 3) || (BF && (k == 3 || k == 4));      // a 16-bit array: 16 rows x 64 bytes = ONE instruction (lane -> row lane / 4, piece lane % 4)
             const int t = (l1 ? t1 : t0) - (k == 4 ? 1 : 0);
             const bool on = (l1 ? t1 >= 0 : (uu >= 2 && t0 >= 0)) && t >= 0;
 #pragma unroll
             for (int hh = 0; hh < (g16 ? 1 : 2); ++hh, ++q) {
                 if ((q & 3) != gwc) continue;             // compile-time
-                float* dst = ibuf + (uu % ISL) * IPAR + iarr_off(a, SV16, HASDY) + hh * 256;
+                float* dst = ibuf + (uu % ISL) * IPAR + iarr_off(a, SV16, HASDY, BF) + hh * 256;
                 if (on && !(p.dbg & 1)) {
                     const unsigned so = (k < 4 ? (l1 ? p.o_sv1 : p.o_sv0) + (unsigned)k * p.svstride * 4u : (k == 4 ? (l1 ? p.o_y1 : p.o_y0) : 0u))
                                         + (unsigned)t * (g16 ? BH * 2u : BH * 4u);
@@ -243,8 +247,8 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
             if (!((o.on >> pr) & 1u)) continue;
-            if (pr * 2 + shalf < 4) { __builtin_amdgcn_raw_buffer_store_b128(o.h[pr], rso1, o.go[pr], 0, 2 /* nt */); __builtin_amdgcn_raw_buffer_store_b128(o.l[pr], rso1, o.go[pr] + 4u * BH * 4u, 0, 2); }
-            else { __builtin_amdgcn_raw_buffer_store_b128(o.h[pr], rso0, o.go[pr], 0, 2 /* nt */); __builtin_amdgcn_raw_buffer_store_b128(o.l[pr], rso0, o.go[pr] + 4u * BH * 4u, 0, 2); }
+            if (pr * 2 + shalf < 4) { __builtin_amdgcn_raw_buffer_store_b128(o.h[pr], rso1, o.go[pr], 0, 2 /* nt */); if constexpr (!BF) __builtin_amdgcn_raw_buffer_store_b128(o.l[pr], rso1, o.go[pr] + 4u * BH * 4u, 0, 2); }
+            else { __builtin_amdgcn_raw_buffer_store_b128(o.h[pr], rso0, o.go[pr], 0, 2 /* nt */); if constexpr (!BF) __builtin_amdgcn_raw_buffer_store_b128(o.l[pr], rso0, o.go[pr] + 4u * BH * 4u, 0, 2); }
         }
     };
     {   // initial recurrent gradient (dh_n) and the pooling gradient of the top layer
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
         // ---- gate gradients (groups 0 and 2; identical code, role-dependent LDS bases), published at once
         if (act) {
             constexpr int GA = gate_arr(SV16);
-            const float* il = ibuf + (v % ISL) * IPAR + (grp == 0 ? 0 : iarr_off(HASDY ? 6 : 5, SV16, HASDY));      // this layer's arrays: r, z, n | hn, hp, [dy]
+            const float* il = ibuf + (v % ISL) * IPAR + (grp == 0 ? 0 : iarr_off(HASDY ? 6 : 5, SV16, HASDY, BF));      // this layer's arrays: r, z, n | hn, hp, [dy]
             float2 r, z, n;
             if constexpr (SV16) {
                 const unsigned* iw = reinterpret_cast<const unsigned*>(il) + iswz16(j, ul);
@@ -283,11 +287,18 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
                 const float* ig = il + iswz(j, ul);
                 r = ld2(ig); z = ld2(ig + GA); n = ld2(ig + 2 * GA);
             }
-            const float* ib = il + 3 * GA + iswz(j, ul);
-            const float2 hn = ld2(ib), hp = ld2(ib + IARR);
+            float2 hn, hp;
+            if constexpr (BF) {                           // bf16 pairs: the value sits in the upper half of its fp32
+                const unsigned* ih = reinterpret_cast<const unsigned*>(il + 3 * GA) + iswz16(j, ul);
+                const unsigned w0 = ih[0], w1 = ih[hid_arr(true)];
+                hn = f2(__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)); hp = f2(__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u));
+            } else {
+                const float* ib = il + 3 * GA + iswz(j, ul);
+                hn = ld2(ib); hp = ld2(ib + IARR);
+            }
             float2 dyv = f2(0.f, 0.f);
             if (grp == 2) dyv = f2(st[3][0], st[3][1]);   // layer 0: masked gradient from layer 1
-            if (HASDY && grp == 0) dyv = ld2(ib + 2 * IARR);
+            if (HASDY && grp == 0) dyv = ld2(il + 3 * GA + 2 * hid_arr(BF) + iswz(j, ul));
             const float2 d = f2(st[0][0] + st[0][2] + dyv.x, st[0][1] + st[0][3] + dyv.y);
             float2 dn, dz, dr, dnr;
             dn.x = d.x * (1.0f - z.x) * (1.0f - n.x * n.x); dn.y = d.y * (1.0f - z.y) * (1.0f - n.y * n.y);
@@ -530,13 +541,17 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
         DEP_CHECK_ARG(span(a.y1, a.sv1, p.sb1, p.sbytes1, p.o_y1, p.o_sv1) && span(a.y0, a.sv0, p.sb0, p.sbytes0, p.o_y0, p.o_sv0));
         DEP_CHECK_ARG(arr < 0xfffffff0ull);           // (an external dy is addressed from its own base)
     }
-    const bool sv16 = a.sv16 != 0, pk = a.dg_pk != 0;
+    const bool sv16 = a.sv16 != 0, pk = a.dg_pk != 0, bf = a.bf16st != 0;
+    DEP_CHECK_ARG(!bf || (sv16 && pk));               // bf16-storage mode: 16-bit gates, PKH image
     DEP_CHECK_ARG(!pk || (sv16 && a.T % 2 == 0 && (size_t)a.B * a.T * 4 * BH * 4 < 0xfffffff0ull));      // PK: 16-bit gates (LDS), whole step pairs, 32-bit offsets into the image
     static bool attr = false;
     if (!attr) {
 #define FB_ATTR(D, Y, S, P) (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<D, Y, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(S, Y, P))
 #define FB_ATTR4(S, P) FB_ATTR(true, true, S, P); FB_ATTR(true, false, S, P); FB_ATTR(false, true, S, P); FB_ATTR(false, false, S, P)
         FB_ATTR4(false, false); FB_ATTR4(true, false); FB_ATTR4(true, true);
+#define FB_ATTRB(D, Y) (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<D, Y, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(true, Y, true, true))
+        FB_ATTRB(true, true); FB_ATTRB(true, false); FB_ATTRB(false, true); FB_ATTRB(false, false);
+#undef FB_ATTRB
         (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<true, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(true, false, true));
         (void)hipFuncSetAttribute((const void*)gru2_bwd_fused<false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(true, false, true));
 #undef FB_ATTR4
@@ -557,7 +572,12 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
 #define FB_GO(D, Y, S, P) hipLaunchKernelGGL((gru2_bwd_fused<D, Y, S, P>), grid, blk, fb_lds_bytes(S, Y, P), a.stream, p)
 #define FB_GO4(S, P) do { if (drop) { if (a.dy) FB_GO(true, true, S, P); else FB_GO(true, false, S, P); } \
                           else      { if (a.dy) FB_GO(false, true, S, P); else FB_GO(false, false, S, P); } } while (0)
-        if (p.trace && pk && !a.dy) {                 // DEP_TRACE=1: the stamped variant (tools/trace_fbwd.py)
+        if (bf) {                                     // bf16-storage mode (never traced)
+#define FB_GOB(D, Y) hipLaunchKernelGGL((gru2_bwd_fused<D, Y, true, true, false, true>), grid, blk, fb_lds_bytes(true, Y, true, true), a.stream, p)
+            if (drop) { if (a.dy) FB_GOB(true, true); else FB_GOB(true, false); } else { if (a.dy) FB_GOB(false, true); else FB_GOB(false, false); }
+#undef FB_GOB
+        }
+        else if (p.trace && pk && !a.dy) {            // DEP_TRACE=1: the stamped variant (tools/trace_fbwd.py)
             if (drop) hipLaunchKernelGGL((gru2_bwd_fused<true, false, true, true, true>), grid, blk, fb_lds_bytes(true, false, true), a.stream, p);
             else hipLaunchKernelGGL((gru2_bwd_fused<false, false, true, true, true>), grid, blk, fb_lds_bytes(true, false, true), a.stream, p);
         }
