@@ -248,6 +248,9 @@ RNN_CASES = [
     ('gru', 2100, 3, 8, 64, 3),         # H = 64: chunks of 2048 + 52
     ('gru', 40, 6, 32, 512, 3),         # H = 512: sixteen members per tile (round-1 backward schedule: no room for service waves)
     ('gru', 300, 5, 16, 512, 3),        # H = 512: chunks of 256 + 44
+    # round 5: the fused two-layer all-gather backward (H = 256, default) at the edges of its pipeline: layer 0 runs two fused steps behind layer 1,
+    # the streaming group one; T = 2 / 3 / 4 (even T: PK write-out in step pairs, odd T: fp32 rows), a ragged tile and a single-step pair
+    ('gru', 5, 2, 8, 256, 3), ('gru', 20, 3, 8, 256, 3), ('gru', 33, 4, 16, 256, 3), ('gru', 17, 6, 256, 256, 3),
 ]
 
 
