@@ -491,7 +491,8 @@ constexpr int DF_RED = 12 * 6 * 256;          // floats: [wave][tile][gate][half
 constexpr int DF_GSL = 3;                     // slots of the staged layer-0 input projection (DMA two steps ahead)
 constexpr int DF_IARR = BT * 32;              // a DMA'd [16 utterances][32 units] fp32 array (unpadded, pieces XOR-swizzled by row)
 constexpr unsigned DF_MB0 = 4096, DF_MB1 = 2048;      // bytes per member: h0 planes (hi, lo) + masked h0 planes ; h1 planes
-constexpr size_t DF_LDS_BYTES = (size_t)(DF_RED + DF_GSL * 3 * DF_IARR + F_OBUF + F_BIAS + 2 * F_MBUF + 64) * sizeof(float);
+constexpr int DF_RED2 = 4 * 6 * 256;          // group 2's partials exist twice (written in one gate phase, read in the next)
+constexpr size_t DF_LDS_BYTES = (size_t)(DF_RED + DF_RED2 + DF_GSL * 3 * DF_IARR + F_OBUF + F_BIAS + 2 * F_MBUF + 64) * sizeof(float);
 
 struct FD {
     FF f;
@@ -518,7 +519,8 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_df(FD pd) {
     const int grp = w >> 2, kq = w & 3;
     const int shalf = kq >> 1;                        // group 2: which array / gate of a pair this wave streams
     float* red = smem;
-    float* gbuf = red + DF_RED;                       // [3 slots][gate][16][32, swizzled]: layer-0 input projection of step s in slot s % 3
+    float* gbuf = red + DF_RED + DF_RED2;             // [3 slots][gate][16][32, swizzled]: layer-0 input projection of step s in slot s % 3
+    float* red2b = red + DF_RED;                      // second copy of group 2's four waves' partials (parity 1; parity 0 = their slots inside red)
     float* obuf = gbuf + DF_GSL * 3 * DF_IARR;        // per layer 6 slots: h, r, z, n, hn, dropout(h) (layer 0 only) -- as gru2_fwd_fused
     float* bias_l = obuf + F_OBUF;
     float* mbuf = bias_l + F_BIAS;                    // [2 parities][16][36]: dropout mask values of step s in slot s & 1
@@ -609,13 +611,17 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_df(FD pd) {
             }
         }
     };
-    if (grp == 2) { stage_gi(tid, 0); stage_gi(tid, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (grp == 2) { stage_gi(tid, 0); stage_gi(tid, 1); stage_gi(tid, 2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     if (DROP && grp == 2 && shalf == 1) {             // the mask of step 0
         const int rem = tid & 127, su = rem >> 3, sqd = rem & 7;
         const size_t o = ((size_t)(b0t + su) * T + 0) * FH + c * 32 + sqd * 4;
         *reinterpret_cast<f32x4*>(mbuf + su * OROW + sqd * 4) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
     }
     __syncthreads();
+    // Group 2 runs ONE BARRIER out of phase with groups 0 / 1 (it passes one extra barrier here and one fewer at the end, as in gru2_fwd_fused):
+    // its product -- the same code site as theirs -- then falls into THEIR gate phase, when the matrix pipes are idle (all twelve waves multiplying
+    // at once is 108 MFMAs per SIMD in one phase: the first build's 6300-tick step), and its stream slot beside their product phase.
+    if (grp == 2) bar_lds();
 
     for (int s = 0; s <= T + 1; ++s) {
         int tv = tid;
@@ -624,11 +630,9 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_df(FD pd) {
         const int lt = tv & 255, jl = lt >> 7, lp = (lt >> 1) & 63, half = lt & 1;
         const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;       // gate threads: utterance row, unit pair (ul, ul+1) of the member's 32
         // ---- the group's product.  group 0: W_hh(l0) h0_{s-1} (layer-0 step s) ; group 1: W_hh(l1) h1_{s-3} (layer-1 step s-2) ;
-        //      group 2: W_ih(l1) dropout(h0_{s-2}) (the input projection of layer-1 step s-2)
-        // (group 2: what it requested a step ago -- the write-out of step s-2, the projection of step s+1 -- had its whole idle time to complete)
-        if (grp == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const bool ract = grp == 0 ? (s < T) : (s >= 2);                       // the role has a step to work for
-        const bool mact = grp == 0 ? (s >= 1 && s < T) : (grp == 1 ? s >= 3 : s >= 2);      // ... and a non-zero operand
+        //      group 2 (in the others' gate phase of step s): W_ih(l1) dropout(h0_{s-1}) = the input projection of layer-1 step s-1, consumed in step s+1
+        const bool ract = grp == 0 ? (s < T) : (grp == 1 ? s >= 2 : (s >= 1 && s <= T));      // the role has a step to work for
+        const bool mact = grp == 0 ? (s >= 1 && s < T) : (grp == 1 ? s >= 3 : ract);          // ... and a non-zero operand
         if (ract) {
             f32x4 acc[2][3];
 #pragma unroll
@@ -638,10 +642,10 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_df(FD pd) {
                     acc[i][g] = (kq == 0 && !(DROP && grp == 2)) ? ld4(bias_l + grp * 96 + g * 32 + i * 16 + (lane >> 4) * 4) : zero4();
             if (mact) {
                 // source block: h0 of step s-1 (group 0) / the masked h0 of step s-2 (group 2) / h1 of layer-1 step s-3, published in fused step s-1
-                const unsigned need = grp == 2 ? (unsigned)s - 1u : (unsigned)s;
+                const unsigned need = (unsigned)s;        // h0_{s-1} / h1 of layer-1 step s-3: both published in fused step s-1
                 if (!wait_flags((grp == 1 ? tflags1 : tflags0) + 8 * kq, 8, need, p.status, 6, p.soft)) return;
                 const unsigned src = (grp == 1 ? pd.off_h1 + (unsigned)((s - 1) & 1) * par1 + (unsigned)(bt * FNC + 2 * kq) * DF_MB1
-                                               : (unsigned)((grp == 0 ? s - 1 : s - 2) % 3) * par0 + (unsigned)(bt * FNC + 2 * kq) * DF_MB0 + ((DROP && grp == 2) ? 2048u : 0u))
+                                               : (unsigned)((s - 1) % 3) * par0 + (unsigned)(bt * FNC + 2 * kq) * DF_MB0 + ((DROP && grp == 2) ? 2048u : 0u))
                                      + (unsigned)lane * 16u;
                 const unsigned mst = grp == 1 ? DF_MB1 : DF_MB0;
                 u32x4 hf[2][2];
@@ -680,22 +684,18 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_df(FD pd) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    float* rb = red + ((w * 2 + i) * 3 + g) * 256 + lane * 2;
+                    float* rb = ((grp == 2 && (s & 1)) ? red2b + ((kq * 2 + i) * 3 + g) * 256 : red + ((w * 2 + i) * 3 + g) * 256) + lane * 2;
                     st2(rb, f2(acc[i][g][0], acc[i][g][1])); st2(rb + 128, f2(acc[i][g][2], acc[i][g][3]));
                 }
         } else if (grp != 2 && lane == 0) sig_raise(sig);
-        if (grp == 2) {
-            // the member's HBM streams, once its eight critical waves have issued their fragment requests: the results of step s-1
-            // (obuf is complete since barrier 2 of that step and is overwritten after barrier 1 of this one), then the projection two steps ahead
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const unsigned want = 8u * ((unsigned)s + 1u);
-                for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
-            }
-            if (!(pd.dbg & 2)) { if (s >= 1) flush(tv, s - 1); }
-            if (!(pd.dbg & 1)) stage_gi(tv, s + 2);       // (waited for at the top of the next step; first read behind barrier 1 of step s+2)
+        if (DROP && grp == 2 && shalf == 1 && s + 1 < T) {
+            // layer 0's dropout mask of step s+1 (two of this group's waves draw the member's 128 blocks), into the other parity
+            const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
+            const size_t o = ((size_t)(b0t + su) * T + (s + 1)) * FH + c * 32 + sqd * 4;
+            *reinterpret_cast<f32x4*>(mbuf + ((s + 1) & 1) * F_MBUF + su * OROW + sqd * 4) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
         }
-        bar_lds();                                        // barrier 1: partials in red
+        bar_lds();                                        // groups 0 / 1: barrier 1 (partials in red) | group 2: barrier 2 of step s
+        if (grp == 2 && s == T + 1) break;                // (its one barrier fewer)
         // ---- gate math (groups 0 and 1), h published at once
         const bool gact = grp == 0 ? (s < T) : (grp == 1 && s >= 2);
         if (gact) {
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_df(FD pd) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) gi[g] = add2(gi[g], ld2(red + (((8 + q4) * 2 + jl) * 3 + g) * 256 + e2));
+                    for (int g = 0; g < 3; ++g) gi[g] = add2(gi[g], ld2((((s - 1) & 1) ? red2b + ((q4 * 2 + jl) * 3 + g) * 256 : red + (((8 + q4) * 2 + jl) * 3 + g) * 256) + e2));      // written in the previous step's gate phase
             }
             float2 mk = f2(1.f, 1.f);
             if (DROP && grp == 0) mk = ld2(mbuf + (s & 1) * F_MBUF + j * OROW + ul);       // this step's mask values (0 or the scale), drawn by group 2
@@ -770,13 +770,19 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_df(FD pd) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's words are acknowledged
             if (lane == 0 && (grp == 0 || s <= T)) { if (fast) st_local(myflag, (unsigned)s + 1u); else st_agent(myflag, (unsigned)s + 1u); }
         }
-        if (DROP && grp == 2 && shalf == 1 && s + 1 < T) {
-            // layer 0's dropout mask of step s+1 (two of this group's waves draw the member's 128 blocks), into the other parity
-            const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
-            const size_t o = ((size_t)(b0t + su) * T + (s + 1)) * FH + c * 32 + sqd * 4;
-            *reinterpret_cast<f32x4*>(mbuf + ((s + 1) & 1) * F_MBUF + su * OROW + sqd * 4) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+        if (grp == 2) {
+            // group 2's stream slot, beside the others' product phase of step s+1: the results of step s go out at once (posted stores disturb
+            // nobody: rnn_fused2_bwd.hip), the projection three steps ahead is requested once the eight critical waves of step s+1 have issued
+            // their fragment loads (an HBM load in the CU's queue holds back every load behind it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // last slot's requests have landed (the projection of step s+2 is read behind barrier 1 of that step)
+            if (!(pd.dbg & 2)) flush(tv, s);
+            {
+                const unsigned want = 8u * ((unsigned)s + 2u);
+                for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
+            }
+            if (!(pd.dbg & 1)) stage_gi(tv, s + 3);
         }
-        bar_lds();                                        // barrier 2: red may be rewritten, obuf is complete
+        bar_lds();                                        // groups 0 / 1: barrier 2 (red may be rewritten, obuf is complete) | group 2: barrier 1 of step s+1
     }
     if (grp == 2) flush(tid, T + 1);
     {
