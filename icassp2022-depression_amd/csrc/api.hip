@@ -682,7 +682,12 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
             rc = dep_multi_copy(D, src, nullptr, dst, cnt, s); if (rc) return rc;
         }
         bool paired = false;
-        if (pk_gru && !lo.bf16st && !stacked && D == 1 && Kl == H) {
+        // (the split-K target follows the layer's SHAPE, not whether the pair really runs: the fp32-row path (DEP_DGI_PK=0) and the unpaired path
+        // (DEP_DW_PAIR=0) must keep summing in the same order as the pair -- tests/test_presplit_gpu.py holds them bit-identical)
+        const bool pair_layer = d->cell == DEP_CELL_GRU && lo.dg4 && !stacked && D == 1 && Kl == H;
+        const bool pair_shape = pair_layer && pk_gru && !lo.bf16st;
+        struct SplitGuard { bool on; SplitGuard(bool o) : on(o) { if (on) dep_gemm_set_split_target(512); } ~SplitGuard() { if (on) dep_gemm_set_split_target(0); } } split_guard(pair_layer);
+        if (pair_shape) {
             // Round 5: dW_ih and dW_hh of this layer in ONE launch -- both read the PK gate gradients, [dr | dz] are the same bytes
             // (gemm_bf16x3_tn_pair; bit-identical to the two calls below, which remain the path for every other configuration)
             float* const* gl = dweights + (size_t)l * 4;

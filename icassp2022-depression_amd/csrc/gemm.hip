@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void gemm_small(SmallP p) {
     }
 }
 
+thread_local long g_split_target_override = 0;      // dep_gemm_set_split_target: per calling thread, 0 = the default / DEP_GEMM_SPLIT_TARGET
 int choose_splits(int M, int N, int K) {
     const long tiles = (long)dep_cdiv(M, BM) * dep_cdiv(N, BN);
     if (tiles >= 256 || K < 1024) return 1;
@@ -294,12 +295,19 @@ int choose_splits(int M, int N, int K) {
     // 384 -> 0.306 ms, 516 -> 0.366 ms)
     static long target = -1;
     if (target < 0) { const char* e = getenv("DEP_GEMM_SPLIT_TARGET"); target = e ? atol(e) : 1024; }
-    long s = target / tiles;
+    long s = (g_split_target_override > 0 ? g_split_target_override : target) / tiles;
     const long maxs = K / 256;
     if (s > maxs) s = maxs;
     if (s > 128) s = 128;
     return s < 1 ? 1 : (int)s;
 }
+
+}  // namespace
+// Split-K target of the calling thread's next contractions, in 128x128 tile-chunks (0 = default).  Round 5: a layer whose dW_ih and dW_hh run as
+// ONE paired launch asks for 512: the pair then fills the persistent grid in one round (2 x 252 tile-jobs on 512 slots) with half the partial-sum
+// traffic; the single launches want 1024.  Set for both paths of such a layer, so that DEP_DW_PAIR=0 stays bit-identical to the pair.
+void dep_gemm_set_split_target(long target) { g_split_target_override = target; }
+namespace {
 
 bool naive_forced() {
     static int v = -1;
