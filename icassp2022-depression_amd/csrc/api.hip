@@ -539,7 +539,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     // per-layer loop below with the sweep launches and layer 1's dX GEMM left out.  DEP_FUSED2_BWD=1 / 0.
     static int fused_bwd_on = -1;
     if (fused_bwd_on < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fused_bwd_on = e ? ((e[0] == '1') ? 1 : 0) : DEP_FUSED2_BWD_DEFAULT; }
-    const bool fused = lo.fused2 && fused_bwd_on && sweep_split_mode() && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && L == 2 && D == 1;
+    const bool fused = lo.fused2 && fused_bwd_on && sweep_split_mode() && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && L == 2 && D == 1 && dep_fused2_bwd_fits(B, T);
     static int pk_env = -1;
     if (pk_env < 0) { const char* e = getenv("DEP_DGI_PK"); pk_env = (e && e[0] == '0') ? 0 : 1; }
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };

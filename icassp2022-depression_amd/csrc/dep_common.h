@@ -235,6 +235,7 @@ struct dep_fused2_bwd_args {
     hipStream_t stream;
 };
 size_t dep_fused2_bwd_xbuf_bytes(int B);
+bool dep_fused2_bwd_fits(int B, int T);       // 32-bit offsets into a layer's arrays: else the per-layer sweeps
 int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_bytes);
 // comm.hip: all-reduce of [buf, buf+n) on comm_stream after everything enqueued so far on `compute`
 int dep_comm_enqueue_after(dep_comm* c, float* buf, long n, hipStream_t compute, hipStream_t comm_stream);

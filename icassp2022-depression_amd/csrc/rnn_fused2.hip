@@ -856,7 +856,7 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     static int df = -1;
     if (df < 0) { const char* e = getenv("DEP_FWD_DF"); df = e ? (e[0] == '1' ? 1 : 0) : DEP_FWD_DF_DEFAULT; }
     // round 5: the direct-fragment form (gru2_fwd_df).  Not with the phase trace (it has no stamps) nor with non-temporal write-out.
-    if (df && !p.trace && !p.ntstore) {
+    if (df && !p.trace && !p.ntstore && (size_t)a.B * a.T * p.ldgi * 4 < 0xfffffff0ull) {      // (32-bit offsets into the projection)
         static_assert(DEP_HDR_SLOTS >= 4, "the direct-fragment forward keeps h1's flags in header slot 3 (slots 1, 2: the fallback sweeps)");
         static bool attr_d = false;
         if (!attr_d) {

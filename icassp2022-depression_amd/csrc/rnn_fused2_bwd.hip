@@ -501,6 +501,10 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
 
 }  // namespace
 
+// The fused backward addresses a layer's input arrays (y, dropped y, r, z, n, hn: one stride apart in the reserve) and its 4H-wide gate-gradient image
+// through 32-bit buffer offsets: larger batches take the per-layer sweeps (tile-relative resources) instead.
+bool dep_fused2_bwd_fits(int B, int T) { return (size_t)B * T * BH * sizeof(float) * 8 < 0xfffffff0ull; }
+
 size_t dep_fused2_bwd_xbuf_bytes(int B) {
     const int CH = dep_cluster_chunk(BNC, 1, 256);
     const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
