@@ -159,7 +159,8 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
                 if (b1 > gb) gb = b1;
             }
     }
-    if (d->cell == DEP_CELL_GRU && d->dirs == 1 && d->training) {      // dW_ih + dW_hh of a layer as one launch (dep_gemm_tn_pair): two sets of partials
+    if (d->training && ((d->cell == DEP_CELL_GRU && d->dirs == 1) || (d->cell == DEP_CELL_LSTM && d->dirs == 2))) {
+        // dW_ih + dW_hh of a GRU layer / dW_hh of both directions of a BiLSTM layer as one launch (dep_gemm_tn_pair): two sets of partials
         const size_t b2 = 2 * dep_gemm_workspace_bytes(1, 0, (int)(G * H), (int)H, (int)lo.BT);
         if (b2 > gb) gb = b2;
     }
@@ -691,11 +692,21 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
             // Round 5: dW_ih and dW_hh of this layer in ONE launch -- both read the PK gate gradients, [dr | dz] are the same bytes
             // (gemm_bf16x3_tn_pair; bit-identical to the two calls below, which remain the path for every other configuration)
             float* const* gl = dweights + (size_t)l * 4;
-            const int pr = dep_gemm_tn_pair(G * H, H, BTr, dgi, ldg, 2 * H, H, in, Kl, R + lo.y[l], H, T, -1, gl[0], Kl, gl[1], H, gws, gwsb, s);
+            const int pr = dep_gemm_tn_pair(G * H, H, BTr, dgi, dgi, ldg, 2 * H, H, in, Kl, 0, 0, R + lo.y[l], H, T, -1, gl[0], Kl, gl[1], H, gws, gwsb, s);
             if (pr < 0) return pr;
             paired = pr == 1;
         }
-        for (int dd = 0; dd < D && !paired; ++dd) {
+        bool paired_hh = false;
+        if (pk_lstm && stacked && D == 2) {
+            // Round 5: dW_hh of the two directions of a BiLSTM layer (4H x H each: 254 tile-jobs, half of the persistent grid) as ONE paired launch;
+            // tiles, K chunks and split-K order per direction are those of the single launches (bit-identical)
+            float* const* gf = dweights + (size_t)(l * D) * 4; float* const* gb = dweights + (size_t)(l * D + 1) * 4;
+            const int pr = dep_gemm_tn_pair(G * H, H, BTr, dgi, dgi + (size_t)G * H, ldg, 0, 0, R + lo.y[l], D * H, T, -1, R + lo.y[l] + H, D * H, T, 1,
+                                            gf[1], H, gb[1], H, gws, gwsb, s);
+            if (pr < 0) return pr;
+            paired_hh = pr == 1;
+        }
+        for (int dd = 0; dd < D && !paired && !paired_hh; ++dd) {
             float* const* gl = dweights + (size_t)(l * D + dd) * 4;
             const float* dg = dgi + (size_t)dd * G * H;
             // dW_ih (G*H, Kl) = dG^T * in

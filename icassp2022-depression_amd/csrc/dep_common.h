@@ -99,6 +99,14 @@ bool dep_gemm_pk_pending();
 // true when dep_gemm_internal would run the bf16x3 kernel for a contraction of this size (it is the one that honours the skip)
 bool dep_gemm_uses_bf16x3(int M, int N, int K, int seq_T);
 void dep_gemm_set_split_target(long target);      // split-K target of this thread's next contractions (0 = default); gemm.hip
+// two TN contractions of equal shape over PK A operands in one launch (gemm.hip): 1 = enqueued, 0 = not covered, < 0 = error
+int dep_gemm_tn_pair(int M, int N, int K, const float* A0, const float* A1, int lda, int skip_at1, int skip_by1,
+                     const float* B0, int ldb0, int seq_T0, int shift0, const float* B1, int ldb1, int seq_T1, int shift1,
+                     float* C0, int ldc0, float* C1, int ldc1, void* ws, size_t ws_bytes, hipStream_t s);
+int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A0, const float* A1, int lda, int skip_at1, int skip_by1,
+                                   const float* B0, int ldb0, int seq_T0, int shift0, const float* B1, int ldb1, int seq_T1, int shift1,
+                                   float* C0, int ldc0, float* C1, int ldc1, int splits, int kchunk, float* part0, float* part1, hipStream_t s);
+void dep_gemm_set_split_target(long target);      // split-K target of this thread's next contractions (0 = default); gemm.hip
 // dW_ih + dW_hh of a GRU layer in one launch (shared PK A operand; gemm.hip): 1 = enqueued, 0 = not covered, < 0 = error
 int dep_gemm_tn_pair(int M, int N, int K, const float* A, int lda, int skip_at1, int skip_by1, const float* B0, int ldb0,
                      const float* B1, int ldb1, int seq_T1, int shift1, float* C0, int ldc0, float* C1, int ldc1,

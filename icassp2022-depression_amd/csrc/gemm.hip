@@ -426,20 +426,22 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     return DEP_OK;
 }
 
-// Two weight-gradient contractions of a GRU layer that share their A operand (the PK gate-gradient image), one launch:
-//   C0 (M x N) = A^T B0            C1 (M x N) = A'^T shift(B1)      (A' = A through the column skip; dW_ih and dW_hh)
+// Two weight-gradient contractions of equal shape in one launch (A operands: the PK gate-gradient image):
+//   C0 (M x N) = A0^T shift0(B0)      C1 (M x N) = A1'^T shift1(B1)      (A' = A through the column skip)
+// GRU layer: dW_ih and dW_hh (A1 = A0: the shared [dr | dz] columns are fetched once); BiLSTM layer: dW_hh of the two directions (each alone fills
+// only half of the persistent grid).
 // Returns 1 when the pair was enqueued, 0 when this configuration is not covered (the caller then issues the two calls itself), < 0 on error.
 // Split count, K chunks and summation order per problem are those dep_gemm_internal would use: bit-identical results.
-int dep_gemm_tn_pair(int M, int N, int K, const float* A, int lda, int skip_at1, int skip_by1, const float* B0, int ldb0,
-                     const float* B1, int ldb1, int seq_T1, int shift1, float* C0, int ldc0, float* C1, int ldc1,
-                     void* ws, size_t ws_bytes, hipStream_t s) {
+int dep_gemm_tn_pair(int M, int N, int K, const float* A0, const float* A1, int lda, int skip_at1, int skip_by1,
+                     const float* B0, int ldb0, int seq_T0, int shift0, const float* B1, int ldb1, int seq_T1, int shift1,
+                     float* C0, int ldc0, float* C1, int ldc1, void* ws, size_t ws_bytes, hipStream_t s) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("DEP_DW_PAIR"); on = (e && e[0] == '0') ? 0 : 1; }
     init_split_mode();
     if (!on || naive_forced() || g_force_exact != 0 || g_split_mode != 1 || (long)M * N * K < g_split_min_macs || M < 512 || dep_gemm_predicate()) return 0;
     if (!dep_gemm_pk_pending()) return 0;
     auto a16 = [](const void* q, int ld) { return ((uintptr_t)q % 16 == 0) && (ld % 4 == 0); };
-    if (!(a16(A, lda) && a16(B0, ldb0) && a16(B1, ldb1) && M % 4 == 0 && N % 4 == 0)) return 0;
+    if (!(a16(A0, lda) && a16(A1, lda) && a16(B0, ldb0) && a16(B1, ldb1) && M % 4 == 0 && N % 4 == 0)) return 0;
     int splits = choose_splits(M, N, K);
     if (splits <= 1 || !ws) return 0;
     const size_t one = dep_align((size_t)splits * M * N * sizeof(float));
@@ -447,8 +449,8 @@ int dep_gemm_tn_pair(int M, int N, int K, const float* A, int lda, int skip_at1,
     const int kchunk = dep_cdiv(dep_cdiv(K, splits), BK) * BK;
     splits = dep_cdiv(K, kchunk);
     DepProfScope prof(DEP_PROF_GEMM_TN, s, true);
-    const int rc = dep_gemm_bf16x3_tn_pair_launch(M, N, K, A, lda, skip_at1, skip_by1, B0, ldb0, B1, ldb1, seq_T1, shift1, C0, ldc0, C1, ldc1,
-                                                  splits, kchunk, (float*)ws, (float*)((char*)ws + one), s);
+    const int rc = dep_gemm_bf16x3_tn_pair_launch(M, N, K, A0, A1, lda, skip_at1, skip_by1, B0, ldb0, seq_T0, shift0, B1, ldb1, seq_T1, shift1,
+                                                  C0, ldc0, C1, ldc1, splits, kchunk, (float*)ws, (float*)((char*)ws + one), s);
     return rc == DEP_OK ? 1 : rc;
 }
 

@@ -896,16 +896,16 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
 // dW_ih + dW_hh of one GRU layer in one launch (gemm_bf16x3_tn_pair above).  A = the sweep's PK gate-gradient image for both (problem 1
 // reads it through the column skip), B0 = the layer's input, B1 = the layer's own output shifted one step; same (M, N, K, splits, kchunk).
 // The caller (dep_gemm_tn_pair, gemm.hip) has checked formats / alignment / sizes; returns DEP_OK after enqueueing both the walk and the reduce.
-int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A, int lda, int skip_at1, int skip_by1,
-                                   const float* B0, int ldb0, const float* B1, int ldb1, int seq_T1, int shift1,
+int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A0, const float* A1, int lda, int skip_at1, int skip_by1,
+                                   const float* B0, int ldb0, int seq_T0, int shift0, const float* B1, int ldb1, int seq_T1, int shift1,
                                    float* C0, int ldc0, float* C1, int ldc1, int splits, int kchunk, float* part0, float* part1, hipStream_t s) {
     DEP_CHECK_ARG(g_fmt_a == FMT_PK && g_fmt_b == FMT_F32 && M >= 512 && splits > 1 && part0 && part1);
     DEP_CHECK_ARG(K % 2 == 0 && kchunk % 2 == 0 && dep_gemm_predicate() == nullptr && g_xcd_lo == 0 && g_xcd_n == 8);
     static int persist = -1;
     if (persist < 0) { const char* e = getenv("DEP_GEMM_PERSIST"); persist = e ? atoi(e) : 768; if (persist < 8) persist = 8; persist = persist / 8 * 8; }
-    GemmP p0{M, N, K, A, lda, B0, ldb0, C0, ldc0, nullptr, 0.f, 0, 0, kchunk, splits, part0, dep_cdiv(N, BN), dep_cdiv(M, 256), 0, nullptr, 0, 8, 0, 0};
+    GemmP p0{M, N, K, A0, lda, B0, ldb0, C0, ldc0, nullptr, 0.f, seq_T0, shift0, kchunk, splits, part0, dep_cdiv(N, BN), dep_cdiv(M, 256), 0, nullptr, 0, 8, 0, 0};
     GemmP p1 = p0;
-    p1.B = B1; p1.ldb = ldb1; p1.C = C1; p1.ldc = ldc1; p1.seqT = seq_T1; p1.shiftB = shift1; p1.part = part1; p1.skip_at = skip_at1; p1.skip_by = skip_by1;
+    p1.A = A1; p1.B = B1; p1.ldb = ldb1; p1.C = C1; p1.ldc = ldc1; p1.seqT = seq_T1; p1.shiftB = shift1; p1.part = part1; p1.skip_at = skip_at1; p1.skip_by = skip_by1;
     const int ntiles = p0.gx * p0.gy * splits;
     const int cap = persist * 2 / 3 / 2;                          // two resident workgroups per CU with 256-row tiles, half of the slots per problem
     const int per_xcd = (ntiles + 7) / 8;
