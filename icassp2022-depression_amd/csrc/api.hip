@@ -685,7 +685,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         bool paired = false;
         // (the split-K target follows the layer's SHAPE, not whether the pair really runs: the fp32-row path (DEP_DGI_PK=0) and the unpaired path
         // (DEP_DW_PAIR=0) must keep summing in the same order as the pair -- tests/test_presplit_gpu.py holds them bit-identical)
-        const bool pair_layer = d->cell == DEP_CELL_GRU && lo.dg4 && !stacked && D == 1 && Kl == H;
+        const bool pair_layer = d->cell == DEP_CELL_GRU && lo.dg4 && !stacked && D == 1 && Kl == H && dep_get_gemm_mode() == 1 && sweep_split_mode();      // (the other precision modes never pair: they keep the single launches' target)
         const bool pair_shape = pair_layer && pk_gru && !lo.bf16st;
         struct SplitGuard { bool on; SplitGuard(bool o) : on(o) { if (on) dep_gemm_set_split_target(512); } ~SplitGuard() { if (on) dep_gemm_set_split_target(0); } } split_guard(pair_layer);
         if (pair_shape) {
