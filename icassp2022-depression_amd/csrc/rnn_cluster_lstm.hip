@@ -20,6 +20,8 @@ struct LF {
     float* svg; float* svc;                        // activated gates (B,T,dirs*4H), cell state (B,T,dirs*H); null in inference
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
     int nofast;
+    long long* trace;        // debug: shader-clock stamps of workgroup 0 (DEP_TRACE=1, tools/trace_lstm.py), else nullptr
+    int dbg;                 // DEP_LSTM_DBG (measurement only): bit 0 = the per-step write-out goes out behind the issue signal instead of at the top of the step
 };
 
 struct LB {
@@ -48,12 +50,30 @@ struct LB {
 // `ibuf') and write out h, dropout(h), the four activated gates and c of the last KB steps (LDS ring `obuf', KB+1 slots).
 constexpr int L_SVC = 256;
 constexpr int LROW = 36, LARR = 16 * LROW;           // LDS row stride / array size (floats) of ibuf / obuf
-constexpr size_t lstm_fwd_lds_floats(int H, int KB) { return (size_t)BT * (H + 8) + 4 * 4 * 64 * 4 + (KB ? KB * 4 * LARR + (KB + 1) * 7 * LARR : 0); }
+constexpr int LF_TRACE_F = 144;                      // floats behind the rings (burst kernels): 64 debug stamps, then the issue-signal word of DF = 2
+constexpr size_t lstm_fwd_lds_floats(int H, int KB, bool DF = false) {
+    return (DF ? (size_t)4096 : (size_t)BT * (H + 8) + 4 * 4 * 64 * 4) + (KB ? KB * 4 * LARR + (KB + 1) * 7 * LARR + LF_TRACE_F : 0);
+}
+// DF = 2: the direct-fragment sweep with PER-STEP streams instead of bursts.  The phase trace of DF = 1 (profiles/r05_s9_*) shows clean steps
+// of ~3600 ticks and a dirty step (every fourth) of 8000-9400: the burst -- 32 KB of loads and 56 KB of stores per member -- keeps the CU's
+// memory pipeline busy for more than a step, and the publish acknowledgement, the polls and the barrier of that step wait behind it.  With
+// one barrier per step and the fragment requests as the only loads on the chain, the streams can go out EVERY step where they hurt nothing
+// (rnn_fused2_bwd.hip's schedule): the write-out of step k-1 (14 KB of posted stores) at the top of step k, the input projection of step
+// k+2 (8 KB) once the four compute waves have their fragment requests in the queue (an LDS counter), landing in the ring a step later.
+// DF (round 5, after the GRU backward's all-gather form -- rnn_cluster_bwd.hip, AG): the forward's exchange always was an all-gather of
+// h_t; what changes is how it is read.  A member publishes h_t of its 32 units ONCE as the (hi, lo) bf16 words in the matrix cores'
+// B-fragment order ([plane][64 lanes][16 B] = 2 KB per member and step: lane (k-group u / 8, utterance j), word (u % 8) / 2), every
+// wave raises its OWN epoch flag as soon as its own two stores are acknowledged (no workgroup barrier in front of the flag), polls the
+// eight per-wave flags of the two source members of its K half and loads their four 1 KB fragment blocks straight into registers --
+// no copy into LDS planes, no unpacking, and ONE workgroup barrier per step (behind the K-half partial sums) instead of three.  The
+// products, their order and the sums are the ones of the LDS form: every output is bit-identical (tests/test_stress_gpu.py).
+constexpr int DF_MEMBER_BYTES = 2 * 1024;
 
 // SV16 (burst kernels only): the saved activated gates are 16-bit fixed point -- i, f, o in (0, 1) as unorm16, g in (-1, 1) as
 // snorm16 (rnn_cluster_common.h; same element positions inside the (B,T,dirs*4H) array, 2 bytes each); c stays fp32.
-template <int KCH, bool SPLIT, int KB, bool SV16 = false>      // k-chunks of 16 per wave = H/32
+template <int KCH, bool SPLIT, int KB, bool SV16 = false, int DF = 0>      // k-chunks of 16 per wave = H/32
 __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
+    static_assert(!DF || (SPLIT && KB == 4 && KCH == 4), "direct-fragment exchange: H = 128, split products, burst length 4");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
     const int LDHB = H + 8;                           // bf16 elements per row of a split plane
@@ -69,13 +89,16 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
     const int hs_floats = SPLIT ? BT * LDHB : BT * LDH;
     unsigned short* hs_hi = reinterpret_cast<unsigned short*>(smem);
     unsigned short* hs_lo = hs_hi + BT * LDHB;
-    float* red = smem + hs_floats;                    // [4 waves][4 gates][64][4]
+    float* red = DF ? smem : smem + hs_floats;        // [4 waves][4 gates][64][4]   (DF: [step parity][4 waves][4 gates][64][2], no planes)
     constexpr bool BURST = KB > 0;
     constexpr int KBX = BURST ? KB : 1;
-    float* ibuf = red + 4 * 4 * 64 * 4;               // [KB][4 gates][16][LROW]: input projection of step k in slot k % KB
+    float* ibuf = red + (DF ? 4096 : 4 * 4 * 64 * 4); // [KB][4 gates][16][LROW]: input projection of step k in slot k % KB
     float* obuf = ibuf + KBX * 4 * LARR;              // [KB+1][7][16][LROW]: h, dropout(h), i, f, g, o, c of step k in slot k % (KB+1)
+    long long* trl = reinterpret_cast<long long*>(obuf + (KBX + 1) * 7 * LARR);      // debug stamps (burst kernels; LF_TRACE_F floats)
+    unsigned* sig = reinterpret_cast<unsigned*>(trl) + 128;                          // DF = 2: fragment requests issued so far, all compute waves
+    if (DF == 2 && tid == 0) *sig = 0;               // (ordered by the prologue's __syncthreads)
     const bool svc = BURST && tid >= CT;              // wave-uniform
-    for (int i = tid; i < hs_floats; i += (BURST ? CT + L_SVC : CT)) hs[i] = 0.f;
+    if constexpr (!DF) for (int i = tid; i < hs_floats; i += (BURST ? CT + L_SVC : CT)) hs[i] = 0.f;
 
     constexpr int KS2 = KCH / 2;                      // 32-wide k-steps per wave (SPLIT)
     f32x4 wr[SPLIT ? 1 : 4][SPLIT ? 1 : KCH];
@@ -103,8 +126,8 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
     const size_t pstride = (size_t)p.dirs * p.nbtp * BT * H;
     const size_t tile_base = (size_t)cl * BT * H;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
-    unsigned* myflag = p.flags + cl * NC + c;
-    unsigned* tflags = p.flags + cl * NC;
+    unsigned* tflags = DF ? p.flags + cl * NC * 4 : p.flags + cl * NC;       // DF: one flag per compute wave
+    unsigned* myflag = DF ? tflags + c * 4 + (w & 3) : tflags + c;
     const int hshift = __ffs(H) - 1;
     const int ldsg = p.dirs * 4 * H, ldsc = p.dirs * H;
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + cl * NC, NC, c, p.status);
@@ -139,10 +162,10 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
                         sreg[d][1] = on ? nt_ld4(a_gi, src + 2 * H) : zero4();
                     }
             };
-            auto svc_put = [&](int k0, int n) {
+            auto svc_put = [&](int k0, int n, int dlo = 0) {
 #pragma unroll
                 for (int d = 0; d < KBX; ++d)
-                    if (d < n) {
+                    if (d >= dlo && d < n) {
                         float* dst = ibuf + ((k0 + d) % KBX) * 4 * LARR + (sodd ? LARR : 0) + sr * LROW + sp * 4;
                         *reinterpret_cast<f32x4*>(dst) = sreg[d][0];
                         *reinterpret_cast<f32x4*>(dst + 2 * LARR) = sreg[d][1];
@@ -172,6 +195,26 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
                     }
                 }
             };
+            if constexpr (DF == 2) {
+                // per-step streams (see above): one register set, one step in flight.  Iteration k, between barrier(k-1) and barrier(k):
+                // ring <- gi(k+1) (requested a step ago); write-out of step k-1; wait for the issue signal; request gi(k+2).
+                svc_issue(0, 1); svc_put(0, 1); svc_issue(1, 1);
+                __syncthreads();
+                for (int k = 0; k < T; ++k) {
+                    if (k + 1 < T) svc_put(k + 1, 1);
+                    if (k > 0 && !(p.dbg & 1)) svc_flush(k - 1, k);
+                    if (k + 2 < T) {
+                        const unsigned want = 4u * ((unsigned)k + 1u);
+                        // (a scheduling hint, not a dependency: give up after ~1 ms -- a compute wave that left on a raised status never raises it)
+                        for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (k > 0 && (p.dbg & 1)) svc_flush(k - 1, k);
+                    if (k + 2 < T) svc_issue(k + 2, 1);
+                    bar_lds();
+                }
+                svc_flush(T - 1, T);
+                return;
+            }
             svc_issue(0, KBX); svc_put(0, KBX);       // steps 0 .. KB-1 straight into the ring
             svc_issue(KBX, phi);                      // steps KB .. KB+phi-1: written at step phi-1, before the first dirty step (k = phi)
             __syncthreads();
@@ -179,12 +222,21 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
                 const int jj = (k + KBX - phi) % KBX, last = k - jj;
                 if (jj == 0) { svc_issue(k + KBX, KBX); svc_flush(k - KBX, k); }
                 bar_lds();                           // #1 (partial sums)
+                if constexpr (DF) {
+                    // ONE barrier per step, at its end; the compute waves read ring slot (k+1) % KB right behind barrier(k).  Step s may be
+                    // written between barrier(s - KB) and barrier(s - 1): of the burst requested at dirty step L the first KB-1 steps go in
+                    // behind barrier(L + KB - 2), the last one behind barrier(L + KB - 1) (rnn_cluster_bwd.hip, AG: same schedule).
+                    if (jj == KBX - 2 && last >= 0) svc_put(last + KBX, KBX - 1);
+                    if (jj == KBX - 1) { if (last >= 0) svc_put(last + KBX, KBX, KBX - 1); else svc_put(KBX, phi); }
+                    if (k == T - 1) break;
+                    continue;
+                }
                 if (k == T - 1) break;
                 bar_lds();                           // #2 (the compute waves' drain barrier): step k's ring slot is consumed
                 if (jj == KBX - 1) { if (last >= 0) svc_put(last + KBX, KBX); else svc_put(KBX, phi); }
                 bar_lds();                           // #3 (gathered h in LDS)
             }
-            __syncthreads();                          // the last step's results are in obuf
+            if constexpr (!DF) __syncthreads();       // the last step's results are in obuf (DF: behind barrier(T-1) already)
             svc_flush(T - 1 - (T - 1 + KBX - phi) % KBX, T);
             return;
         }
@@ -199,11 +251,121 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
     }
     if constexpr (!BURST) __syncthreads();            // (BURST: the barrier above, shared with the service waves' prologue)
 
+    // debug stamps (DEP_TRACE=1, tools/trace_lstm.py): workgroup 0, wave 0, steps 196 .. 199, buffered in LDS, copied out after the sweep
+    long long* trb = (BURST && p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
+#define LSTAMP(k_, slot) do { if (trb && (k_) >= 196 && (k_) < 200) trl[((k_) - 196) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+    if (trb) { for (int i = 0; i < 64; ++i) trl[i] = 0; trl[7] = (long long)__builtin_readcyclecounter(); }
+    if constexpr (DF) {
+        // ---- direct-fragment sweep (see DF_MEMBER_BYTES above).  Exchange buffer: [parity][cluster][member][plane][64 lanes][16 B]; this
+        // thread's pair (units ulc, ulc+1 of utterance j) is word `pw' of its member's two 1 KB blocks.
+        const int ulc = col - 32 * c;                 // = 16 jl + 4 q + 2 kh
+        const unsigned pw = (unsigned)((((ulc >> 3) * 16 + j) << 2) + ((ulc & 7) >> 1));
+        const unsigned par_bytes = (unsigned)p.dirs * p.nbtp * NC * DF_MEMBER_BYTES;
+        const unsigned pub0 = (unsigned)(cl * NC + c) * DF_MEMBER_BYTES + pw * 4;
+        const unsigned ld0 = (unsigned)(cl * NC + 2 * kh) * DF_MEMBER_BYTES + lane * 16;      // this wave's four blocks are contiguous: members 2kh, 2kh+1
+        unsigned* srcflags = tflags + 8 * kh;         // the eight per-wave flags of source members 2kh, 2kh+1
+        const bool khu = __builtin_amdgcn_readfirstlane(kh) != 0;
+        // inter-layer dropout of the output: the Philox draw of step k+1 is made behind step k's fragment requests (it depends on
+        // nothing but the position)
+        const bool masked = p.ydrop != nullptr;
+        auto draw = [&](int k) {
+            const size_t o = ((size_t)b * T + (dir ? T - 1 - k : k)) * p.ldy + dir * H + col;
+            const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+            return f2(kh ? m[2] : m[0], kh ? m[3] : m[1]);
+        };
+        float2 mk = masked ? draw(0) : f2(1.f, 1.f);
+        float2 rec[4] = {f2(0.f, 0.f), f2(0.f, 0.f), f2(0.f, 0.f), f2(0.f, 0.f)};      // W_hh h_{k-1} of this thread's pair (h_{-1} = 0)
+        for (int k = 0; k < T; ++k) {
+            const bool more = k + 1 < T;
+            LSTAMP(k, 0);
+            const float* ib = ibuf + (k % KBX) * 4 * LARR + j * LROW + ulc;
+            float2 tot[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const float2 gv = ld2(ib + g * LARR); tot[g] = f2(rec[g].x + gv.x, rec[g].y + gv.y); }
+            float2 ig, fg, gg, og, h;
+            ig.x = fast_sigmoid(tot[0].x); ig.y = fast_sigmoid(tot[0].y);
+            fg.x = fast_sigmoid(tot[1].x); fg.y = fast_sigmoid(tot[1].y);
+            gg.x = fast_tanh(tot[2].x); gg.y = fast_tanh(tot[2].y);
+            og.x = fast_sigmoid(tot[3].x); og.y = fast_sigmoid(tot[3].y);
+            cst.x = fg.x * cst.x + ig.x * gg.x; cst.y = fg.y * cst.y + ig.y * gg.y;
+            h.x = og.x * fast_tanh(cst.x); h.y = og.y * fast_tanh(cst.y);
+            hlast = h;
+            if (more) {       // publish first: the (hi, lo) pair words of h_k -- what every member's MFMAs read
+                unsigned hw, lw;
+                split_pair(h.x, h.y, hw, lw);
+                const unsigned po = (unsigned)(k & 1) * par_bytes + pub0;
+                if (fast) {   // same-XCD clusters: plain stores (that XCD's L2 is the coherence point)
+                    __builtin_amdgcn_raw_buffer_store_b32(hw, rsrc, po, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(lw, rsrc, po + 1024, 0, 0);
+                } else {      // write-through
+                    __builtin_amdgcn_raw_buffer_store_b32(hw, rsrc, po, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(lw, rsrc, po + 1024, 0, 16);
+                }
+            }
+            {
+                float* ob = obuf + (k % (KBX + 1)) * 7 * LARR + j * LROW + ulc;
+                st2(ob, h);
+                if (masked) st2(ob + LARR, f2(h.x * mk.x, h.y * mk.y));
+                if (p.svg) { st2(ob + 2 * LARR, ig); st2(ob + 3 * LARR, fg); st2(ob + 4 * LARR, gg); st2(ob + 5 * LARR, og); st2(ob + 6 * LARR, cst); }
+            }
+            LSTAMP(k, 1);
+            if (!more) { bar_lds(); break; }          // (the service waves' final flush reads obuf behind this barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's two stores are acknowledged
+            LSTAMP(k, 2);
+            const unsigned epoch = (unsigned)k + 1u;
+            if (lane == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+            LSTAMP(k, 3);
+            if (!wait_flags(srcflags, 8, epoch, p.status, 6)) return;
+            LSTAMP(k, 4);
+            const unsigned lo_ = (unsigned)(k & 1) * par_bytes + ld0;
+            u32x4 hfr[KS2][2];
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    hfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo_ + (unsigned)(ks * 2 + pl) * 1024, 0, 16 /* sc1: served by L2 */);
+            if (DF == 2 && lane == 0) sig_raise(sig); // this wave's requests are in the CU's queue: the service waves may issue theirs
+            __builtin_amdgcn_sched_barrier(0);        // all four requests first
+            if (masked) mk = draw(k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const bf16x8 hh = __builtin_bit_cast(bf16x8, hfr[ks][0]), hl = __builtin_bit_cast(bf16x8, hfr[ks][1]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[g][ks][0]), wl = __builtin_bit_cast(bf16x8, wq[g][ks][1]);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hl, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, hh, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hh, acc[g], 0, 0, 0);
+                }
+            }
+            // the partner wave (other K half, same tile) needs the two units this wave does NOT keep.  (khu: a SCALAR copy of kh -- with the
+            // per-lane value hipcc indexes the sixteen accumulator registers dynamically: 128 v_cmp / v_cndmask pairs, 1600 ticks a step)
+            float2 keep[4], send[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (khu) { keep[g] = f2(acc[g][2], acc[g][3]); send[g] = f2(acc[g][0], acc[g][1]); }
+                else     { keep[g] = f2(acc[g][0], acc[g][1]); send[g] = f2(acc[g][2], acc[g][3]); }
+            }
+            float* rw = red + (((k & 1) * 4 + w) * 4) * 128 + lane * 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) st2(rw + g * 128, send[g]);
+            LSTAMP(k, 5);
+            bar_lds();
+            const float* rr = red + (((k & 1) * 4 + (w ^ 1)) * 4) * 128 + lane * 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float2 pv = ld2(rr + g * 128);
+                rec[g] = f2(keep[g].x + pv.x, keep[g].y + pv.y);
+            }
+            LSTAMP(k, 6);
+        }
+    } else
     for (int s = 0; s < T; ++s) {
         const int t = dir ? (T - 1 - s) : s;
         const size_t row = (size_t)b * T + t;
         float2 gi[4];
         const bool more = s + 1 < T;
+        LSTAMP(s, 0);
         if constexpr (!BURST) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) gi[g] = gin[g];
@@ -248,6 +410,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(red + ((w * 4 + g) * 64 + lane) * 4) = acc[g];
+        LSTAMP(s, 1);
         bar_lds();
         const int ulc = col - 32 * c;                 // this lane's pair of units inside the member's 32
         if constexpr (BURST) {
@@ -278,9 +441,11 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
             gu64* dst = (gu64*)(p.payload + pbase + (size_t)j * H + col);
             if (fast) __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            LSTAMP(s, 2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+            LSTAMP(s, 3);
         }
         if constexpr (BURST) {
             float* ob = obuf + (s % (KBX + 1)) * 7 * LARR + j * LROW + ulc;
@@ -305,7 +470,9 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
             }
         }
         if (more) {
+            LSTAMP(s, 4);
             if (!wait_flags(tflags, NC, epoch, p.status, 6)) return;      // every wave polls: no verdict-broadcast barrier
+            LSTAMP(s, 5);
             constexpr int PER = KCH / 2;              // 16-byte pieces per thread = 16*H/4/256
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
@@ -324,10 +491,13 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
                 }
             }
             bar_lds();
+            LSTAMP(s, 6);
         }
     }
-    if constexpr (BURST) __syncthreads();             // the service waves flush the last steps after this
+    if constexpr (BURST && !DF) __syncthreads();      // the service waves flush the last steps after this (DF: barrier(T-1) was that)
     if (valid && p.h_n) st2(p.h_n + ((size_t)dir * p.B + b) * H + col, hlast);
+    if (trb) { trl[15] = (long long)__builtin_readcyclecounter(); for (int i = 0; i < 32; ++i) trb[i] = trl[i]; }
+#undef LSTAMP
 }
 
 // =============================================================================== backward
@@ -719,12 +889,22 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
     static int kb_env = -1;                           // DEP_LSTM_BURST=0: every wave streams for itself, every step (round-1 schedule)
     if (kb_env < 0) { const char* v = getenv("DEP_LSTM_BURST"); kb_env = (v && atoi(v) == 0) ? 0 : 4; }
     const int kb = kb_env;
-    const size_t lds = lstm_fwd_lds_floats(a.H, kb) * sizeof(float);
+    // Round 5: the direct-fragment exchange (DF above).  DEP_LSTM_DF=0: h_t through LDS planes, one flag per member, three barriers per step.
+    static int df_env = -1;
+    if (df_env < 0) { const char* v = getenv("DEP_LSTM_DF"); df_env = v ? (v[0] == '2' ? 2 : v[0] == '1' ? 1 : 0) : DEP_LSTM_DF_DEFAULT; }
+    const int df = (kb == 4 && a.split && a.H == 128) ? df_env : 0;
+    { static int dbg_env = -1; if (dbg_env < 0) { const char* v = getenv("DEP_LSTM_DBG"); dbg_env = v ? atoi(v) : 0; } p.dbg = dbg_env; }
+    p.trace = (kb && trace_env()) ? (long long*)(hdr_base(xbuf, a.hdr_slot) + TRACE_OFF) : nullptr;
+    const size_t lds = lstm_fwd_lds_floats(a.H, kb, df != 0) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4) * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4) * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4, true) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4, true) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4, true) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4, true) * sizeof(float)));
         attr = true;
     }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
@@ -733,7 +913,12 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
-        if (kb && a.split && a.sv16 && a.training) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true>), grid, block, lds, a.stream, p);
+        const bool sv16 = kb && a.split && a.sv16 && a.training;
+        if (df == 2) { if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true, 2>), grid, block, lds, a.stream, p);
+                       else hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, false, 2>), grid, block, lds, a.stream, p); }
+        else if (df) { if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true, 1>), grid, block, lds, a.stream, p);
+                       else hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, false, 1>), grid, block, lds, a.stream, p); }
+        else if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true>), grid, block, lds, a.stream, p);
         else if (kb) { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4>), grid, block, lds, a.stream, p);
                   else hipLaunchKernelGGL((lstm_fwd_cluster<4, false, 4>), grid, block, lds, a.stream, p); }
         else    { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 0>), grid, block, lds, a.stream, p);

@@ -40,7 +40,9 @@ else:
 rnn.check()
 torch.cuda.synchronize()
 res = {'g%d' % i: t.cpu().numpy() for i, t in enumerate(Gd)}
-if not lstm:
+if lstm:
+    res['h_n'] = h_n.cpu().numpy()
+else:
     res['pooled'] = pooled.cpu().numpy()
 if dx is not None:
     res['dx'] = dx.cpu().numpy()

@@ -57,6 +57,19 @@ def test_pk_gate_gradients_of_the_bilstm_stack_are_bit_identical_too(tmp_path, B
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
 
 
+# Round 5: the BiLSTM forward sweep reads the exchanged h_t as MFMA fragments straight from the exchange buffer (lstm_fwd_cluster<.., DF>:
+# per-wave flags, one barrier per step).  Same products in the same order and the same K-half sums as the LDS-plane form (DEP_LSTM_DF=0):
+# h_n and -- through the saved gates, cell states and dropped outputs the backward reads -- every gradient BIT-IDENTICAL.  B = 416: every
+# burst phase; T = 5 = burst + 1, T = 22, cfg3's full shape once.
+@pytest.mark.parametrize('B,T,F,dx', [(416, 5, 64, False), (416, 22, 64, True), (512, 300, 1024, False)])
+def test_direct_fragment_bilstm_forward_is_bit_identical_to_the_lds_plane_form(tmp_path, B, T, F, dx):
+    a = _run(tmp_path, 'a', 1, B, T, F, dx, lstm=True, env={'DEP_LSTM_DF': '0'})
+    b = _run(tmp_path, 'b', 1, B, T, F, dx, lstm=True, env={'DEP_LSTM_DF': '1'})
+    for k in a.files:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+
+
 def test_16bit_saved_gates_move_no_gradient_by_more_than_1e4_of_its_scale(tmp_path):
     """Round 4: the GRU stack saves r, z (unorm16) and n (snorm16) as 16-bit fixed point (|error| <= 7.6e-6 / 1.5e-5) instead of fp32.
     Forward outputs cannot change (the gates are only stored for the backward); every gradient of the cfg2-shaped stack must stay

@@ -42,6 +42,8 @@ CASES = [
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, ['--load']),
     ('lstm', 4, {'DEP_NUM_CUS': '200'}, []),
     ('lstm', 6, {'DEP_LSTM_BURST': '0'}, []),                     # round-1 BiLSTM schedule (no service waves)
+    ('lstm', 6, {'DEP_LSTM_DF': '0'}, []),                        # round 5: the default BiLSTM forward reads h_t as fragments from the exchange buffer; 0 = through LDS planes
+    ('lstm', 6, {'DEP_LSTM_DF': '0'}, ['--load']),
     ('lstm', 6, {}, ['--load', '--load-phase', 'bwd']),           # burst-stream BiLSTM backward with a co-scheduled kernel
 ]
 
@@ -140,6 +142,16 @@ def test_direct_fragment_forward_passes_the_kernel_parity_suite():
     suite against the oracle."""
     e = dict(os.environ, DEP_FWD_DF='1')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
+                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+
+
+def test_lstm_lds_plane_forward_passes_the_kernel_parity_suite():
+    """Round 5: lstm_fwd_cluster<.., DF = false> (h_t gathered into LDS planes, one flag per member, three barriers a step; DEP_LSTM_DF=0)
+    stays parity-green beside the direct-fragment default."""
+    e = dict(os.environ, DEP_LSTM_DF='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'lstm',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
