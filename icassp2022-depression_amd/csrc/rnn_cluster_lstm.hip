@@ -36,6 +36,7 @@ struct LB {
     unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
     int nofast;
     int dgpk;                // gate gradients as the PK image of gemm_bf16x3.hip (burst kernel, T even)
+    long long* trace;        // debug: shader-clock stamps of workgroup 0 (DEP_TRACE=1, tools/trace_lstm.py bwd), else nullptr
 };
 
 // block id = (dir*NC + c)*nbtp + bt  (nbtp a multiple of 8: all members of a cluster share blockIdx % 8)
@@ -507,10 +508,18 @@ struct StepIn { float2 ig, fg, gg, og, ct, cp, dy; };
 // KB steps per burst into the LDS ring `ibuf' and write the four gate gradients of the last KB steps out of `obuf'.
 constexpr int LB_IBUF = 2304;                        // float offset of ibuf (the gate-gradient planes live in [0, 2304))
 constexpr int lstm_bwd_oslots(int KB) { return KB + 2; }      // KB + 1 would do for fp32 rows; the PK flush works on step pairs and may lag one step
-constexpr size_t lstm_bwd_lds_floats(int KB) { return KB ? (size_t)LB_IBUF + KB * 7 * LARR + lstm_bwd_oslots(KB) * 4 * LARR : (size_t)BT * (128 + 8); }
+constexpr size_t lstm_bwd_lds_floats(int KB) { return KB ? (size_t)LB_IBUF + KB * 7 * LARR + lstm_bwd_oslots(KB) * 4 * LARR + LF_TRACE_F : (size_t)BT * (128 + 8); }
 
-template <int NTW, bool SPLIT, int KB, bool SV16 = false>      // output tiles per wave = H/64; SV16: 16-bit saved gates (burst kernel only)
+// SE (round 5, after lstm_fwd_cluster's DF = 2): per-step streams and per-wave flags.  The exchange stays the reduce-scatter of fp32 partial
+// dh (with H = 128 a member's gate gradients are as large as its partials: the all-gather form has nothing to save here), but
+// * every compute wave raises its OWN epoch flag once its two partial tiles are acknowledged and every wave polls all 4 NC flags (which also
+//   orders a step's reads of the gate-gradient planes before the next step's writes): the drain barrier is gone, ONE barrier per step;
+// * the service waves stream every step instead of every fourth: the gate gradients of step k-1 (8 KB, or a PK pair every other step) go out
+//   at the top of their iteration, the saved gates / c / dy of step k+2 (14 KB) are requested once the four compute waves have their gather
+//   loads of step k-1 in the CU's queue (an LDS counter) and land in the ring an iteration later -- no dirty step.
+template <int NTW, bool SPLIT, int KB, bool SV16 = false, bool SE = false>      // output tiles per wave = H/64; SV16: 16-bit saved gates (burst kernel only)
 __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
+    static_assert(!SE || (SPLIT && KB == 4), "per-step streams: the split-precision burst kernel's rings");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 128, KCB = KS / 16, LDG = KS + LPAD;
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane
@@ -533,6 +542,9 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
     const bool svc = BURST && tid >= CT;              // wave-uniform
     float* ibuf = smem + LB_IBUF;                     // [KB][7][16][LROW]: i, f, g, o, c_t, c_{t-1}, dy of step k (k = T-1-s) in slot k % KB
     float* obuf = ibuf + KBX * 7 * LARR;              // [KB+1][4][16][LROW]: di, df, dg, do of step k in slot k % (KB+1)
+    long long* trl = reinterpret_cast<long long*>(obuf + lstm_bwd_oslots(KBX) * 4 * LARR);      // debug stamps (burst kernels; LF_TRACE_F floats)
+    unsigned* sig = reinterpret_cast<unsigned*>(trl) + 128;                                     // SE: gather loads issued so far, all compute waves
+    if (SE && tid == 0) *sig = 0;                     // (ordered by the prologue's __syncthreads)
     f32x4 wr[SPLIT ? 1 : NTW][SPLIT ? 1 : KCB];
     u32x4 wq[SPLIT ? NTW : 1][SPLIT ? 4 : 1][2];      // [tile][k-step = gate][hi, lo]
     if (svc) {
@@ -559,8 +571,8 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
     const size_t pstride = (size_t)p.dirs * p.nbtp * NC * BT * H;
     const size_t tile_base = (size_t)cl * NC * BT * H;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
-    unsigned* myflag = p.flags + cl * NC + c;
-    unsigned* tflags = p.flags + cl * NC;
+    unsigned* tflags = SE ? p.flags + cl * NC * 4 : p.flags + cl * NC;       // SE: one flag per compute wave
+    unsigned* myflag = SE ? tflags + c * 4 + (w & 3) : tflags + c;
     const int ml = lane & 15, mq = lane >> 4;
     const int ldsg = p.dirs * 4 * H, ldsc = p.dirs * H;
     const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + cl * NC, NC, c, p.status);
@@ -672,6 +684,27 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                     }
                 }
             };
+            if constexpr (SE) {
+                // per-step streams (see above): one register set, one step in flight.  Iteration k, between barrier(k-1) and barrier(k):
+                // ring <- inputs of step k+1 (requested an iteration ago); gate gradients of step k-1 (PK: of the pair (k-2, k-1), k even);
+                // wait for the compute waves' gather loads of step k-1 to be in the queue; request the inputs of step k+2.
+                svc_issue(0, 1); svc_put(0, 1); svc_issue(1, 1);
+                __syncthreads();
+                for (int k = 0; k < T; ++k) {
+                    if (k + 1 < T) svc_put(k + 1, 1);
+                    if (p.dgpk) { if (k >= 2 && !(k & 1)) svc_flush_pk(k - 2, k); }
+                    else if (k > 0) svc_flush(k - 1, k);
+                    if (k + 2 < T) {
+                        const unsigned want = 4u * (unsigned)k;
+                        // (a scheduling hint, not a dependency: give up after ~1 ms -- a compute wave that left on a raised status never raises it)
+                        for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
+                        svc_issue(k + 2, 1);
+                    }
+                    bar_lds();
+                }
+                if (p.dgpk) svc_flush_pk(T - 2, T); else svc_flush(T - 1, T);
+                return;
+            }
             svc_issue(0, KBX); svc_put(0, KBX);
             svc_issue(KBX, phi);
             __syncthreads();
@@ -700,10 +733,15 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
         return f2(half ? m[2] : m[0], half ? m[3] : m[1]);
     };
     float2 mk = masked ? draw(T - 1) : f2(1.f, 1.f);
+    // debug stamps (DEP_TRACE=1, tools/trace_lstm.py bwd): workgroup 0, wave 0, steps k = 196 .. 199, buffered in LDS, copied out after the sweep
+    long long* trb = (BURST && p.trace && blockIdx.x == 0 && tid == 0) ? p.trace : nullptr;
+#define LSTAMP(k_, slot) do { if (trb && (k_) >= 196 && (k_) < 200) trl[((k_) - 196) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+    if (trb) { for (int i = 0; i < 64; ++i) trl[i] = 0; trl[7] = (long long)__builtin_readcyclecounter(); }
 
     for (int s = T - 1; s >= 0; --s) {
         const int t = dir ? (T - 1 - s) : s;
         const size_t row = (size_t)b * T + t;
+        LSTAMP(T - 1 - s, 0);
         if constexpr (BURST) {
             const float* ib = ibuf + ((T - 1 - s) % KBX) * 7 * LARR + j * LROW + ul;
             cur.ig = ld2(ib); cur.fg = ld2(ib + LARR); cur.gg = ld2(ib + 2 * LARR); cur.og = ld2(ib + 3 * LARR);
@@ -742,7 +780,9 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
         }
         db[0].x += dig.x; db[0].y += dig.y; db[1].x += dfg.x; db[1].y += dfg.y;
         db[2].x += dgg.x; db[2].y += dgg.y; db[3].x += dog.x; db[3].y += dog.y;
+        LSTAMP(T - 1 - s, 1);
         bar_lds();                                   // LDS only: the dgi stores above stay in flight
+        LSTAMP(T - 1 - s, 2);
         if (s == 0) break;
         if constexpr (!BURST) load_step(s - 1, nxt);
         f32x4 acc[NTW];
@@ -791,21 +831,38 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
             if (fast) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 16);
         }
+        LSTAMP(T - 1 - s, 3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        if constexpr (SE) {
+            // per-wave flags: this wave's partial tiles are acknowledged -> say so; nobody waits for the sibling waves here (their flags are
+            // among the 4 NC words every wave polls below: a sibling raises its flag only after its MFMAs have read the gate-gradient planes)
+            if (lane == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        } else {
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
+        }
+        LSTAMP(T - 1 - s, 4);
         if (masked) mk = draw(s - 1);                // next step's mask, in the shadow of the wait below
-        if (!wait_flags(tflags, NC, epoch, p.status, 7)) return;
+        if (!wait_flags(tflags, SE ? 4 * NC : NC, epoch, p.status, 7)) return;
+        LSTAMP(T - 1 - s, 5);
         const float* src = p.payload + pbase + ((size_t)(2 * c + jl) * 64 + lp) * 4 + 2 * half;
         float2 part[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) part[m] = (m < NC) ? ld2_agent(src + (size_t)m * NTT * 256) : f2(0.f, 0.f);
+        if constexpr (SE) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (lane == 0) sig_raise(sig);           // this wave's gather loads are in the CU's queue: the service waves may issue theirs
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float2 sum = f2(0.f, 0.f);
 #pragma unroll
         for (int m = 0; m < 4; ++m) { sum.x += part[m].x; sum.y += part[m].y; }
         dhrec = sum;
         if constexpr (!BURST) cur = nxt;
+        LSTAMP(T - 1 - s, 6);
     }
+    if (trb) { trl[15] = (long long)__builtin_readcyclecounter(); for (int i = 0; i < 32; ++i) trb[i] = trl[i]; }
+#undef LSTAMP
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -965,12 +1022,19 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
     const int kb = kb_env;
     DEP_CHECK_ARG(!a.dg_pk || (kb == 4 && a.T % 2 == 0));
     DEP_CHECK_ARG(!a.sv16 || (kb == 4 && a.split));           // 16-bit saved gates: burst kernel, split-precision mode      // the PK image comes out of the burst kernel's flush (dep_cluster_lstm_bwd_pk_ok)
+    // Round 5: per-step streams + per-wave flags (SE above).  DEP_LSTM_SE=0: burst streams, one flag per member behind a drain barrier.
+    static int se_env = -1;
+    if (se_env < 0) { const char* v = getenv("DEP_LSTM_SE"); se_env = v ? (v[0] == '1' ? 1 : 0) : DEP_LSTM_SE_DEFAULT; }
+    const bool se = se_env && kb == 4 && a.split;
+    p.trace = (kb && trace_env()) ? (long long*)(hdr_base(xbuf, a.hdr_slot) + TRACE_OFF) : nullptr;
     const size_t lds = lstm_bwd_lds_floats(kb) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, true, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_bwd_cluster<2, true, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_bwd_lds_floats(4) * sizeof(float)));
         attr = true;
     }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
@@ -979,7 +1043,9 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
-        if (kb && a.split && a.sv16) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4, true>), grid, block, lds, a.stream, p);
+        if (se) { if (a.sv16) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4, true, true>), grid, block, lds, a.stream, p);
+                  else hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4, false, true>), grid, block, lds, a.stream, p); }
+        else if (kb && a.split && a.sv16) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4, true>), grid, block, lds, a.stream, p);
         else if (kb) { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4>), grid, block, lds, a.stream, p);
                   else hipLaunchKernelGGL((lstm_bwd_cluster<2, false, 4>), grid, block, lds, a.stream, p); }
         else    { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 0>), grid, block, lds, a.stream, p);

@@ -70,6 +70,17 @@ def test_direct_fragment_bilstm_forward_is_bit_identical_to_the_lds_plane_form(t
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
 
 
+# ... and the backward sweep with per-step streams and per-wave flags (lstm_bwd_cluster<.., SE>; DEP_LSTM_SE=0 = burst streams + drain barrier):
+# same products, same member-order sum of the partials, same PK image -- every gradient bit-identical; fp32 gate-gradient rows (DEP_DGI_PK=0) too.
+@pytest.mark.parametrize('B,T,F,dx,pk', [(416, 5, 64, False, 0), (416, 22, 64, True, 1), (416, 6, 64, True, 0), (512, 300, 1024, False, 1)])
+def test_per_step_stream_bilstm_backward_is_bit_identical_to_the_burst_form(tmp_path, B, T, F, dx, pk):
+    a = _run(tmp_path, 'a', pk, B, T, F, dx, lstm=True, env={'DEP_LSTM_SE': '0'})
+    b = _run(tmp_path, 'b', pk, B, T, F, dx, lstm=True, env={'DEP_LSTM_SE': '1'})
+    for k in a.files:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+
+
 def test_16bit_saved_gates_move_no_gradient_by_more_than_1e4_of_its_scale(tmp_path):
     """Round 4: the GRU stack saves r, z (unorm16) and n (snorm16) as 16-bit fixed point (|error| <= 7.6e-6 / 1.5e-5) instead of fp32.
     Forward outputs cannot change (the gates are only stored for the backward); every gradient of the cfg2-shaped stack must stay

@@ -44,6 +44,8 @@ CASES = [
     ('lstm', 6, {'DEP_LSTM_BURST': '0'}, []),                     # round-1 BiLSTM schedule (no service waves)
     ('lstm', 6, {'DEP_LSTM_DF': '0'}, []),                        # round 5: the default BiLSTM forward reads h_t as fragments from the exchange buffer; 0 = through LDS planes
     ('lstm', 6, {'DEP_LSTM_DF': '0'}, ['--load']),
+    ('lstm', 6, {'DEP_LSTM_DF': '1', 'DEP_LSTM_SE': '0'}, []),    # direct fragments with burst streams; the backward with burst streams + one flag per member
+    ('lstm', 6, {'DEP_LSTM_SE': '0'}, ['--load', '--load-phase', 'bwd']),
     ('lstm', 6, {}, ['--load', '--load-phase', 'bwd']),           # burst-stream BiLSTM backward with a co-scheduled kernel
 ]
 
@@ -148,9 +150,9 @@ def test_direct_fragment_forward_passes_the_kernel_parity_suite():
 
 
 def test_lstm_lds_plane_forward_passes_the_kernel_parity_suite():
-    """Round 5: lstm_fwd_cluster<.., DF = false> (h_t gathered into LDS planes, one flag per member, three barriers a step; DEP_LSTM_DF=0)
-    stays parity-green beside the direct-fragment default."""
-    e = dict(os.environ, DEP_LSTM_DF='0')
+    """Round 5: lstm_fwd_cluster<.., DF = 0> (h_t gathered into LDS planes, one flag per member, three barriers a step; DEP_LSTM_DF=0) and
+    lstm_bwd_cluster<.., SE = false> (burst streams, drain barrier; DEP_LSTM_SE=0) stay parity-green beside the per-step-stream defaults."""
+    e = dict(os.environ, DEP_LSTM_DF='0', DEP_LSTM_SE='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'lstm',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
