@@ -174,12 +174,17 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
             };
             // write-out arrays: 0 h, 1 dropout(h), 2..5 the activated gates, 6 c.  Even waves: 0, 2, 4, 6; odd waves: 1, 3, 5.
             float* const ybase = sodd ? p.ydrop : p.y;
-            auto svc_flush = [&](int k0, int k1) {
+            // mk4 (DF = 2): the odd waves form dropout(h) themselves -- h times the mask of the piece's four positions -- instead of reading a second array
+            auto svc_flush = [&](int k0, int k1, const f32x4* mk4 = nullptr) {
                 if (!svalid) return;
                 for (int k = k0 < 0 ? 0 : k0; k < k1; ++k) {
                     const size_t row = (size_t)sb * T + tstep(k);
                     const float* o = obuf + (k % (KBX + 1)) * 7 * LARR + sr * LROW + sp * 4;
-                    if (ybase) nt_st4(a_y, ybase + row * p.ldy + dir * H + scol, ld4(o + (sodd ? LARR : 0)));
+                    if (ybase) {
+                        f32x4 v = ld4(o + ((sodd && !mk4) ? LARR : 0));
+                        if (sodd && mk4) { v[0] *= (*mk4)[0]; v[1] *= (*mk4)[1]; v[2] *= (*mk4)[2]; v[3] *= (*mk4)[3]; }
+                        nt_st4(a_y, ybase + row * p.ldy + dir * H + scol, v);
+                    }
                     if (p.svg) {
                         if constexpr (SV16) {                 // even waves: i (unorm), g (snorm) ; odd waves: f, o (unorm)
                             unsigned short* gs16 = reinterpret_cast<unsigned short*>(p.svg) + row * ldsg + dir * 4 * H + scol;
@@ -199,21 +204,31 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
             if constexpr (DF == 2) {
                 // per-step streams (see above): one register set, one step in flight.  Iteration k, between barrier(k-1) and barrier(k):
                 // ring <- gi(k+1) (requested a step ago); write-out of step k-1; wait for the issue signal; request gi(k+2).
+                // The inter-layer dropout mask is drawn HERE (odd waves, one Philox call per 16-byte piece, an iteration ahead, behind the
+                // requests): on the compute waves the draw (~700 ticks of VALU for half as many useful values) sat between the fragment
+                // requests and the MFMAs, and the requests return in less than that.
+                const bool sdrop = sodd && p.ydrop != nullptr;        // wave-uniform
+                auto sdraw = [&](int k) {
+                    const size_t o = ((size_t)sb * T + tstep(k)) * p.ldy + dir * H + scol;
+                    return dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+                };
+                f32x4 mk4 = {1.f, 1.f, 1.f, 1.f};                     // mask of the step the next iteration writes out
                 svc_issue(0, 1); svc_put(0, 1); svc_issue(1, 1);
                 __syncthreads();
                 for (int k = 0; k < T; ++k) {
                     if (k + 1 < T) svc_put(k + 1, 1);
-                    if (k > 0 && !(p.dbg & 1)) svc_flush(k - 1, k);
+                    if (k > 0 && !(p.dbg & 1)) svc_flush(k - 1, k, &mk4);
                     if (k + 2 < T) {
                         const unsigned want = 4u * ((unsigned)k + 1u);
                         // (a scheduling hint, not a dependency: give up after ~1 ms -- a compute wave that left on a raised status never raises it)
                         for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
                     }
-                    if (k > 0 && (p.dbg & 1)) svc_flush(k - 1, k);
+                    if (k > 0 && (p.dbg & 1)) svc_flush(k - 1, k, &mk4);
                     if (k + 2 < T) svc_issue(k + 2, 1);
+                    if (sdrop) mk4 = sdraw(k);
                     bar_lds();
                 }
-                svc_flush(T - 1, T);
+                svc_flush(T - 1, T, &mk4);
                 return;
             }
             svc_issue(0, KBX); svc_put(0, KBX);       // steps 0 .. KB-1 straight into the ring
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
         const bool khu = __builtin_amdgcn_readfirstlane(kh) != 0;
         // inter-layer dropout of the output: the Philox draw of step k+1 is made behind step k's fragment requests (it depends on
         // nothing but the position)
-        const bool masked = p.ydrop != nullptr;
+        const bool masked = DF != 2 && p.ydrop != nullptr;      // (DF = 2: the service waves draw the mask and form dropout(h) at write-out)
         auto draw = [&](int k) {
             const size_t o = ((size_t)b * T + (dir ? T - 1 - k : k)) * p.ldy + dir * H + col;
             const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
@@ -630,7 +645,8 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                         sreg[d][3] = (on && !sodd && p.dy) ? nt_ld4(a_dy, p.dy + row * p.lddy + dir * H + scol) : zero4();
                     }
             };
-            auto svc_put = [&](int k0, int n) {
+            // mk4 (SE): the even waves apply the inter-layer dropout mask to the incoming dy as they put it into the ring
+            auto svc_put = [&](int k0, int n, const f32x4* mk4 = nullptr) {
 #pragma unroll
                 for (int d = 0; d < KBX; ++d)
                     if (d < n) {
@@ -648,7 +664,11 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                             *reinterpret_cast<f32x4*>(dst + 2 * LARR) = sreg[d][1];
                         }
                         *reinterpret_cast<f32x4*>(dst + 4 * LARR) = sreg[d][2];
-                        if (!sodd) *reinterpret_cast<f32x4*>(dst + 6 * LARR) = sreg[d][3];
+                        if (!sodd) {
+                            f32x4 v = sreg[d][3];
+                            if (mk4) { v[0] *= (*mk4)[0]; v[1] *= (*mk4)[1]; v[2] *= (*mk4)[2]; v[3] *= (*mk4)[3]; }
+                            *reinterpret_cast<f32x4*>(dst + 6 * LARR) = v;
+                        }
                     }
             };
             auto svc_flush = [&](int k0, int k1) {    // gate gradients of steps k0 .. k1-1: even waves di, dg ; odd waves df, do
@@ -688,10 +708,21 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                 // per-step streams (see above): one register set, one step in flight.  Iteration k, between barrier(k-1) and barrier(k):
                 // ring <- inputs of step k+1 (requested an iteration ago); gate gradients of step k-1 (PK: of the pair (k-2, k-1), k even);
                 // wait for the compute waves' gather loads of step k-1 to be in the queue; request the inputs of step k+2.
-                svc_issue(0, 1); svc_put(0, 1); svc_issue(1, 1);
+                // The dropout mask of the incoming dy is drawn HERE (even waves, one Philox call per 16-byte piece, behind the requests of the step
+                // it belongs to) and applied as dy enters the ring: on the compute waves the draw was the floor of the poll phase.
+                const bool sdrop = !sodd && p.dy && p.drop_p > 0.f;   // wave-uniform
+                auto sdraw = [&](int k) {
+                    const int sstep = T - 1 - k, t = dir ? (T - 1 - sstep) : sstep;
+                    const size_t o = ((size_t)sb * T + t) * p.lddy + dir * H + scol;
+                    return dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
+                };
+                f32x4 mk4 = {1.f, 1.f, 1.f, 1.f};                     // mask of the step the next put moves into the ring
+                svc_issue(0, 1); if (sdrop) mk4 = sdraw(0);
+                svc_put(0, 1, &mk4);
+                svc_issue(1, 1); if (sdrop && T > 1) mk4 = sdraw(1);
                 __syncthreads();
                 for (int k = 0; k < T; ++k) {
-                    if (k + 1 < T) svc_put(k + 1, 1);
+                    if (k + 1 < T) svc_put(k + 1, 1, &mk4);
                     if (p.dgpk) { if (k >= 2 && !(k & 1)) svc_flush_pk(k - 2, k); }
                     else if (k > 0) svc_flush(k - 1, k);
                     if (k + 2 < T) {
@@ -699,6 +730,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
                         // (a scheduling hint, not a dependency: give up after ~1 ms -- a compute wave that left on a raised status never raises it)
                         for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
                         svc_issue(k + 2, 1);
+                        if (sdrop) mk4 = sdraw(k + 2);
                     }
                     bar_lds();
                 }
@@ -725,7 +757,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_bwd_cluster(LB p) {
     StepIn cur, nxt;
     if constexpr (!BURST) load_step(T - 1, cur);
     // dropout mask of the incoming dy: drawn one step ahead while waiting for the other members (see rnn_cluster_bwd.hip)
-    const bool masked = p.dy && p.drop_p > 0.f && valid;
+    const bool masked = !SE && p.dy && p.drop_p > 0.f && valid;      // (SE: the service waves draw the mask and apply it as dy enters the ring)
     auto draw = [&](int s) {
         const int t = dir ? (T - 1 - s) : s;
         const size_t o = ((size_t)b * T + t) * p.lddy + dir * H + col;

@@ -17,9 +17,9 @@ echo "== traces"
 for df in 2 1 0; do echo "-- DEP_LSTM_DF=$df"; DEP_TRACE=1 DEP_LSTM_DF=$df timeout 120 python tools/trace_lstm.py 2>&1 | grep -v amdgpu.ids; done
 for se in 1 0; do echo "-- backward, DEP_LSTM_SE=$se"; DEP_TRACE=1 DEP_LSTM_SE=$se timeout 120 python tools/trace_lstm.py bwd 2>&1 | grep -v amdgpu.ids; done
 echo "== A/B rnn operator"
-for i in 1 2; do for se in 0 1; do echo "se=$se"; DEP_LSTM_SE=$se STEPS=10 timeout 120 python tools/bench_rnn.py lstm 2>&1 | grep -v amdgpu.ids; done; done
+for i in 1 2; do for se in 0 1; do echo "se=$se df=$((se+1))"; DEP_LSTM_DF=$((se+1)) DEP_LSTM_SE=$se STEPS=10 timeout 120 python tools/bench_rnn.py lstm 2>&1 | grep -v amdgpu.ids; done; done
 echo "== bench step cfg3"
-for df in 0 1 0 1; do DEP_LSTM_SE=$df timeout 200 python bench.py --workload text_bilstm --no-cpu-baseline --no-other-workloads --profile-run 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('se=$df', d['ms_per_step'], d['roofline'].get('kernels_ms_per_step'))"; done
+for df in 0 1 0 1; do DEP_LSTM_DF=$((df+1)) DEP_LSTM_SE=$df timeout 200 python bench.py --workload text_bilstm --no-cpu-baseline --no-other-workloads --profile-run 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('se=$df df=$((df+1))', d['ms_per_step'], d['roofline'].get('kernels_ms_per_step'))"; done
 echo "== bench step fusion"
 for df in 0 1; do DEP_LSTM_SE=$df timeout 200 python bench.py --workload fusion --no-cpu-baseline --no-other-workloads 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('se=$df', d['ms_per_step'])"; done
 } > $out/log.txt 2>&1
