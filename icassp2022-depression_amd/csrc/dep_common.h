@@ -180,7 +180,7 @@ struct dep_sweep_bwd_args {
 bool dep_cluster_bwd_pk_ok(int H, int T);
 #define DEP_BWD_AG_DEFAULT 1          /* the GRU-256 backward sweep's exchange: 0 = reduce-scatter of fp32 partials, 1 = all-gather of gate gradients (DEP_BWD_AG overrides) */
 bool dep_cluster_bwd_ag_on();
-#define DEP_LSTM_DF_DEFAULT 2          /* the BiLSTM-128 forward sweep: 0 = h_t through LDS planes (three barriers a step), 1 = direct fragment loads + per-wave flags, burst streams, 2 = the same with per-step streams (DEP_LSTM_DF overrides) */
+#define DEP_LSTM_DF_DEFAULT 3          /* the BiLSTM-128 forward sweep: 0 = h_t through LDS planes (three barriers a step), 1 = direct fragment loads + per-wave flags, burst streams, 2 = + per-step streams, 3 = + the data are their own flag (sentinel slots) (DEP_LSTM_DF overrides) */
 #define DEP_LSTM_SE_DEFAULT 1          /* the BiLSTM-128 backward sweep: 0 = burst streams, one flag per member behind a drain barrier, 1 = per-step streams + per-wave flags (DEP_LSTM_SE overrides) */
 #define DEP_FWD_DF_DEFAULT 0           /* the fused GRU forward with direct fragment loads (gru2_fwd_df, rnn_fused2.hip); DEP_FWD_DF overrides */
 #define DEP_FUSED2_BWD_DEFAULT 1      /* both GRU layers' BPTT as one all-gather launch (rnn_fused2_bwd.hip); DEP_FUSED2_BWD overrides */

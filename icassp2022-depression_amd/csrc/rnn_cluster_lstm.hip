@@ -69,12 +69,22 @@ constexpr size_t lstm_fwd_lds_floats(int H, int KB, bool DF = false) {
 // no copy into LDS planes, no unpacking, and ONE workgroup barrier per step (behind the K-half partial sums) instead of three.  The
 // products, their order and the sums are the ones of the LDS form: every output is bit-identical (tests/test_stress_gpu.py).
 constexpr int DF_MEMBER_BYTES = 2 * 1024;
+// DF = 3: the data are their own flag.  A step's hand-off in DF = 1 / 2 is three L2 round trips in a row -- the publish acknowledged, the
+// flag seen by the poll, the fragments loaded.  Here a member publishes into one of FOUR slots (step k -> slot k % 4) whose words hold a
+// SENTINEL until they are written -- 0xffffffff, a pair of bf16 NaNs no finite h produces (a NaN input is published as 0x7fc07fc0) -- and a
+// consumer simply loads its four fragment blocks until none of its sixteen words is the sentinel: no acknowledgement wait, no flag store, no
+// separate poll.  With step k's data a member re-arms its slot (k + 2) % 4 (it held step k-2: every reader of that finished before the member
+// could gate step k); that store is acknowledged before the member's next publish is even issued (the load loop's vmcnt(0)), and nobody polls
+// slot (k + 2) % 4 before having consumed that next publish -- so a poll never meets the slot's previous tenant.  The slots are armed in the
+// kernel's prologue, in front of the hello rendezvous.
+constexpr unsigned DF_SENT = 0xffffffffu;
 
 // SV16 (burst kernels only): the saved activated gates are 16-bit fixed point -- i, f, o in (0, 1) as unorm16, g in (-1, 1) as
 // snorm16 (rnn_cluster_common.h; same element positions inside the (B,T,dirs*4H) array, 2 bytes each); c stays fp32.
 template <int KCH, bool SPLIT, int KB, bool SV16 = false, int DF = 0>      // k-chunks of 16 per wave = H/32
 __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
     static_assert(!DF || (SPLIT && KB == 4 && KCH == 4), "direct-fragment exchange: H = 128, split products, burst length 4");
+    static_assert(DF >= 0 && DF <= 3, "DF: 0 LDS planes, 1 direct fragments + bursts, 2 + per-step streams, 3 + sentinel hand-off");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = p.H, T = p.T, LDH = H + LPAD, KC = H / 16, NC = H / 32;
     const int LDHB = H + 8;                           // bf16 elements per row of a split plane
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
     float* obuf = ibuf + KBX * 4 * LARR;              // [KB+1][7][16][LROW]: h, dropout(h), i, f, g, o, c of step k in slot k % (KB+1)
     long long* trl = reinterpret_cast<long long*>(obuf + (KBX + 1) * 7 * LARR);      // debug stamps (burst kernels; LF_TRACE_F floats)
     unsigned* sig = reinterpret_cast<unsigned*>(trl) + 128;                          // DF = 2: fragment requests issued so far, all compute waves
-    if (DF == 2 && tid == 0) *sig = 0;               // (ordered by the prologue's __syncthreads)
+    if (DF >= 2 && tid == 0) *sig = 0;               // (ordered by the prologue's __syncthreads)
     const bool svc = BURST && tid >= CT;              // wave-uniform
     if constexpr (!DF) for (int i = tid; i < hs_floats; i += (BURST ? CT + L_SVC : CT)) hs[i] = 0.f;
 
@@ -131,9 +141,24 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
     unsigned* myflag = DF ? tflags + c * 4 + (w & 3) : tflags + c;
     const int hshift = __ffs(H) - 1;
     const int ldsg = p.dirs * 4 * H, ldsc = p.dirs * H;
-    const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + cl * NC, NC, c, p.status);
+    if constexpr (DF == 3) {
+        // arm this member's words of all four slots (write-through: the placement is not known yet), then the hello is the rendezvous
+        if (!svc) {
+            const int ulc0 = jt * 16 + q * 4 + 2 * kh - 32 * c;
+            const unsigned pw0 = (unsigned)((((ulc0 >> 3) * 16 + j) << 2) + ((ulc0 & 7) >> 1));
+            const unsigned pb0 = (unsigned)(cl * NC + c) * DF_MEMBER_BYTES + pw0 * 4, pbs = (unsigned)p.dirs * p.nbtp * NC * DF_MEMBER_BYTES;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                __builtin_amdgcn_raw_buffer_store_b32(DF_SENT, rsrc, pb0 + sl * pbs, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(DF_SENT, rsrc, pb0 + sl * pbs + 1024, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+    const int sx = (p.nofast && DF != 3) ? 0 : cluster_same_xcd(p.hello + cl * NC, NC, c, p.status);
     if (sx < 0) return;
-    const bool fast = sx == 1;
+    const bool fast = sx == 1 && !p.nofast;
     if constexpr (BURST) {
         if (svc) {
             // ---- the service waves' whole life.  Thread st: piece idx = st + 256 i of a step's pieces -> array idx / 128 (wave-
@@ -201,7 +226,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
                     }
                 }
             };
-            if constexpr (DF == 2) {
+            if constexpr (DF >= 2) {
                 // per-step streams (see above): one register set, one step in flight.  Iteration k, between barrier(k-1) and barrier(k):
                 // ring <- gi(k+1) (requested a step ago); write-out of step k-1; wait for the issue signal; request gi(k+2).
                 // The inter-layer dropout mask is drawn HERE (odd waves, one Philox call per 16-byte piece, an iteration ahead, behind the
@@ -283,7 +308,7 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
         const bool khu = __builtin_amdgcn_readfirstlane(kh) != 0;
         // inter-layer dropout of the output: the Philox draw of step k+1 is made behind step k's fragment requests (it depends on
         // nothing but the position)
-        const bool masked = DF != 2 && p.ydrop != nullptr;      // (DF = 2: the service waves draw the mask and form dropout(h) at write-out)
+        const bool masked = DF < 2 && p.ydrop != nullptr;       // (DF >= 2: the service waves draw the mask and form dropout(h) at write-out)
         auto draw = [&](int k) {
             const size_t o = ((size_t)b * T + (dir ? T - 1 - k : k)) * p.ldy + dir * H + col;
             const f32x4 m = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
@@ -309,11 +334,24 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
             if (more) {       // publish first: the (hi, lo) pair words of h_k -- what every member's MFMAs read
                 unsigned hw, lw;
                 split_pair(h.x, h.y, hw, lw);
+                if constexpr (DF == 3) {
+                    if (hw == DF_SENT) hw = 0x7fc07fc0u;      // (NaN inputs only) never the sentinel
+                    if (lw == DF_SENT) lw = 0x7fc07fc0u;
+                    const unsigned po = (unsigned)(k & 3) * par_bytes + pub0, pr = (unsigned)((k + 2) & 3) * par_bytes + pub0;
+                    if (fast) {
+                        __builtin_amdgcn_raw_buffer_store_b32(hw, rsrc, po, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(lw, rsrc, po + 1024, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(DF_SENT, rsrc, pr, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(DF_SENT, rsrc, pr + 1024, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(hw, rsrc, po, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(lw, rsrc, po + 1024, 0, 16);
+                        __builtin_amdgcn_raw_buffer_store_b32(DF_SENT, rsrc, pr, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(DF_SENT, rsrc, pr + 1024, 0, 16);
+                    }
+                } else {
                 const unsigned po = (unsigned)(k & 1) * par_bytes + pub0;
                 if (fast) {   // same-XCD clusters: plain stores (that XCD's L2 is the coherence point)
                     __builtin_amdgcn_raw_buffer_store_b32(hw, rsrc, po, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(lw, rsrc, po + 1024, 0, 0);
                 } else {      // write-through
                     __builtin_amdgcn_raw_buffer_store_b32(hw, rsrc, po, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(lw, rsrc, po + 1024, 0, 16);
+                }
                 }
             }
             {
@@ -324,6 +362,31 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
             }
             LSTAMP(k, 1);
             if (!more) { bar_lds(); break; }          // (the service waves' final flush reads obuf behind this barrier)
+            u32x4 hfr[KS2][2];
+            if constexpr (DF == 3) {
+                LSTAMP(k, 2); LSTAMP(k, 3);
+                const unsigned lo_ = (unsigned)(k & 3) * par_bytes + ld0;
+                for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+                            hfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo_ + (unsigned)(ks * 2 + pl) * 1024, 0, 16 /* sc1: served by L2 */);
+                    unsigned mn = 0xffffffffu;        // min over the sixteen words of ~word: 0 <=> one of them is still the sentinel (branch-free)
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) {
+                            const u32x4 v = hfr[ks][pl];
+                            mn = min(min(min(mn, ~v.x), min(~v.y, ~v.z)), ~v.w);
+                        }
+                    if (!__any(mn == 0u)) break;
+                    if (spins > SPIN_LIMIT) { st_agent(p.status, 6); return; }
+                    if ((spins & 63) == 63 && ld_agent(p.status) != 0) return;
+                }
+                LSTAMP(k, 4);
+                if (lane == 0) sig_raise(sig);        // nothing of this wave is in the CU's queue any more: the service waves may issue their requests
+            } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's two stores are acknowledged
             LSTAMP(k, 2);
             const unsigned epoch = (unsigned)k + 1u;
@@ -332,13 +395,13 @@ __global__ __launch_bounds__(KB ? CT + L_SVC : CT) void lstm_fwd_cluster(LF p) {
             if (!wait_flags(srcflags, 8, epoch, p.status, 6)) return;
             LSTAMP(k, 4);
             const unsigned lo_ = (unsigned)(k & 1) * par_bytes + ld0;
-            u32x4 hfr[KS2][2];
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     hfr[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo_ + (unsigned)(ks * 2 + pl) * 1024, 0, 16 /* sc1: served by L2 */);
             if (DF == 2 && lane == 0) sig_raise(sig); // this wave's requests are in the CU's queue: the service waves may issue theirs
+            }
             __builtin_amdgcn_sched_barrier(0);        // all four requests first
             if (masked) mk = draw(k + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -956,7 +1019,7 @@ bool dep_cluster_lstm_ok(int H, int B, int dirs) {
 size_t dep_cluster_lstm_xbuf_bytes(int H, int B, int dirs) {
     const int NC = H / 32, CH = dep_cluster_chunk(dirs * NC, 1, 256);
     const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
-    return PAYLOAD_OFF + (size_t)2 * dirs * nbtp * NC * BT * H * sizeof(float) + 256;
+    return PAYLOAD_OFF + (size_t)2 * dirs * nbtp * NC * BT * H * sizeof(float) + 256;      // the backward's two parities of NC x 16 x H fp32 per cluster (NC >= 2: covers the forward's four slots of 16 x H)
 }
 
 int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
@@ -970,7 +1033,7 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
     p.drop_p = a.drop_p; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f; p.seed = a.seed; p.site = a.site;
     p.h_n = a.h_n;
     p.svg = a.training ? a.sv0 : nullptr; p.svc = a.sv1;
-    const size_t pay = (size_t)2 * a.dirs * nbtp_max * BT * a.H * sizeof(float);
+    const size_t pay = (size_t)4 * a.dirs * nbtp_max * BT * a.H * sizeof(float);      // four slots (DF = 3; the other forms use two)
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)a.dirs * nbtp_max * NC <= 256);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, a.hdr_slot) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
@@ -980,7 +1043,7 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
     const int kb = kb_env;
     // Round 5: the direct-fragment exchange (DF above).  DEP_LSTM_DF=0: h_t through LDS planes, one flag per member, three barriers per step.
     static int df_env = -1;
-    if (df_env < 0) { const char* v = getenv("DEP_LSTM_DF"); df_env = v ? (v[0] == '2' ? 2 : v[0] == '1' ? 1 : 0) : DEP_LSTM_DF_DEFAULT; }
+    if (df_env < 0) { const char* v = getenv("DEP_LSTM_DF"); df_env = v ? (v[0] >= '0' && v[0] <= '3' ? v[0] - '0' : 0) : DEP_LSTM_DF_DEFAULT; }
     const int df = (kb == 4 && a.split && a.H == 128) ? df_env : 0;
     { static int dbg_env = -1; if (dbg_env < 0) { const char* v = getenv("DEP_LSTM_DBG"); dbg_env = v ? atoi(v) : 0; } p.dbg = dbg_env; }
     p.trace = (kb && trace_env()) ? (long long*)(hdr_base(xbuf, a.hdr_slot) + TRACE_OFF) : nullptr;
@@ -994,6 +1057,8 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
         (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4, true) * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4, true) * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4, true) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4, true) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)lstm_fwd_cluster<4, true, 4, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lstm_fwd_lds_floats(128, 4, true) * sizeof(float)));
         attr = true;
     }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
@@ -1003,7 +1068,9 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
         const bool sv16 = kb && a.split && a.sv16 && a.training;
-        if (df == 2) { if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true, 2>), grid, block, lds, a.stream, p);
+        if (df == 3) { if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true, 3>), grid, block, lds, a.stream, p);
+                       else hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, false, 3>), grid, block, lds, a.stream, p); }
+        else if (df == 2) { if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true, 2>), grid, block, lds, a.stream, p);
                        else hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, false, 2>), grid, block, lds, a.stream, p); }
         else if (df) { if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true, 1>), grid, block, lds, a.stream, p);
                        else hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, false, 1>), grid, block, lds, a.stream, p); }

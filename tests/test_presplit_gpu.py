@@ -61,10 +61,11 @@ def test_pk_gate_gradients_of_the_bilstm_stack_are_bit_identical_too(tmp_path, B
 # per-wave flags, one barrier per step).  Same products in the same order and the same K-half sums as the LDS-plane form (DEP_LSTM_DF=0):
 # h_n and -- through the saved gates, cell states and dropped outputs the backward reads -- every gradient BIT-IDENTICAL.  B = 416: every
 # burst phase; T = 5 = burst + 1, T = 22, cfg3's full shape once.
-@pytest.mark.parametrize('B,T,F,dx', [(416, 5, 64, False), (416, 22, 64, True), (512, 300, 1024, False)])
-def test_direct_fragment_bilstm_forward_is_bit_identical_to_the_lds_plane_form(tmp_path, B, T, F, dx):
+@pytest.mark.parametrize('B,T,F,dx,df', [(416, 5, 64, False, 1), (416, 22, 64, True, 2), (416, 22, 64, False, 3), (416, 5, 64, False, 3), (512, 300, 1024, False, 2),
+                                         (512, 300, 1024, False, 3)])
+def test_direct_fragment_bilstm_forward_is_bit_identical_to_the_lds_plane_form(tmp_path, B, T, F, dx, df):
     a = _run(tmp_path, 'a', 1, B, T, F, dx, lstm=True, env={'DEP_LSTM_DF': '0'})
-    b = _run(tmp_path, 'b', 1, B, T, F, dx, lstm=True, env={'DEP_LSTM_DF': '1'})
+    b = _run(tmp_path, 'b', 1, B, T, F, dx, lstm=True, env={'DEP_LSTM_DF': str(df)})
     for k in a.files:
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))

@@ -42,9 +42,11 @@ CASES = [
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, ['--load']),
     ('lstm', 4, {'DEP_NUM_CUS': '200'}, []),
     ('lstm', 6, {'DEP_LSTM_BURST': '0'}, []),                     # round-1 BiLSTM schedule (no service waves)
-    ('lstm', 6, {'DEP_LSTM_DF': '0'}, []),                        # round 5: the default BiLSTM forward reads h_t as fragments from the exchange buffer; 0 = through LDS planes
+    ('lstm', 6, {'DEP_LSTM_DF': '0'}, []),                        # round 5: the default BiLSTM forward reads h_t as fragments from the exchange buffer (sentinel hand-off, per-step streams); 0 = through LDS planes
     ('lstm', 6, {'DEP_LSTM_DF': '0'}, ['--load']),
     ('lstm', 6, {'DEP_LSTM_DF': '1', 'DEP_LSTM_SE': '0'}, []),    # direct fragments with burst streams; the backward with burst streams + one flag per member
+    ('lstm', 6, {'DEP_LSTM_DF': '2'}, ['--load']),                # per-step streams with per-wave flags (the default adds the sentinel hand-off)
+    ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, []),
     ('lstm', 6, {'DEP_LSTM_SE': '0'}, ['--load', '--load-phase', 'bwd']),
     ('lstm', 6, {}, ['--load', '--load-phase', 'bwd']),           # burst-stream BiLSTM backward with a co-scheduled kernel
 ]

@@ -38,6 +38,9 @@ tr = rnn.workspace[(off + 6400) // 4:(off + 6400) // 4 + 64].view(torch.int64).c
 if bwd:
     names = ['ring read + gate gradients + planes + write-out ring', 'barrier', 'LDS fragment reads + 24 MFMAs + partial-dh stores issued',
              'stores acknowledged (+ drain barrier) + flag', 'mask draw + poll', 'gather 4 partials + sum']
+elif os.environ.get('DEP_LSTM_DF', '2') == '3':
+    names = ['ring read + gates + c, h + publish + re-arm issue + write-out ring', '-', '-', 'fragment loads until no word is the sentinel',
+             '24 MFMAs + partial write', 'barrier + K-half sum']
 elif os.environ.get('DEP_LSTM_DF', '2') != '0':
     names = ['ring read + gates + c, h + publish issue + write-out ring', 'publish acknowledged', 'flag', 'poll (2 source members, 8 wave flags)',
              '4 fragment loads + mask draw + 24 MFMAs + partial write', 'barrier + K-half sum']
