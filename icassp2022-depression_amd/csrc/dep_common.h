@@ -182,6 +182,7 @@ bool dep_cluster_bwd_pk_ok(int H, int T);
 bool dep_cluster_bwd_ag_on();
 #define DEP_LSTM_DF_DEFAULT 3          /* the BiLSTM-128 forward sweep: 0 = h_t through LDS planes (three barriers a step), 1 = direct fragment loads + per-wave flags, burst streams, 2 = + per-step streams, 3 = + the data are their own flag (sentinel slots) (DEP_LSTM_DF overrides) */
 #define DEP_LSTM_SE_DEFAULT 1          /* the BiLSTM-128 backward sweep: 0 = burst streams, one flag per member behind a drain barrier, 1 = per-step streams + per-wave flags (DEP_LSTM_SE overrides) */
+#define DEP_FWD_SX_DEFAULT 1            /* the fused GRU forward's hand-off: 0 = acknowledgement wait + flag + poll, 1 = the exchanged words are their own flag (sentinel slots) (DEP_FWD_SX overrides) */
 #define DEP_FWD_DF_DEFAULT 0           /* the fused GRU forward with direct fragment loads (gru2_fwd_df, rnn_fused2.hip); DEP_FWD_DF overrides */
 #define DEP_FUSED2_BWD_DEFAULT 1      /* both GRU layers' BPTT as one all-gather launch (rnn_fused2_bwd.hip); DEP_FUSED2_BWD overrides */
 bool dep_cluster_lstm_bwd_pk_ok(int T);

@@ -66,7 +66,17 @@ __device__ __forceinline__ float2 add2(float2 a, float2 b) { return make_float2(
 // cost the launch 4 % (profiles/r04_ab_pairs.txt).
 // BF (bf16-storage mode, implies SV16): h, dropout(h) and hn are written as bf16 too (2-byte elements at the same positions of their
 // arrays); the recurrence itself is unchanged -- the exchanged h words keep both split planes.
-template <bool DROP, bool TRACE, bool SV16, bool BF = false>
+// SX (round 5, after lstm_fwd_cluster's DF = 3): the exchanged words are their own flag.  A step's hand-off used to be: payload stores
+// acknowledged -> workgroup barrier -> flag store -> every wave polls the eight flags -> gather loads -- three L2 round trips and a flag's
+// flight in a row.  Now a member publishes into one of FOUR slots (step s -> slot s % 4) whose words hold a SENTINEL until they are written
+// (0xffffffff: split_word() of a finite h never is; a NaN is published as 0x7fc07fc0; the mask byte's sentinel is 0xff, its values are 0..3)
+// and the gather simply loads its pieces until none of their words is the sentinel: no acknowledgement wait, no flag, no poll.  With step
+// s's words a member re-arms its words of slot (s + 2) % 4 (they held step s-2: every member finished gathering that before it published
+// step s-1, which this member needed to gate step s); that store is acknowledged before the member's next publish is issued (the gather
+// loop's vmcnt(0)), and nobody loads slot (s + 2) % 4 for step s+2 before having gathered this member's step s+1 -- a gather never meets
+// a slot's previous tenant.  The slots are armed in the prologue, in front of the hello rendezvous (which SX therefore always runs).
+constexpr unsigned FX_SENT = 0xffffffffu;
+template <bool DROP, bool TRACE, bool SV16, bool BF = false, bool SX = false>
 __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     static_assert(!BF || SV16, "bf16 storage implies 16-bit gates");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -126,8 +136,26 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
     unsigned* myflag = p.flags + bt * FNC + c;
     unsigned* tflags = p.flags + bt * FNC;
+    if constexpr (SX) {
+        // arm this member's words of all four slots (write-through: the placement is not known yet); the hello below is the rendezvous
+        if (grp < 2) {
+            const int l0 = tid & 63, j0 = l0 & 15, ul0 = jl * 16 + (l0 >> 4) * 4 + 2 * kh;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const unsigned pb = (unsigned)sl * pstride + tile_base;
+                __hip_atomic_store((gu64*)(p.payload + (pb + (unsigned)(grp == 0 ? 0 : 2) * F_REGION + j0 * FH + c * 32 + ul0)), ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (DROP && grp == 0) {
+                    typedef __attribute__((address_space(1))) unsigned char gu8;
+                    __hip_atomic_store((gu8*)(reinterpret_cast<unsigned char*>(p.payload + (pb + (unsigned)F_REGION)) + j0 * (FH / 2) + c * 16 + (ul0 >> 1)), (unsigned char)0xff,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     // (with a fallback the hello also runs under DEP_CLUSTER_NOFAST: it is what proves that every member is resident)
-    const int sxh = (p.nofast && !p.soft) ? 0 : cluster_same_xcd(p.hello + bt * FNC, FNC, c, p.status, p.soft);
+    const int sxh = (p.nofast && !p.soft && !SX) ? 0 : cluster_same_xcd(p.hello + bt * FNC, FNC, c, p.status, p.soft);
     const int sx = (p.nofast && sxh >= 0) ? 0 : sxh;
     if (sx < 0) return;
     if (p.soft && p.force_soft == 3 && c == FNC - 1 && bt == 0) { if (threadIdx.x == 0) st_agent(p.soft, 1); return; }
@@ -292,7 +320,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         FSTAMP(1);
         bar_lds();                                        // groups 0/1: #1 of step s (partial sums in LDS) | group 2: #2 of step s
         FSTAMP(2);
-        const unsigned pbase = (unsigned)(s & 1) * pstride + tile_base;
+        const unsigned pbase = (unsigned)(SX ? (s & 3) : (s & 1)) * pstride + tile_base;
         if (grp == 2) {                                   // ---- slot Y of group 2 (the others are polling / gathering); placed before the gate block so that
                                                           // the accumulators' live range does not span it
             if (act) {
@@ -352,9 +380,23 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             const float2 hd = f2(h.x * st1[0], h.y * st1[1]);
             if (s <= T) {                                 // publish first: it is on the other members' critical path
                 gu64* dst = (gu64*)(p.payload + (pbase + (unsigned)(grp == 0 ? 0 : 2) * F_REGION + j * FH + c * 32 + ul));
-                const u64 bits = (u64)split_word(h.x) | ((u64)split_word(h.y) << 32);
+                unsigned w0 = split_word(h.x), w1 = split_word(h.y);
+                if constexpr (SX) { if (w0 == FX_SENT) w0 = 0x7fc07fc0u; if (w1 == FX_SENT) w1 = 0x7fc07fc0u; }       // (NaN inputs only) never the sentinel
+                const u64 bits = (u64)w0 | ((u64)w1 << 32);
                 if (fast) __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (SX) {                       // re-arm the slot two steps ahead
+                    const unsigned rb = (unsigned)((s + 2) & 3) * pstride + tile_base;
+                    gu64* rdst = (gu64*)(p.payload + (rb + (unsigned)(grp == 0 ? 0 : 2) * F_REGION + j * FH + c * 32 + ul));
+                    if (fast) __hip_atomic_store(rdst, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store(rdst, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (DROP && grp == 0) {
+                        typedef __attribute__((address_space(1))) unsigned char gu8;
+                        gu8* rm = (gu8*)(reinterpret_cast<unsigned char*>(p.payload + (rb + (unsigned)F_REGION)) + j * (FH / 2) + c * 16 + (ul >> 1));
+                        if (fast) __hip_atomic_store(rm, (unsigned char)0xff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else __hip_atomic_store(rm, (unsigned char)0xff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (DROP && grp == 0) {
                     // the mask bits of this lane's unit pair: byte [utterance j][pair (32 c + ul) / 2] of the second payload block
                     typedef __attribute__((address_space(1))) unsigned char gu8;
@@ -391,10 +433,10 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         }
         if (grp < 2 && s == T + 1) break;
         FSTAMP(3);
-        if (grp < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // payload stores acknowledged
+        if (!SX && grp < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // payload stores acknowledged (SX: nobody waits for that)
         FSTAMP(4);
         bar_lds();                                        // groups 0/1: #2 (every publishing wave drained) | group 2: #3
-        if (tid == 0) { if (fast) st_local(myflag, (unsigned)s + 1u); else st_agent(myflag, (unsigned)s + 1u); }
+        if (!SX && tid == 0) { if (fast) st_local(myflag, (unsigned)s + 1u); else st_agent(myflag, (unsigned)s + 1u); }
         if (grp == 2) {
             // slot Z of group 2 (groups 0 / 1 are in their MFMAs: nothing latency-critical uses the CU's memory pipeline now, and
             // a CU returns loads in issue order across its waves -- DESIGN 4.1c): the member's HBM streams.  Write-out of step s,
@@ -408,12 +450,13 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             issue_gi(tv, s + 2);
         } else {
             FSTAMP(5);
-            if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6, p.soft)) return;      // every wave polls (one poller + a verdict barrier measured no faster)
+            if constexpr (!SX) { if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6, p.soft)) return; }      // every wave polls (one poller + a verdict barrier measured no faster)
             FSTAMP(6);
             // gather: h0_s (next layer-0 step; also layer 1's input when there is no dropout) and h1_{s-2} (next layer-1 step)
             const bool need0 = s < T, need2 = s >= 2;    // (h0_{T-1} is still layer 1's last input)
             u32x4 v[2][2];
             unsigned mk[2] = {0u, 0u};                    // DROP: the four mask bits of the piece's units (two bytes: pairs col0 / 2, col0 / 2 + 1)
+            for (unsigned spins = 0;; ++spins) {          // (SX: until no word is the sentinel; otherwise one pass)
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
                 if (rg == 0 ? need0 : need2) {
@@ -426,6 +469,17 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                         }
                     }
                 }
+            }
+            if constexpr (!SX) break;
+            else {
+                unsigned mx = 0u;                         // max over the requested words: all-ones <=> one of them is still the sentinel
+                if (need0) { mx = max(max(max(v[0][0].x, v[0][0].y), max(v[0][0].z, v[0][0].w)), max(max(v[0][1].x, v[0][1].y), max(v[0][1].z, v[0][1].w)));
+                             if (DROP && ((mk[0] | mk[1]) & 0xfcfcu)) mx = FX_SENT; }
+                if (need2) mx = max(mx, max(max(max(v[1][0].x, v[1][0].y), max(v[1][0].z, v[1][0].w)), max(max(v[1][1].x, v[1][1].y), max(v[1][1].z, v[1][1].w))));
+                if (!__any(mx == FX_SENT)) break;
+                if (spins > SPIN_LIMIT) { st_agent(p.status, 6); return; }
+                if ((spins & 63) == 63 && (ld_agent(p.status) != 0 || (p.soft && ld_agent(p.soft) != 0))) return;
+            }
             }
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
@@ -809,7 +863,7 @@ bool dep_fused2_ok(int cell, int H, int L, int dirs) {
 size_t dep_fused2_xbuf_bytes(int B) {
     const int CH = dep_cluster_chunk(FNC, 1, 256);
     const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
-    const size_t a = (size_t)2 * nbtp * 3 * F_REGION * sizeof(float), b = (size_t)nbtp * FNC * (3 * DF_MB0 + 2 * DF_MB1);      // gather form / direct-fragment form
+    const size_t a = (size_t)4 * nbtp * 3 * F_REGION * sizeof(float), b = (size_t)nbtp * FNC * (3 * DF_MB0 + 2 * DF_MB1);      // gather form (four slots: SX) / direct-fragment form
     return PAYLOAD_OFF + (a > b ? a : b) + 4096;
 }
 
@@ -829,7 +883,7 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     DEP_CHECK_ARG(!drop || a.y0d == a.y0 + a.ostride);
     if (a.training) for (int k = 0; k < 4; ++k)
         DEP_CHECK_ARG(a.sv[0][k] == a.y0 + (size_t)(k + (drop ? 2 : 1)) * a.ostride && a.sv[1][k] == a.y1 + (size_t)(k + 1) * a.ostride);
-    const size_t pay = (size_t)2 * nbtp_max * 3 * F_REGION * sizeof(float);
+    const size_t pay = (size_t)4 * nbtp_max * 3 * F_REGION * sizeof(float);      // four slots (SX; the flag form uses two)
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * FNC <= 256);
     DEP_CHECK_ARG(!drop || a.y0d);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
@@ -844,9 +898,12 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; } p.force_soft = fs; }
     static bool attr = false;
     if (!attr) {
-#define F2_ATTR(D, TR, X) (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<D, TR, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES)
+#define F2_ATTR(D, TR, X) do { (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<D, TR, X, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES); \
+                               (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<D, TR, X, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES); } while (0)
         (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
         F2_ATTR(true, false, false); F2_ATTR(false, false, false); F2_ATTR(true, true, false); F2_ATTR(false, true, false);
         F2_ATTR(true, false, true); F2_ATTR(false, false, true); F2_ATTR(true, true, true); F2_ATTR(false, true, true);
 #undef F2_ATTR
@@ -886,16 +943,23 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
         }
         return DEP_OK;
     }
+    // round 5: the sentinel hand-off (SX above).  DEP_FWD_SX=0: acknowledgement wait + flag + poll.
+    static int sx = -1;
+    if (sx < 0) { const char* e = getenv("DEP_FWD_SX"); sx = e ? (e[0] == '1' ? 1 : 0) : DEP_FWD_SX_DEFAULT; }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, 0, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(FNC * p.nbtp), blk(FTHREADS);
-#define F2_LAUNCH(D, TR) do { if (sv16) hipLaunchKernelGGL((gru2_fwd_fused<D, TR, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
+#define F2_LAUNCH(D, TR) do { if (sx) { if (sv16) hipLaunchKernelGGL((gru2_fwd_fused<D, TR, true, false, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
+                                        else hipLaunchKernelGGL((gru2_fwd_fused<D, TR, false, false, true>), grid, blk, F_LDS_BYTES, a.stream, p); } \
+                              else if (sv16) hipLaunchKernelGGL((gru2_fwd_fused<D, TR, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
                               else hipLaunchKernelGGL((gru2_fwd_fused<D, TR, false>), grid, blk, F_LDS_BYTES, a.stream, p); } while (0)
         if (bf) {                                         // bf16-storage mode (never traced)
-            if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+            if (sx) { if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, false, true, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+                      else hipLaunchKernelGGL((gru2_fwd_fused<false, false, true, true, true>), grid, blk, F_LDS_BYTES, a.stream, p); }
+            else if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
             else hipLaunchKernelGGL((gru2_fwd_fused<false, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
         } else if (p.trace) {                             // DEP_TRACE=1: the stamped variant (tools/trace_fused.py)
             if (drop) F2_LAUNCH(true, true); else F2_LAUNCH(false, true);

@@ -46,6 +46,17 @@ def test_paired_weight_gradient_launch_leaves_every_gradient_bit_identical(tmp_p
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
 
 
+# Round 5: the fused GRU forward's hand-off without flags (gru2_fwd_fused<.., SX>: the exchanged words are their own flag, four sentinel-armed
+# slots).  Nothing of the arithmetic changes: pooled output and -- through the reserve -- every gradient bit-identical to the flag form.
+@pytest.mark.parametrize('B,T,F,dx', [(416, 20, 64, False), (160, 6, 256, True), (512, 300, 256, False)])
+def test_sentinel_handoff_of_the_fused_forward_is_bit_identical_to_the_flag_form(tmp_path, B, T, F, dx):
+    a = _run(tmp_path, 'a', 1, B, T, F, dx, env={'DEP_FWD_SX': '0'})
+    b = _run(tmp_path, 'b', 1, B, T, F, dx, env={'DEP_FWD_SX': '1'})
+    for k in a.files:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+
+
 # the BiLSTM-128 x2 stack (both directions in one launch; the reverse direction's step pairs are rows (ka, ka + 1)): B = 416 -> 26 tiles x 2
 # directions, burst phases 0..3 again; cfg3's full shape once
 @pytest.mark.parametrize('B,T,F,dx', [(416, 20, 64, True), (416, 22, 1024, False), (512, 300, 1024, False)])

@@ -32,6 +32,8 @@ CASES = [
     ('gru', 8, {'DEP_BWD_AG': '0', 'DEP_FUSED2_BWD': '0'}, []),                          # round 5: the default backward exchange is the all-gather of gate gradients; 0 = the reduce-scatter of fp32 partials
     ('gru', 6, {'DEP_BWD_AG': '0', 'DEP_FUSED2_BWD': '0'}, ['--load', '--load-phase', 'bwd']),
     ('gru', 6, {'DEP_FWD_DF': '1'}, []),                          # opt-in direct-fragment fused forward
+    ('gru', 6, {'DEP_FWD_SX': '0'}, []),                          # round 5: the fused forward's hand-off is the sentinel form by default; 0 = acknowledgement wait + flag + poll
+    ('gru', 6, {'DEP_FWD_SX': '0'}, ['--load', '--load-m', '1024', '--two-refs']),
     ('gru', 8, {'DEP_BWD_BURST': '0', 'DEP_FUSED2_BWD': '0'}, []),                       # round-1 backward schedule (no service waves)
     ('gru', 8, {'DEP_BWD_BURST': '6', 'DEP_FUSED2_BWD': '0'}, ['--load', '--load-phase', 'bwd']),   # longer bursts, with a co-scheduled kernel
     ('gru', 6, {'DEP_BWD_BURST': '4', 'DEP_NUM_CUS': '200'}, ['--H', '128']),
@@ -145,6 +147,16 @@ def test_direct_fragment_forward_passes_the_kernel_parity_suite():
     opt-in DEP_FWD_DF=1 -- measured slower than the gather form, profiles/r05_s8_*) stays parity-green: the GRU part of the RNN-stack
     suite against the oracle."""
     e = dict(os.environ, DEP_FWD_DF='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
+                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+
+
+def test_flag_handoff_forward_passes_the_kernel_parity_suite():
+    """Round 5: gru2_fwd_fused<.., SX = false> (payload acknowledged -> barrier -> flag -> poll -> gather; DEP_FWD_SX=0) stays parity-green
+    beside the sentinel hand-off that is the default now: the GRU part of the RNN-stack suite against the oracle."""
+    e = dict(os.environ, DEP_FWD_SX='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -18,14 +18,15 @@ for i in 1 2 3; do python bench.py --no-cpu-baseline --no-other-workloads --prof
 { echo "== fused two-layer backward (rnn_fused2_bwd.hip), tools/trace_fbwd.py"; DEP_TRACE=1 python tools/trace_fbwd.py 2>&1 | grep -v amdgpu.ids;
   echo "== per-layer all-gather backward sweep (DEP_FUSED2_BWD=0), tools/trace_bwd.py"; DEP_TRACE=1 DEP_FUSED2_BWD=0 python tools/trace_bwd.py 2>&1 | grep -v amdgpu.ids;
   echo "== per-layer reduce-scatter backward sweep (DEP_FUSED2_BWD=0 DEP_BWD_AG=0)"; DEP_TRACE=1 DEP_FUSED2_BWD=0 DEP_BWD_AG=0 python tools/trace_bwd.py 2>&1 | grep -v amdgpu.ids; } > $out/trace_bwd.txt 2>&1
-{ echo "== fused two-layer forward (rnn_fused2.hip gru2_fwd_fused), tools/trace_fused.py"; DEP_TRACE=1 python tools/trace_fused.py 2>&1 | grep -v amdgpu.ids; } > $out/trace_fwd.txt 2>&1
-{ for df in 2 1 0; do echo "== BiLSTM-128 forward sweep, layer 0 of cfg3's T and B (rnn_cluster_lstm.hip), DEP_LSTM_DF=$df, tools/trace_lstm.py"; DEP_TRACE=1 DEP_LSTM_DF=$df python tools/trace_lstm.py 2>&1 | grep -v amdgpu.ids; done
+{ echo "== fused two-layer forward (rnn_fused2.hip gru2_fwd_fused, sentinel hand-off = default), tools/trace_fused.py"; DEP_TRACE=1 python tools/trace_fused.py 2>&1 | grep -v amdgpu.ids;
+  echo "== the same with DEP_FWD_SX=0 (acknowledgement wait + flag + poll)"; DEP_TRACE=1 DEP_FWD_SX=0 python tools/trace_fused.py 2>&1 | grep -v amdgpu.ids; } > $out/trace_fwd.txt 2>&1
+{ for df in 3 2 1 0; do echo "== BiLSTM-128 forward sweep, layer 0 of cfg3's T and B (rnn_cluster_lstm.hip), DEP_LSTM_DF=$df, tools/trace_lstm.py"; DEP_TRACE=1 DEP_LSTM_DF=$df python tools/trace_lstm.py 2>&1 | grep -v amdgpu.ids; done
   for se in 1 0; do echo "== BiLSTM-128 backward sweep, DEP_LSTM_SE=$se, tools/trace_lstm.py bwd"; DEP_TRACE=1 DEP_LSTM_SE=$se python tools/trace_lstm.py bwd 2>&1 | grep -v amdgpu.ids; done; } > $out/trace_lstm.txt 2>&1
 { echo "== A/B of the round's switches, full train step (bench.py --profile-run), same session";
-  for env in "" "DEP_FUSED2_BWD=0" "DEP_FUSED2_BWD=0 DEP_BWD_AG=0" "DEP_DW_PAIR=0" "DEP_FUSED2_BWD=0 DEP_BWD_AG=0 DEP_DW_PAIR=0" "DEP_FWD_DF=1" ""; do
+  for env in "" "DEP_FUSED2_BWD=0" "DEP_FUSED2_BWD=0 DEP_BWD_AG=0" "DEP_DW_PAIR=0" "DEP_FUSED2_BWD=0 DEP_BWD_AG=0 DEP_DW_PAIR=0" "DEP_FWD_DF=1" "DEP_FWD_SX=0" ""; do
     echo "-- ${env:-default}"; env $env python bench.py --no-cpu-baseline --no-other-workloads --profile-run 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['kernels_ms_per_step'])"; done;
   echo "== cfg3 (--workload text_bilstm)";
-  for env in "" "DEP_LSTM_DF=0 DEP_LSTM_SE=0" "DEP_LSTM_DF=1 DEP_LSTM_SE=0" "DEP_LSTM_DF=0" "DEP_LSTM_SE=0" ""; do
+  for env in "" "DEP_LSTM_DF=0 DEP_LSTM_SE=0" "DEP_LSTM_DF=1 DEP_LSTM_SE=0" "DEP_LSTM_DF=2" "DEP_LSTM_DF=0" "DEP_LSTM_SE=0" ""; do
     echo "-- ${env:-default}"; env $env python bench.py --workload text_bilstm --no-cpu-baseline --no-other-workloads --profile-run 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['kernels_ms_per_step'])"; done;
   echo "== fusion (--workload fusion)";
   for env in "" "DEP_LSTM_DF=0 DEP_LSTM_SE=0" ""; do
