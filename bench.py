@@ -97,7 +97,7 @@ def build_workload(name, dev, rank, world):
     torch.manual_seed(0)
     g = torch.Generator(device='cpu'); g.manual_seed(1234 + rank)
     y = torch.randint(0, 2, (B,), generator=g).to(dev)
-    out = {'mod': mod, 'B': B, 'T': T, 'F': F, 'H': H}
+    out = {'mod': mod, 'B': B, 'T': T, 'F': F, 'H': H, 'y': y}
     if name == 'fusion':
         cfg = dict(mod.config); cfg.update(audio_embed_size=F, audio_hidden_dims=H, text_embed_size=1024, text_hidden_dims=128)
         model = mod.fusion_net(cfg['text_embed_size'], cfg['text_hidden_dims'], cfg['rnn_layers'], cfg['dropout'],

@@ -98,6 +98,8 @@ _SIGS = {
     'dep_vlad_normalize': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     'dep_profile_enable': (C.c_int, [C.c_int]),
     'dep_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
+    'dep_instance_log_enable': (C.c_int, [C.c_int]),
+    'dep_instance_log_read': (C.c_long, [C.c_char_p, C.c_long, C.c_int]),
     'dep_fill': (C.c_int, [_P, C.c_long, C.c_float, _P]),
     'dep_axpby': (C.c_int, [_P, _P, C.c_long, C.c_float, C.c_float, _P]),
     'dep_sigmoid_gate': (C.c_int, [_P, _P, _P, C.c_long, _P]),
@@ -487,6 +489,19 @@ class Rnn:
 
 
 PROF_CATS = ('gru_fwd_sweep', 'gru_bwd_sweep', 'lstm_fwd_sweep', 'lstm_bwd_sweep', 'gemm_nt', 'gemm_nn', 'gemm_tn')
+
+
+def instance_log_enable(on=True):
+    load().dep_instance_log_enable(int(on))
+
+
+def instance_log_read(reset=False):
+    """Set of kernel template instances launched since the log was enabled (dep_instance_log_read)."""
+    lib = load()
+    n = lib.dep_instance_log_read(None, 0, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.dep_instance_log_read(buf, n + 1, int(reset))
+    return set(l for l in buf.value.decode().split('\n') if l)
 
 
 def profile_enable(on=True):

@@ -6,6 +6,8 @@
 #include <string.h>
 #include <atomic>
 #include <mutex>
+#include <set>
+#include <string>
 #include <utility>
 #include <vector>
 #include "dep_common.h"
@@ -68,6 +70,43 @@ extern "C" int dep_profile_read(double* total_ms, int* counts, int ncat) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : recs) g_pool.push_back({r.a, r.b});
     return DEP_OK;
+}
+
+// ---- launch-instance log (DEP_LAUNCH, dep_common.h) ------------------------------------------------
+namespace {
+std::atomic<bool> g_ilog_on{false};
+std::mutex g_ilog_mu;
+std::set<std::string> g_ilog;
+}  // namespace
+bool dep_ilog_on() { return g_ilog_on.load(std::memory_order_relaxed); }
+void dep_ilog_note(const char* kern, const char* where) {
+    std::string k(kern);
+    // the kernel as written is enough when it names every template argument; launchers that are templates themselves
+    // (kernel<TA, TB, ..>) are told apart by their own signature
+    bool symbolic = false;
+    for (size_t i = 0; i + 1 < k.size(); ++i)
+        if ((k[i] == '<' || k[i] == ' ' ) && k[i + 1] >= 'A' && k[i + 1] <= 'Z') symbolic = true;
+    if (symbolic) { k += " @ "; k += where; }
+    std::lock_guard<std::mutex> lk(g_ilog_mu);
+    g_ilog.insert(std::move(k));
+}
+extern "C" int dep_instance_log_enable(int on) {
+    if (on) { std::lock_guard<std::mutex> lk(g_ilog_mu); g_ilog.clear(); }
+    g_ilog_on.store(on != 0);
+    return DEP_OK;
+}
+// Newline-separated distinct launch instances recorded so far -> buf (NUL-terminated, truncated to cap); returns the bytes the
+// full list needs (incl. the NUL).  reset != 0 empties the log afterwards.
+extern "C" long dep_instance_log_read(char* buf, long cap, int reset) {
+    std::lock_guard<std::mutex> lk(g_ilog_mu);
+    std::string all;
+    for (const auto& s : g_ilog) { all += s; all += '\n'; }
+    if (buf && cap > 0) {
+        const long n = (long)all.size() < cap - 1 ? (long)all.size() : cap - 1;
+        memcpy(buf, all.data(), (size_t)n); buf[n] = 0;
+    }
+    if (reset) g_ilog.clear();
+    return (long)all.size() + 1;
 }
 
 namespace {

@@ -235,9 +235,9 @@ int dep_attn2_fwd(const float* out, const float* pre, float* ctx, float* alpha, 
 #define GO(HQ)                                                                                                   \
     do {                                                                                                         \
         if (cache) { allow_lds(attn_fwd2_kernel<HQ, true>, lds);                                                 \
-                     hipLaunchKernelGGL((attn_fwd2_kernel<HQ, true>), dim3(B), dim3(AT), lds, s, out, pre, ctx, alpha, T); } \
+                     DEP_LAUNCH((attn_fwd2_kernel<HQ, true>), dim3(B), dim3(AT), lds, s, out, pre, ctx, alpha, T); } \
         else { allow_lds(attn_fwd2_kernel<HQ, false>, lds);                                                      \
-               hipLaunchKernelGGL((attn_fwd2_kernel<HQ, false>), dim3(B), dim3(AT), lds, s, out, pre, ctx, alpha, T); }      \
+               DEP_LAUNCH((attn_fwd2_kernel<HQ, false>), dim3(B), dim3(AT), lds, s, out, pre, ctx, alpha, T); }      \
     } while (0)
     if (H == 64) GO(16); else if (H == 128) GO(32); else GO(64);
 #undef GO
@@ -256,9 +256,9 @@ int dep_attn2_bwd(const float* dctx, const float* out, const float* alpha, const
 #define GO(HQ)                                                                                                   \
     do {                                                                                                         \
         if (cache) { allow_lds(attn_bwd2_kernel<HQ, true>, lds);                                                 \
-                     hipLaunchKernelGGL((attn_bwd2_kernel<HQ, true>), dim3(B), dim3(AT), lds, s, dctx, out, alpha, pre, dout, dpre, T); } \
+                     DEP_LAUNCH((attn_bwd2_kernel<HQ, true>), dim3(B), dim3(AT), lds, s, dctx, out, alpha, pre, dout, dpre, T); } \
         else { allow_lds(attn_bwd2_kernel<HQ, false>, lds);                                                      \
-               hipLaunchKernelGGL((attn_bwd2_kernel<HQ, false>), dim3(B), dim3(AT), lds, s, dctx, out, alpha, pre, dout, dpre, T); }      \
+               DEP_LAUNCH((attn_bwd2_kernel<HQ, false>), dim3(B), dim3(AT), lds, s, dctx, out, alpha, pre, dout, dpre, T); }      \
     } while (0)
     if (H == 64) GO(16); else if (H == 128) GO(32); else GO(64);
 #undef GO

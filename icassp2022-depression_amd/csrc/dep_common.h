@@ -81,6 +81,19 @@ __device__ __forceinline__ void dep_xcd_tile(int gx, int gy, int gz, int& bx, in
     bx = id % gx; by = (id / gx) % gy; bz = id / (gx * gy);
 }
 
+// ---- launch-instance log (dep_instance_log_*, include/dep_rnn.h) ------------------------------------
+// Every kernel launch of the library goes through DEP_LAUNCH: while the log is on it records the kernel expression as written at the
+// launch site plus the enclosing function's signature (which carries the template arguments of templated launchers), once per distinct
+// pair.  tests/test_instance_coverage_gpu.py uses it to tie the template instances a bench.py step launches to the ones the
+// oracle-comparing tests launched.  Off (the default): one relaxed atomic load per launch.
+bool dep_ilog_on();
+void dep_ilog_note(const char* kern, const char* where);
+#define DEP_LAUNCH(kern, grid, blk, lds, stream, ...)                                          \
+    do {                                                                                       \
+        if (dep_ilog_on()) dep_ilog_note(#kern, __PRETTY_FUNCTION__);                          \
+        hipLaunchKernelGGL(kern, grid, blk, lds, stream, __VA_ARGS__);                         \
+    } while (0)
+
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
 enum { DEP_PROF_GRU_FWD = 0, DEP_PROF_GRU_BWD = 1, DEP_PROF_LSTM_FWD = 2, DEP_PROF_LSTM_BWD = 3,
        DEP_PROF_GEMM_NT = 4, DEP_PROF_GEMM_NN = 5, DEP_PROF_GEMM_TN = 6, DEP_PROF_NCAT = 7 };
@@ -105,14 +118,6 @@ int dep_gemm_tn_pair(int M, int N, int K, const float* A0, const float* A1, int 
                      float* C0, int ldc0, float* C1, int ldc1, void* ws, size_t ws_bytes, hipStream_t s);
 int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A0, const float* A1, int lda, int skip_at1, int skip_by1,
                                    const float* B0, int ldb0, int seq_T0, int shift0, const float* B1, int ldb1, int seq_T1, int shift1,
-                                   float* C0, int ldc0, float* C1, int ldc1, int splits, int kchunk, float* part0, float* part1, hipStream_t s);
-void dep_gemm_set_split_target(long target);      // split-K target of this thread's next contractions (0 = default); gemm.hip
-// dW_ih + dW_hh of a GRU layer in one launch (shared PK A operand; gemm.hip): 1 = enqueued, 0 = not covered, < 0 = error
-int dep_gemm_tn_pair(int M, int N, int K, const float* A, int lda, int skip_at1, int skip_by1, const float* B0, int ldb0,
-                     const float* B1, int ldb1, int seq_T1, int shift1, float* C0, int ldc0, float* C1, int ldc1,
-                     void* ws, size_t ws_bytes, hipStream_t s);
-int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A, int lda, int skip_at1, int skip_by1,
-                                   const float* B0, int ldb0, const float* B1, int ldb1, int seq_T1, int shift1,
                                    float* C0, int ldc0, float* C1, int ldc1, int splits, int kchunk, float* part0, float* part1, hipStream_t s);
 // process-wide: may dep_rnn_forward use kernels that need every CU to themselves (dep_rnn_set_exclusive, include/dep_rnn.h)
 bool dep_exclusive_on();

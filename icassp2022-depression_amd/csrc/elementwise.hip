@@ -492,10 +492,10 @@ extern "C" int dep_layernorm_fwd(const float* x, const float* gamma, const float
     DEP_CHECK_ARG(x && y && rows > 0 && F > 0 && ((gamma != nullptr) == (beta != nullptr)));
     const bool al16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
     const dim3 g(dep_cdiv(rows, 4)), b(256);
-    if (al16 && F == 256) hipLaunchKernelGGL(ln_fwd_vec_kernel<1>, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, eps);
-    else if (al16 && F == 512) hipLaunchKernelGGL(ln_fwd_vec_kernel<2>, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, eps);
-    else if (al16 && F == 1024) hipLaunchKernelGGL(ln_fwd_vec_kernel<4>, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, eps);
-    else hipLaunchKernelGGL(ln_fwd_kernel, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, F, eps);
+    if (al16 && F == 256) DEP_LAUNCH(ln_fwd_vec_kernel<1>, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, eps);
+    else if (al16 && F == 512) DEP_LAUNCH(ln_fwd_vec_kernel<2>, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, eps);
+    else if (al16 && F == 1024) DEP_LAUNCH(ln_fwd_vec_kernel<4>, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, eps);
+    else DEP_LAUNCH(ln_fwd_kernel, g, b, 0, S_, x, gamma, beta, y, mean_rstd, rows, F, eps);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -503,7 +503,7 @@ extern "C" int dep_layernorm_fwd(const float* x, const float* gamma, const float
 extern "C" int dep_ln_fold_fwd(const float* W, const float* b, const float* gamma, const float* beta, float* Wf,
                                float* bf, int J, int F, void* stream) {
     DEP_CHECK_ARG(W && b && gamma && beta && Wf && bf && J > 0 && F > 0);
-    hipLaunchKernelGGL(ln_fold_fwd_kernel, dim3(dep_cdiv(J, 4)), dim3(256), 0, S_, W, b, gamma, beta, Wf, bf, J, F);
+    DEP_LAUNCH(ln_fold_fwd_kernel, dim3(dep_cdiv(J, 4)), dim3(256), 0, S_, W, b, gamma, beta, Wf, bf, J, F);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -511,7 +511,7 @@ extern "C" int dep_ln_fold_fwd(const float* W, const float* b, const float* gamm
 extern "C" int dep_ln_fold_bwd(const float* W, const float* dWf, const float* dbf, const float* gamma, const float* beta,
                                float* dW, float* db, float* dgamma, float* dbeta, int J, int F, void* stream) {
     DEP_CHECK_ARG(W && dWf && dbf && gamma && beta && dW && db && dgamma && dbeta && J > 0 && F > 0);
-    hipLaunchKernelGGL(ln_fold_bwd_kernel, dim3(dep_cdiv(F, LFC)), dim3(1024), 0, S_, W, dWf, dbf, gamma, beta, dW, db, dgamma, dbeta, J, F);
+    DEP_LAUNCH(ln_fold_bwd_kernel, dim3(dep_cdiv(F, LFC)), dim3(1024), 0, S_, W, dWf, dbf, gamma, beta, dW, db, dgamma, dbeta, J, F);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -531,14 +531,14 @@ extern "C" int dep_layernorm_bwd(const float* dy, const float* x, const float* g
         dep_set_error("dep_layernorm_bwd: workspace too small"); return DEP_ERR_WORKSPACE;
     }
     const int rpb = dep_cdiv(rows, nb);
-    hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(nb), dim3(256), 0, S_, dy, x, mean_rstd, (float*)workspace, rows, F, rpb);
+    DEP_LAUNCH(ln_bwd_param_kernel, dim3(nb), dim3(256), 0, S_, dy, x, mean_rstd, (float*)workspace, rows, F, rpb);
     DEP_CHECK_LAUNCH();
     // partial is [nb][2F]: column sums of its two halves (parallel over row groups, unlike the old serial finish)
-    hipLaunchKernelGGL(colsum_kernel, dim3(dep_cdiv(F, 64)), dim3(256), 0, S_, (const float*)workspace, nb, F, 2 * F, dgamma);
-    hipLaunchKernelGGL(colsum_kernel, dim3(dep_cdiv(F, 64)), dim3(256), 0, S_, (const float*)workspace + F, nb, F, 2 * F, dbeta);
+    DEP_LAUNCH(colsum_kernel, dim3(dep_cdiv(F, 64)), dim3(256), 0, S_, (const float*)workspace, nb, F, 2 * F, dgamma);
+    DEP_LAUNCH(colsum_kernel, dim3(dep_cdiv(F, 64)), dim3(256), 0, S_, (const float*)workspace + F, nb, F, 2 * F, dbeta);
     DEP_CHECK_LAUNCH();
     if (dx) {
-        hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(dep_cdiv(rows, 4)), dim3(256), 0, S_, dy, x, gamma, mean_rstd, dx, rows, F);
+        DEP_LAUNCH(ln_bwd_dx_kernel, dim3(dep_cdiv(rows, 4)), dim3(256), 0, S_, dy, x, gamma, mean_rstd, dx, rows, F);
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
@@ -547,35 +547,35 @@ extern "C" int dep_layernorm_bwd(const float* dy, const float* x, const float* g
 extern "C" int dep_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint32_t site, void* stream) {
     DEP_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f);
     if (p == 0.f) {
-        if (x != y) hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n)), dim3(256), 0, S_, x, y, n, 1.0f, 0.0f);
+        if (x != y) DEP_LAUNCH(axpby_kernel, dim3(nblk(n)), dim3(256), 0, S_, x, y, n, 1.0f, 0.0f);
     } else {
-        hipLaunchKernelGGL(dropout_kernel, dim3(nblk(n)), dim3(256), 0, S_, x, y, n, p, 1.0f / (1.0f - p), seed, site);
+        DEP_LAUNCH(dropout_kernel, dim3(nblk(n)), dim3(256), 0, S_, x, y, n, p, 1.0f / (1.0f - p), seed, site);
     }
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_dropout_mask(float* mask, long n, float p, uint64_t seed, uint32_t site, void* stream) {
     DEP_CHECK_ARG(mask && n > 0 && p >= 0.f && p < 1.f);
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(nblk(n)), dim3(256), 0, S_, mask, n, p, 1.0f / (1.0f - p), seed, site);
+    DEP_LAUNCH(dropout_mask_kernel, dim3(nblk(n)), dim3(256), 0, S_, mask, n, p, 1.0f / (1.0f - p), seed, site);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_relu_dropout_fwd(const float* z, float* a, long n, float p, uint64_t seed, uint32_t site, void* stream) {
     DEP_CHECK_ARG(z && a && n > 0 && p >= 0.f && p < 1.f);
-    hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(nblk(n)), dim3(256), 0, S_, z, a, n, p, 1.0f / (1.0f - p), seed, site);
+    DEP_LAUNCH(relu_dropout_fwd_kernel, dim3(nblk(n)), dim3(256), 0, S_, z, a, n, p, 1.0f / (1.0f - p), seed, site);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_relu_dropout_bwd(const float* da, const float* z, float* dz, long n, float p, uint64_t seed,
                                     uint32_t site, void* stream) {
     DEP_CHECK_ARG(da && z && dz && n > 0 && p >= 0.f && p < 1.f);
-    hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(nblk(n)), dim3(256), 0, S_, da, z, dz, n, p, 1.0f / (1.0f - p), seed, site);
+    DEP_LAUNCH(relu_dropout_bwd_kernel, dim3(nblk(n)), dim3(256), 0, S_, da, z, dz, n, p, 1.0f / (1.0f - p), seed, site);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_colsum(const float* x, int M, int N, int ld, float* out, void* stream) {
     DEP_CHECK_ARG(x && out && M > 0 && N > 0 && ld >= N);
-    hipLaunchKernelGGL(colsum_kernel, dim3(dep_cdiv(N, 64)), dim3(256), 0, S_, x, M, N, ld, out);
+    DEP_LAUNCH(colsum_kernel, dim3(dep_cdiv(N, 64)), dim3(256), 0, S_, x, M, N, ld, out);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -584,13 +584,13 @@ extern "C" int dep_head_loss(int kind, const float* z, const void* target, float
     DEP_CHECK_ARG(z && B > 0 && C > 0 && C <= MAXC && (kind & ~DEP_LOSS_LABELS_I64) >= 0 && (kind & ~DEP_LOSS_LABELS_I64) <= 4 && norm > 0.f);
     DEP_CHECK_ARG(!(kind & DEP_LOSS_LABELS_I64) || (kind & ~DEP_LOSS_LABELS_I64) == DEP_LOSS_CE_ON_SOFTMAX || (kind & ~DEP_LOSS_LABELS_I64) == DEP_LOSS_CE_LOGITS);
     DEP_CHECK_ARG(target || (!dz && !loss_rows));
-    hipLaunchKernelGGL(head_loss_kernel, dim3(nblk(B, 128)), dim3(128), 0, S_, kind, z, target, out, loss_rows, dz, B, C, 1.0f / norm);
+    DEP_LAUNCH(head_loss_kernel, dim3(nblk(B, 128)), dim3(128), 0, S_, kind, z, target, out, loss_rows, dz, B, C, 1.0f / norm);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_reduce_loss(const float* loss_rows, int B, float norm, float* loss_out, int accumulate, void* stream) {
     DEP_CHECK_ARG(loss_rows && loss_out && B > 0 && norm > 0.f);
-    hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, S_, loss_rows, B, 1.0f / norm, loss_out, accumulate);
+    DEP_LAUNCH(reduce_loss_kernel, dim3(1), dim3(256), 0, S_, loss_rows, B, 1.0f / norm, loss_out, accumulate);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -601,14 +601,14 @@ extern "C" int dep_adam_step(float* p, const float* g, float* m, float* v, long 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, S_, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+    DEP_LAUNCH(adam_kernel, dim3(nblk(n)), dim3(256), 0, S_, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                        decoupled, step_size, inv_sqrt_bc2);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_fill(float* p, long n, float value, void* stream) {
     DEP_CHECK_ARG(p && n > 0);
-    hipLaunchKernelGGL(fill_kernel, dim3(nblk(n)), dim3(256), 0, S_, p, n, value);
+    DEP_LAUNCH(fill_kernel, dim3(nblk(n)), dim3(256), 0, S_, p, n, value);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -624,20 +624,20 @@ int dep_multi_copy(int count, const float* const* src, const float* const* add, 
     }
     j.count = count;
     int gx = dep_cdiv(mx, 256 * 4); if (gx > 512) gx = 512; if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(multi_copy_kernel, dim3(gx, count), dim3(256), 0, s, j);
+    DEP_LAUNCH(multi_copy_kernel, dim3(gx, count), dim3(256), 0, s, j);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 
 extern "C" int dep_axpby(const float* x, float* y, long n, float a, float b, void* stream) {
     DEP_CHECK_ARG(x && y && n > 0);
-    hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n)), dim3(256), 0, S_, x, y, n, a, b);
+    DEP_LAUNCH(axpby_kernel, dim3(nblk(n)), dim3(256), 0, S_, x, y, n, a, b);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_sigmoid_gate(const float* g, const float* x, float* y, long n, void* stream) {
     DEP_CHECK_ARG(g && x && y && n > 0);
-    hipLaunchKernelGGL(sigmoid_gate_kernel, dim3(nblk(n)), dim3(256), 0, S_, g, x, y, n);
+    DEP_LAUNCH(sigmoid_gate_kernel, dim3(nblk(n)), dim3(256), 0, S_, g, x, y, n);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -646,27 +646,27 @@ extern "C" int dep_gather_rows(const float* src, const long long* idx, float* ds
     DEP_CHECK_ARG(src && idx && dst && nrows > 0 && row_floats > 0 && nrows <= 65535);
     const int vec = (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (row_floats & 3) == 0) ? 1 : 0;
     int gx = dep_cdiv(vec ? row_floats >> 2 : row_floats, 256); if (gx > 64) gx = 64; if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, (unsigned)nrows), dim3(256), 0, S_, src, idx, dst, row_floats, vec);
+    DEP_LAUNCH(gather_rows_kernel, dim3(gx, (unsigned)nrows), dim3(256), 0, S_, src, idx, dst, row_floats, vec);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_copy2d(const float* src, long lds, float* dst, long ldd, long rows, long cols, void* stream) {
     DEP_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols);
     int gx = nblk(rows * cols); if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(copy2d_kernel, dim3(gx), dim3(256), 0, S_, src, lds, dst, ldd, rows, cols);
+    DEP_LAUNCH(copy2d_kernel, dim3(gx), dim3(256), 0, S_, src, lds, dst, ldd, rows, cols);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_loss_accumulate(const float* loss, const unsigned* status, const unsigned* soft, double* acc, void* stream) {
     DEP_CHECK_ARG(acc && (loss || status || soft));
-    hipLaunchKernelGGL(loss_accumulate_kernel, dim3(1), dim3(64), 0, S_, loss, status, soft, acc);
+    DEP_LAUNCH(loss_accumulate_kernel, dim3(1), dim3(64), 0, S_, loss, status, soft, acc);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 extern "C" int dep_argmax_count(const float* p, const void* labels, int labels_i64, int B, int C, long long* count,
                                 long long* pred, void* stream) {
     DEP_CHECK_ARG(p && B > 0 && C > 0 && (count || pred) && (!count || labels));
-    hipLaunchKernelGGL(argmax_count_kernel, dim3(1), dim3(256), 0, S_, p, labels, labels_i64, B, C, count, pred);
+    DEP_LAUNCH(argmax_count_kernel, dim3(1), dim3(256), 0, S_, p, labels, labels_i64, B, C, count, pred);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -675,13 +675,13 @@ extern "C" int dep_attn_fwd(const float* out, const float* h_n, int K, const flo
                             float* alpha, float* pre, float* hsum, int B, int T, int H, void* stream) {
     DEP_CHECK_ARG(out && h_n && Wa && ba && ctx && alpha && pre && hsum && B > 0 && T > 0 && H > 0 && K > 0);
     const long BH = (long)B * H;
-    hipLaunchKernelGGL(attn_hsum_kernel, dim3(nblk(BH)), dim3(256), 0, S_, h_n, K, BH, hsum);
+    DEP_LAUNCH(attn_hsum_kernel, dim3(nblk(BH)), dim3(256), 0, S_, h_n, K, BH, hsum);
     DEP_CHECK_LAUNCH();
     int rc = dep_gemm_internal(0, 1, B, H, H, hsum, H, Wa, H, pre, H, ba, 0.f, 0, 0, nullptr, 0, S_);
     if (rc) return rc;
     if (!dep_attn2_fwd(out, pre, ctx, alpha, B, T, H, S_)) {
         const size_t lds = (size_t)(H + T + 16) * sizeof(float);
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), lds, S_, out, pre, ctx, alpha, T, H);
+        DEP_LAUNCH(attn_fwd_kernel, dim3(B), dim3(256), lds, S_, out, pre, ctx, alpha, T, H);
     }
     DEP_CHECK_LAUNCH();
     return DEP_OK;
@@ -705,7 +705,7 @@ extern "C" int dep_attn_bwd(const float* dctx, const float* out, const float* Wa
     const size_t gws_bytes = workspace_bytes - dep_align((size_t)2 * B * H * sizeof(float));
     if (!dep_attn2_bwd(dctx, out, alpha, pre, dout, dpre, B, T, H, S_)) {
         const size_t lds = (size_t)(2 * H + 2 * T + 16) * sizeof(float);
-        hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(256), lds, S_, dctx, out, alpha, pre, dout, dpre, T, H);
+        DEP_LAUNCH(attn_bwd_kernel, dim3(B), dim3(256), lds, S_, dctx, out, alpha, pre, dout, dpre, T, H);
     }
     DEP_CHECK_LAUNCH();
     // dWa (H,H) = dpre^T (H,B) * hsum (B,H) ; dba = colsum(dpre) ; dhsum = dpre * Wa
@@ -716,7 +716,7 @@ extern "C" int dep_attn_bwd(const float* dctx, const float* out, const float* Wa
     rc = dep_gemm_internal(0, 0, B, H, H, dpre, H, Wa, H, dhs, H, nullptr, 0.f, 0, 0, nullptr, 0, S_);
     if (rc) return rc;
     const long BH = (long)B * H;
-    hipLaunchKernelGGL(attn_bcast_kernel, dim3(nblk(BH)), dim3(256), 0, S_, dhs, K, BH, dh_n);
+    DEP_LAUNCH(attn_bcast_kernel, dim3(nblk(BH)), dim3(256), 0, S_, dhs, K, BH, dh_n);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

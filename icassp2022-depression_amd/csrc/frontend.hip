@@ -73,7 +73,7 @@ extern "C" int dep_frame_window(const float* y, long n, int n_fft, int hop, int 
     DEP_CHECK_ARG(y && out && n > n_fft / 2 && n_fft > 0 && hop > 0 && n_frames > 0);
     DEP_CHECK_ARG((long)(n_frames - 1) * hop + n_fft <= n + n_fft);      // the last frame ends inside the padded signal
     const long tot = (long)n_frames * n_fft;
-    hipLaunchKernelGGL(frame_window_kernel, dim3(dep_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, y, n, n_fft, hop, n_frames, out);
+    DEP_LAUNCH(frame_window_kernel, dim3(dep_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, y, n, n_fft, hop, n_frames, out);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -81,28 +81,28 @@ extern "C" int dep_frame_window(const float* y, long n, int n_fft, int hop, int 
 extern "C" int dep_power_spectrum(const float* reim, int rows, int bins, int ld, float* power, void* stream) {
     DEP_CHECK_ARG(reim && power && rows > 0 && bins > 0 && ld >= 2 * bins);
     const long tot = (long)rows * bins;
-    hipLaunchKernelGGL(power_kernel, dim3(dep_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, reim, rows, bins, ld, power);
+    DEP_LAUNCH(power_kernel, dim3(dep_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, reim, rows, bins, ld, power);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 
 extern "C" int dep_log_floor(const float* x, float* y, long n, float floor_value, void* stream) {
     DEP_CHECK_ARG(x && y && n > 0 && floor_value > 0.f);
-    hipLaunchKernelGGL(log_floor_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, floor_value);
+    DEP_LAUNCH(log_floor_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, floor_value);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 
 extern "C" int dep_row_softmax(const float* z, float* p, int rows, int C, void* stream) {
     DEP_CHECK_ARG(z && p && rows > 0 && C > 0 && C <= 64);
-    hipLaunchKernelGGL(row_softmax_kernel, dim3(dep_cdiv(rows, 128)), dim3(128), 0, (hipStream_t)stream, z, p, rows, C);
+    DEP_LAUNCH(row_softmax_kernel, dim3(dep_cdiv(rows, 128)), dim3(128), 0, (hipStream_t)stream, z, p, rows, C);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 
 extern "C" int dep_vlad_normalize(const float* vkf, const float* a_sum, const float* w2, float* out, int F, int K, void* stream) {
     DEP_CHECK_ARG(vkf && a_sum && w2 && out && F > 0 && K > 0 && (size_t)(F * K + K + 1) * sizeof(float) <= 64 * 1024);
-    hipLaunchKernelGGL(vlad_normalize_kernel, dim3(1), dim3(256), (size_t)(F * K + K + 1) * sizeof(float), (hipStream_t)stream,
+    DEP_LAUNCH(vlad_normalize_kernel, dim3(1), dim3(256), (size_t)(F * K + K + 1) * sizeof(float), (hipStream_t)stream,
                        vkf, a_sum, w2, out, F, K);
     DEP_CHECK_LAUNCH();
     return DEP_OK;

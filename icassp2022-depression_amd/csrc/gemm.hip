@@ -371,7 +371,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     }
     if (naive_forced()) {
         dim3 g(dep_cdiv(N, 128), M);
-        hipLaunchKernelGGL(gemm_naive, g, dim3(128), 0, s, p, transA, transB);
+        DEP_LAUNCH(gemm_naive, g, dim3(128), 0, s, p, transA, transB);
         DEP_CHECK_LAUNCH();
         return DEP_OK;
     }
@@ -379,7 +379,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
         SmallP q{M, N, K, A, transA ? 1L : (long)lda, transA ? (long)lda : 1L, B, transB ? 1L : (long)ldb,
                  transB ? (long)ldb : 1L, C, ldc, bias, beta, dep_gemm_predicate()};
         DepProfScope prof(transA ? DEP_PROF_GEMM_TN : (transB ? DEP_PROF_GEMM_NT : DEP_PROF_GEMM_NN), s, dep_gemm_predicate() == nullptr);
-        hipLaunchKernelGGL(gemm_small, dim3(dep_cdiv(N, 32), dep_cdiv(M, 32)), dim3(256), 0, s, q);
+        DEP_LAUNCH(gemm_small, dim3(dep_cdiv(N, 32), dep_cdiv(M, 32)), dim3(256), 0, s, q);
         DEP_CHECK_LAUNCH();
         return DEP_OK;
     }
@@ -409,8 +409,8 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
                                       splits, kchunk, p.part, vec, s, (g_force_exact != 2 && g_split_mode >= 2) ? 1 : 3);     // the public bf16x3 entry is always 3 terms
 #define LAUNCH(TA, TB)                                                                    \
     do {                                                                                   \
-        if (vec) hipLaunchKernelGGL((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \
-        else     hipLaunchKernelGGL((gemm_mfma<TA, TB, false>), g, dim3(NT), 0, s, p);     \
+        if (vec) DEP_LAUNCH((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \
+        else     DEP_LAUNCH((gemm_mfma<TA, TB, false>), g, dim3(NT), 0, s, p);     \
     } while (0)
     if (!transA && transB) LAUNCH(false, true);
     else if (!transA && !transB) LAUNCH(false, false);
@@ -419,7 +419,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     DEP_CHECK_LAUNCH();
     if (splits > 1) {
         const long n = (long)M * N;
-        hipLaunchKernelGGL(splitk_reduce, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, p.only_if, p.part, splits, M, N, C, ldc,
+        DEP_LAUNCH(splitk_reduce, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, p.only_if, p.part, splits, M, N, C, ldc,
                            bias, beta);
         DEP_CHECK_LAUNCH();
     }

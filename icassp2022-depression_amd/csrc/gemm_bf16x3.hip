@@ -817,8 +817,8 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
         if (!attr) { WS_ATTR(2); WS_ATTR(3); WS_ATTR(4); attr = true; }
 #undef WS_ATTR
 #undef WS_ATTR1
-#define WS_L1(TA, TB, DD) do { if (vec) hipLaunchKernelGGL((gemm_bf16x3_ws<TA, TB, true, DD>), g, dim3(WS_NT), WS_LDS_BYTES, s, p); \
-                               else     hipLaunchKernelGGL((gemm_bf16x3_ws<TA, TB, false, DD>), g, dim3(WS_NT), WS_LDS_BYTES, s, p); } while (0)
+#define WS_L1(TA, TB, DD) do { if (vec) DEP_LAUNCH((gemm_bf16x3_ws<TA, TB, true, DD>), g, dim3(WS_NT), WS_LDS_BYTES, s, p); \
+                               else     DEP_LAUNCH((gemm_bf16x3_ws<TA, TB, false, DD>), g, dim3(WS_NT), WS_LDS_BYTES, s, p); } while (0)
 #define WS_L(TA, TB) do { if (wsd == 2) WS_L1(TA, TB, 2); else if (wsd == 4) WS_L1(TA, TB, 4); else WS_L1(TA, TB, 3); } while (0)
         if (!transA && transB) WS_L(false, true);
         else if (!transA && !transB) WS_L(false, false);
@@ -828,7 +828,7 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
         DEP_CHECK_LAUNCH();
         if (splits > 1) {
             const long n = (long)M * N;
-            hipLaunchKernelGGL(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, dep_gemm_predicate(), part, splits, M, N, C, ldc, bias, beta);
+            DEP_LAUNCH(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, dep_gemm_predicate(), part, splits, M, N, C, ldc, bias, beta);
             DEP_CHECK_LAUNCH();
         }
         return DEP_OK;
@@ -851,14 +851,14 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     dim3 g((per_xcd < cap / 8 ? per_xcd : cap / 8) * 8);
 #define LAUNCH1(TA, TB, TERMS)                                                                       \
     do {                                                                                             \
-        if (big) { if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, 256, TERMS>), g, dim3(NT), 0, s, p);      \
-                   else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false, 256, TERMS>), g, dim3(NT), 0, s, p); }   \
-        else     { if (vec) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, 128, TERMS>), g, dim3(NT), 0, s, p);      \
-                   else     hipLaunchKernelGGL((gemm_bf16x3<TA, TB, false, 128, TERMS>), g, dim3(NT), 0, s, p); }   \
+        if (big) { if (vec) DEP_LAUNCH((gemm_bf16x3<TA, TB, true, 256, TERMS>), g, dim3(NT), 0, s, p);      \
+                   else     DEP_LAUNCH((gemm_bf16x3<TA, TB, false, 256, TERMS>), g, dim3(NT), 0, s, p); }   \
+        else     { if (vec) DEP_LAUNCH((gemm_bf16x3<TA, TB, true, 128, TERMS>), g, dim3(NT), 0, s, p);      \
+                   else     DEP_LAUNCH((gemm_bf16x3<TA, TB, false, 128, TERMS>), g, dim3(NT), 0, s, p); }   \
     } while (0)
 #define LAUNCH(TA, TB) do { if (terms == 1) LAUNCH1(TA, TB, 1); else LAUNCH1(TA, TB, 3); } while (0)
-#define LAUNCH_PK(TA, TB, BM, FA_, FB_) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, BM, 3, FA_, FB_>), g, dim3(NT), 0, s, p)
-#define LAUNCH_H(TA, TB, BM, FB_) hipLaunchKernelGGL((gemm_bf16x3<TA, TB, true, BM, 1, FMT_PKH, FB_>), g, dim3(NT), 0, s, p)
+#define LAUNCH_PK(TA, TB, BM, FA_, FB_) DEP_LAUNCH((gemm_bf16x3<TA, TB, true, BM, 3, FA_, FB_>), g, dim3(NT), 0, s, p)
+#define LAUNCH_H(TA, TB, BM, FB_) DEP_LAUNCH((gemm_bf16x3<TA, TB, true, BM, 1, FMT_PKH, FB_>), g, dim3(NT), 0, s, p)
     if (fa == FMT_PKH) {
         if (transA) {
             if (big) { if (fb == FMT_BF16) LAUNCH_H(true, false, 256, FMT_BF16); else LAUNCH_H(true, false, 256, FMT_F32); }
@@ -887,7 +887,7 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     DEP_CHECK_LAUNCH();
     if (splits > 1) {
         const long n = (long)M * N;
-        hipLaunchKernelGGL(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, dep_gemm_predicate(), part, splits, M, N, C, ldc, bias, beta);
+        DEP_LAUNCH(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, dep_gemm_predicate(), part, splits, M, N, C, ldc, bias, beta);
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
@@ -910,10 +910,10 @@ int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A0, const f
     const int cap = persist * 2 / 3 / 2;                          // two resident workgroups per CU with 256-row tiles, half of the slots per problem
     const int per_xcd = (ntiles + 7) / 8;
     dim3 g((per_xcd < cap / 8 ? per_xcd : cap / 8) * 8 * 2);
-    hipLaunchKernelGGL((gemm_bf16x3_tn_pair<true, 256, FMT_PK, FMT_F32>), g, dim3(NT), 0, s, p0, p1);
+    DEP_LAUNCH((gemm_bf16x3_tn_pair<true, 256, FMT_PK, FMT_F32>), g, dim3(NT), 0, s, p0, p1);
     DEP_CHECK_LAUNCH();
     const long n = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce2_pair, dim3(dep_cdiv(n, 256), 2), dim3(256), 0, s, part0, part1, splits, M, N, C0, ldc0, C1, ldc1);
+    DEP_LAUNCH(splitk_reduce2_pair, dim3(dep_cdiv(n, 256), 2), dim3(256), 0, s, part0, part1, splits, M, N, C0, ldc0, C1, ldc1);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

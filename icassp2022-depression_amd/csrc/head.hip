@@ -304,12 +304,12 @@ extern "C" int dep_head_mlp_fwd(const float* x, const float* W1, const float* b1
     HeadF q{x, W1, b1, W2, b2, a0, z1, a1, z2, B, Hin, H1, C, p, 1.0f / (1.0f - p), seed, site0, site1, first_dropout};
     const dim3 g(dep_cdiv(B, HR)), b(HT);
     switch (Hin / 8) {
-        case 1: hipLaunchKernelGGL(head_mlp_fwd_kernel<1>, g, b, 0, S_, q); break;
-        case 2: hipLaunchKernelGGL(head_mlp_fwd_kernel<2>, g, b, 0, S_, q); break;
-        case 4: hipLaunchKernelGGL(head_mlp_fwd_kernel<4>, g, b, 0, S_, q); break;
-        case 8: hipLaunchKernelGGL(head_mlp_fwd_kernel<8>, g, b, 0, S_, q); break;
-        case 16: hipLaunchKernelGGL(head_mlp_fwd_kernel<16>, g, b, 0, S_, q); break;
-        default: hipLaunchKernelGGL(head_mlp_fwd_kernel<32>, g, b, 0, S_, q); break;
+        case 1: DEP_LAUNCH(head_mlp_fwd_kernel<1>, g, b, 0, S_, q); break;
+        case 2: DEP_LAUNCH(head_mlp_fwd_kernel<2>, g, b, 0, S_, q); break;
+        case 4: DEP_LAUNCH(head_mlp_fwd_kernel<4>, g, b, 0, S_, q); break;
+        case 8: DEP_LAUNCH(head_mlp_fwd_kernel<8>, g, b, 0, S_, q); break;
+        case 16: DEP_LAUNCH(head_mlp_fwd_kernel<16>, g, b, 0, S_, q); break;
+        default: DEP_LAUNCH(head_mlp_fwd_kernel<32>, g, b, 0, S_, q); break;
     }
     DEP_CHECK_LAUNCH();
     return DEP_OK;
@@ -326,14 +326,14 @@ extern "C" int dep_head_mlp_bwd(const float* dz2, const float* a0, const float* 
     HeadB q{dz2, a0, z1, a1, W1, W2, dW1, db1, dW2, db2, dx, dz1, B, Hin, H1, C, p, 1.0f / (1.0f - p), seed, site0, site1, first_dropout};
     const dim3 g(dep_cdiv(B, HR)), b(HT);
     switch (H1 / 8) {
-        case 1: hipLaunchKernelGGL(head_mlp_bwd_rows_kernel<1>, g, b, 0, S_, q); break;
-        case 2: hipLaunchKernelGGL(head_mlp_bwd_rows_kernel<2>, g, b, 0, S_, q); break;
-        case 4: hipLaunchKernelGGL(head_mlp_bwd_rows_kernel<4>, g, b, 0, S_, q); break;
-        case 8: hipLaunchKernelGGL(head_mlp_bwd_rows_kernel<8>, g, b, 0, S_, q); break;
-        case 16: hipLaunchKernelGGL(head_mlp_bwd_rows_kernel<16>, g, b, 0, S_, q); break;
-        default: hipLaunchKernelGGL(head_mlp_bwd_rows_kernel<32>, g, b, 0, S_, q); break;
+        case 1: DEP_LAUNCH(head_mlp_bwd_rows_kernel<1>, g, b, 0, S_, q); break;
+        case 2: DEP_LAUNCH(head_mlp_bwd_rows_kernel<2>, g, b, 0, S_, q); break;
+        case 4: DEP_LAUNCH(head_mlp_bwd_rows_kernel<4>, g, b, 0, S_, q); break;
+        case 8: DEP_LAUNCH(head_mlp_bwd_rows_kernel<8>, g, b, 0, S_, q); break;
+        case 16: DEP_LAUNCH(head_mlp_bwd_rows_kernel<16>, g, b, 0, S_, q); break;
+        default: DEP_LAUNCH(head_mlp_bwd_rows_kernel<32>, g, b, 0, S_, q); break;
     }
-    hipLaunchKernelGGL(head_mlp_bwd_w_kernel, dim3(dep_cdiv(H1, JR) + dep_cdiv(C, JR)), b, 0, S_, q);
+    DEP_LAUNCH(head_mlp_bwd_w_kernel, dim3(dep_cdiv(H1, JR) + dep_cdiv(C, JR)), b, 0, S_, q);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

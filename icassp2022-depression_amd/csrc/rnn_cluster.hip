@@ -89,7 +89,7 @@ int dep_cluster_reset_flags(void* xbuf, hipStream_t s) {
 
 int dep_pack_cluster_bwd(const float* w_hh, float* out, int G, int H, hipStream_t s) {
     const long n = (long)G * H * H;
-    hipLaunchKernelGGL(pack_cluster_bwd_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, out, G, H);
+    DEP_LAUNCH(pack_cluster_bwd_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, out, G, H);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }

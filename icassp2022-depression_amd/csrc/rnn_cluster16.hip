@@ -462,7 +462,7 @@ __global__ void pack_cluster16_fwd_split_kernel(const float* __restrict__ W, u32
 
 int dep_pack_cluster16_fwd_split(const float* w_hh, float* out, int H, hipStream_t s) {
     const long n = (long)(H / 16) * 3 * 4 * (H / 128) * 64;
-    hipLaunchKernelGGL(pack_cluster16_fwd_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)out, H);
+    DEP_LAUNCH(pack_cluster16_fwd_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)out, H);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -478,7 +478,7 @@ bool dep_cluster16_ok(int cell, int H, int B) {
 
 int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s) {
     const long n = 3L * H * H;
-    hipLaunchKernelGGL(pack_cluster16_bwd_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, out, H);
+    DEP_LAUNCH(pack_cluster16_bwd_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, out, H);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -508,8 +508,8 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
-        if (a.split) hipLaunchKernelGGL((gru_fwd_cluster16<4, true>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
-        else hipLaunchKernelGGL((gru_fwd_cluster16<4, false>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
+        if (a.split) DEP_LAUNCH((gru_fwd_cluster16<4, true>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
+        else DEP_LAUNCH((gru_fwd_cluster16<4, false>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
@@ -539,7 +539,7 @@ int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbu
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
-        hipLaunchKernelGGL(gru_bwd_cluster16<4>, dim3(NC * p.nbtp), dim3(CT), lds, a.stream, p);
+        DEP_LAUNCH(gru_bwd_cluster16<4>, dim3(NC * p.nbtp), dim3(CT), lds, a.stream, p);
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;

@@ -950,21 +950,21 @@ int dep_pack_cluster_split_multi(int n, const float* const* src, float* const* d
     j.n = n;
     for (int k = 0; k < n; ++k) { DEP_CHECK_ARG(src[k] && dst[k]); j.src[k] = src[k]; j.dst[k] = (u32x4*)dst[k]; j.bwd[k] = bwd[k]; }
     const long nf = (long)(H / 16) * 3 * 2 * (H / 64) * 64, nb = (long)(H / 32) * (H / 16) * 3 * 64;
-    hipLaunchKernelGGL(pack_cluster_split_multi_kernel, dim3(dep_cdiv(nf > nb ? nf : nb, 256), n), dim3(256), 0, s, j, H);
+    DEP_LAUNCH(pack_cluster_split_multi_kernel, dim3(dep_cdiv(nf > nb ? nf : nb, 256), n), dim3(256), 0, s, j, H);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 
 int dep_pack_cluster_fwd_split(const float* w_hh, float* out, int H, hipStream_t s) {
     const long n = (long)(H / 16) * 3 * 2 * (H / 64) * 64;
-    hipLaunchKernelGGL(pack_cluster_fwd_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)out, H);
+    DEP_LAUNCH(pack_cluster_fwd_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)out, H);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
 
 int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s) {
     const long n = (long)(H / 32) * (H / 16) * 3 * 64;
-    hipLaunchKernelGGL(pack_cluster_bwd_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)out, H);
+    DEP_LAUNCH(pack_cluster_bwd_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)out, H);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -1007,8 +1007,8 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         dim3 grid(NC * p.nbtp);
 #define DEP_FWD_LAUNCH(K)                                                                                                 \
-        do { if (a.split) hipLaunchKernelGGL((gru_fwd_cluster_r1<K, true>), grid, dim3(CT), lds, a.stream, p);            \
-             else hipLaunchKernelGGL((gru_fwd_cluster_r1<K, false>), grid, dim3(CT), lds, a.stream, p); } while (0)
+        do { if (a.split) DEP_LAUNCH((gru_fwd_cluster_r1<K, true>), grid, dim3(CT), lds, a.stream, p);            \
+             else DEP_LAUNCH((gru_fwd_cluster_r1<K, false>), grid, dim3(CT), lds, a.stream, p); } while (0)
         switch (a.H) {                                // KCH = H / 32
             case 64: DEP_FWD_LAUNCH(2); break;
             case 128: DEP_FWD_LAUNCH(4); break;
@@ -1109,24 +1109,24 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         dim3 grid(NC * p.nbtp * (p.xhalf ? 2 : 1));
         const dim3 block(kb ? CT + SVC_THREADS : CT);
 #define DEP_BWD_LAUNCH1(N, S, X)                                                                                          \
-        do { if (kb == 4) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 4, X>), grid, block, lds, a.stream, p);            \
-             else if (kb == 6) hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 6, X>), grid, block, lds, a.stream, p);       \
-             else hipLaunchKernelGGL((gru_bwd_cluster_r1<N, S, 0, X>), grid, block, lds, a.stream, p); } while (0)
+        do { if (kb == 4) DEP_LAUNCH((gru_bwd_cluster_r1<N, S, 4, X>), grid, block, lds, a.stream, p);            \
+             else if (kb == 6) DEP_LAUNCH((gru_bwd_cluster_r1<N, S, 6, X>), grid, block, lds, a.stream, p);       \
+             else DEP_LAUNCH((gru_bwd_cluster_r1<N, S, 0, X>), grid, block, lds, a.stream, p); } while (0)
 #define DEP_BWD_LAUNCH(N, S) do { if (S && a.sv16) DEP_BWD_LAUNCH1(N, true, true); else DEP_BWD_LAUNCH1(N, S, false); } while (0)
         switch (a.H) {                                // NTW = H / 64
             case 64: if (a.split) DEP_BWD_LAUNCH(1, true); else DEP_BWD_LAUNCH(1, false); break;
             case 128: if (a.split) DEP_BWD_LAUNCH(2, true); else DEP_BWD_LAUNCH(2, false); break;
             case 256:
-                if (ag && a.bf16st) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, true, true>), grid, block, lds, a.stream, p);
-                else if (ag && a.sv16) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, false, true>), grid, block, lds, a.stream, p);
-                else if (ag) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, false, false, true>), grid, block, lds, a.stream, p);
-                else if (a.bf16st) hipLaunchKernelGGL((gru_bwd_cluster_r1<4, true, 4, true, true>), grid, block, lds, a.stream, p);
+                if (ag && a.bf16st) DEP_LAUNCH((gru_bwd_cluster_r1<4, true, 4, true, true, true>), grid, block, lds, a.stream, p);
+                else if (ag && a.sv16) DEP_LAUNCH((gru_bwd_cluster_r1<4, true, 4, true, false, true>), grid, block, lds, a.stream, p);
+                else if (ag) DEP_LAUNCH((gru_bwd_cluster_r1<4, true, 4, false, false, true>), grid, block, lds, a.stream, p);
+                else if (a.bf16st) DEP_LAUNCH((gru_bwd_cluster_r1<4, true, 4, true, true>), grid, block, lds, a.stream, p);
                 else if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false);
                 break;
             default:                                  // 512: round-1 schedule only (kb == 0)
-                if (a.split && a.sv16) hipLaunchKernelGGL((gru_bwd_cluster_r1<8, true, 0, true>), grid, block, lds, a.stream, p);
-                else if (a.split) hipLaunchKernelGGL((gru_bwd_cluster_r1<8, true, 0>), grid, block, lds, a.stream, p);
-                else hipLaunchKernelGGL((gru_bwd_cluster_r1<8, false, 0>), grid, block, lds, a.stream, p);
+                if (a.split && a.sv16) DEP_LAUNCH((gru_bwd_cluster_r1<8, true, 0, true>), grid, block, lds, a.stream, p);
+                else if (a.split) DEP_LAUNCH((gru_bwd_cluster_r1<8, true, 0>), grid, block, lds, a.stream, p);
+                else DEP_LAUNCH((gru_bwd_cluster_r1<8, false, 0>), grid, block, lds, a.stream, p);
                 break;
         }
 #undef DEP_BWD_LAUNCH1

@@ -1004,7 +1004,7 @@ __global__ void pack_lstm_split_kernel(const float* __restrict__ W, u32x4* __res
 
 int dep_pack_cluster_lstm_split(const float* w_hh, float* wp, float* wpT, int H, hipStream_t s) {
     const long n = (long)(H / 16) * 4 * 2 * (H / 64) * 64;
-    hipLaunchKernelGGL(pack_lstm_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)wp, (u32x4*)wpT, H);
+    DEP_LAUNCH(pack_lstm_split_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, (u32x4*)wp, (u32x4*)wpT, H);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -1068,17 +1068,17 @@ int dep_launch_cluster_lstm_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
         const bool sv16 = kb && a.split && a.sv16 && a.training;
-        if (df == 3) { if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true, 3>), grid, block, lds, a.stream, p);
-                       else hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, false, 3>), grid, block, lds, a.stream, p); }
-        else if (df == 2) { if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true, 2>), grid, block, lds, a.stream, p);
-                       else hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, false, 2>), grid, block, lds, a.stream, p); }
-        else if (df) { if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true, 1>), grid, block, lds, a.stream, p);
-                       else hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, false, 1>), grid, block, lds, a.stream, p); }
-        else if (sv16) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4, true>), grid, block, lds, a.stream, p);
-        else if (kb) { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 4>), grid, block, lds, a.stream, p);
-                  else hipLaunchKernelGGL((lstm_fwd_cluster<4, false, 4>), grid, block, lds, a.stream, p); }
-        else    { if (a.split) hipLaunchKernelGGL((lstm_fwd_cluster<4, true, 0>), grid, block, lds, a.stream, p);
-                  else hipLaunchKernelGGL((lstm_fwd_cluster<4, false, 0>), grid, block, lds, a.stream, p); }
+        if (df == 3) { if (sv16) DEP_LAUNCH((lstm_fwd_cluster<4, true, 4, true, 3>), grid, block, lds, a.stream, p);
+                       else DEP_LAUNCH((lstm_fwd_cluster<4, true, 4, false, 3>), grid, block, lds, a.stream, p); }
+        else if (df == 2) { if (sv16) DEP_LAUNCH((lstm_fwd_cluster<4, true, 4, true, 2>), grid, block, lds, a.stream, p);
+                       else DEP_LAUNCH((lstm_fwd_cluster<4, true, 4, false, 2>), grid, block, lds, a.stream, p); }
+        else if (df) { if (sv16) DEP_LAUNCH((lstm_fwd_cluster<4, true, 4, true, 1>), grid, block, lds, a.stream, p);
+                       else DEP_LAUNCH((lstm_fwd_cluster<4, true, 4, false, 1>), grid, block, lds, a.stream, p); }
+        else if (sv16) DEP_LAUNCH((lstm_fwd_cluster<4, true, 4, true>), grid, block, lds, a.stream, p);
+        else if (kb) { if (a.split) DEP_LAUNCH((lstm_fwd_cluster<4, true, 4>), grid, block, lds, a.stream, p);
+                  else DEP_LAUNCH((lstm_fwd_cluster<4, false, 4>), grid, block, lds, a.stream, p); }
+        else    { if (a.split) DEP_LAUNCH((lstm_fwd_cluster<4, true, 0>), grid, block, lds, a.stream, p);
+                  else DEP_LAUNCH((lstm_fwd_cluster<4, false, 0>), grid, block, lds, a.stream, p); }
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;
@@ -1142,13 +1142,13 @@ int dep_launch_cluster_lstm_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t 
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(a.dirs * NC * p.nbtp), block(kb ? CT + L_SVC : CT);
-        if (se) { if (a.sv16) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4, true, true>), grid, block, lds, a.stream, p);
-                  else hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4, false, true>), grid, block, lds, a.stream, p); }
-        else if (kb && a.split && a.sv16) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4, true>), grid, block, lds, a.stream, p);
-        else if (kb) { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 4>), grid, block, lds, a.stream, p);
-                  else hipLaunchKernelGGL((lstm_bwd_cluster<2, false, 4>), grid, block, lds, a.stream, p); }
-        else    { if (a.split) hipLaunchKernelGGL((lstm_bwd_cluster<2, true, 0>), grid, block, lds, a.stream, p);
-                  else hipLaunchKernelGGL((lstm_bwd_cluster<2, false, 0>), grid, block, lds, a.stream, p); }
+        if (se) { if (a.sv16) DEP_LAUNCH((lstm_bwd_cluster<2, true, 4, true, true>), grid, block, lds, a.stream, p);
+                  else DEP_LAUNCH((lstm_bwd_cluster<2, true, 4, false, true>), grid, block, lds, a.stream, p); }
+        else if (kb && a.split && a.sv16) DEP_LAUNCH((lstm_bwd_cluster<2, true, 4, true>), grid, block, lds, a.stream, p);
+        else if (kb) { if (a.split) DEP_LAUNCH((lstm_bwd_cluster<2, true, 4>), grid, block, lds, a.stream, p);
+                  else DEP_LAUNCH((lstm_bwd_cluster<2, false, 4>), grid, block, lds, a.stream, p); }
+        else    { if (a.split) DEP_LAUNCH((lstm_bwd_cluster<2, true, 0>), grid, block, lds, a.stream, p);
+                  else DEP_LAUNCH((lstm_bwd_cluster<2, false, 0>), grid, block, lds, a.stream, p); }
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;

@@ -934,9 +934,9 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
             { const int rc_h = hdr_prepare(xbuf, 0, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
             { const int rc_h = hdr_prepare(xbuf, 3, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
             const dim3 grid(FNC * pd.f.nbtp), blk(FTHREADS);
-#define DF_GO(D) do { if (bf) hipLaunchKernelGGL((gru2_fwd_df<D, true, true>), grid, blk, DF_LDS_BYTES, a.stream, pd); \
-                      else if (sv16) hipLaunchKernelGGL((gru2_fwd_df<D, true, false>), grid, blk, DF_LDS_BYTES, a.stream, pd); \
-                      else hipLaunchKernelGGL((gru2_fwd_df<D, false, false>), grid, blk, DF_LDS_BYTES, a.stream, pd); } while (0)
+#define DF_GO(D) do { if (bf) DEP_LAUNCH((gru2_fwd_df<D, true, true>), grid, blk, DF_LDS_BYTES, a.stream, pd); \
+                      else if (sv16) DEP_LAUNCH((gru2_fwd_df<D, true, false>), grid, blk, DF_LDS_BYTES, a.stream, pd); \
+                      else DEP_LAUNCH((gru2_fwd_df<D, false, false>), grid, blk, DF_LDS_BYTES, a.stream, pd); } while (0)
             if (drop) DF_GO(true); else DF_GO(false);
 #undef DF_GO
             DEP_CHECK_LAUNCH();
@@ -952,15 +952,15 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, 0, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(FNC * p.nbtp), blk(FTHREADS);
-#define F2_LAUNCH(D, TR) do { if (sx) { if (sv16) hipLaunchKernelGGL((gru2_fwd_fused<D, TR, true, false, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
-                                        else hipLaunchKernelGGL((gru2_fwd_fused<D, TR, false, false, true>), grid, blk, F_LDS_BYTES, a.stream, p); } \
-                              else if (sv16) hipLaunchKernelGGL((gru2_fwd_fused<D, TR, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
-                              else hipLaunchKernelGGL((gru2_fwd_fused<D, TR, false>), grid, blk, F_LDS_BYTES, a.stream, p); } while (0)
+#define F2_LAUNCH(D, TR) do { if (sx) { if (sv16) DEP_LAUNCH((gru2_fwd_fused<D, TR, true, false, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
+                                        else DEP_LAUNCH((gru2_fwd_fused<D, TR, false, false, true>), grid, blk, F_LDS_BYTES, a.stream, p); } \
+                              else if (sv16) DEP_LAUNCH((gru2_fwd_fused<D, TR, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
+                              else DEP_LAUNCH((gru2_fwd_fused<D, TR, false>), grid, blk, F_LDS_BYTES, a.stream, p); } while (0)
         if (bf) {                                         // bf16-storage mode (never traced)
-            if (sx) { if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, false, true, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
-                      else hipLaunchKernelGGL((gru2_fwd_fused<false, false, true, true, true>), grid, blk, F_LDS_BYTES, a.stream, p); }
-            else if (drop) hipLaunchKernelGGL((gru2_fwd_fused<true, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
-            else hipLaunchKernelGGL((gru2_fwd_fused<false, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+            if (sx) { if (drop) DEP_LAUNCH((gru2_fwd_fused<true, false, true, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+                      else DEP_LAUNCH((gru2_fwd_fused<false, false, true, true, true>), grid, blk, F_LDS_BYTES, a.stream, p); }
+            else if (drop) DEP_LAUNCH((gru2_fwd_fused<true, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+            else DEP_LAUNCH((gru2_fwd_fused<false, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
         } else if (p.trace) {                             // DEP_TRACE=1: the stamped variant (tools/trace_fused.py)
             if (drop) F2_LAUNCH(true, true); else F2_LAUNCH(false, true);
         } else {

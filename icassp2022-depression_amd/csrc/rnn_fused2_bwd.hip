@@ -573,17 +573,17 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
         { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
         { const int rc_h = hdr_prepare(xbuf, 1, false, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(BNC * p.nbtp), blk(BTHREADS);
-#define FB_GO(D, Y, S, P) hipLaunchKernelGGL((gru2_bwd_fused<D, Y, S, P>), grid, blk, fb_lds_bytes(S, Y, P), a.stream, p)
+#define FB_GO(D, Y, S, P) DEP_LAUNCH((gru2_bwd_fused<D, Y, S, P>), grid, blk, fb_lds_bytes(S, Y, P), a.stream, p)
 #define FB_GO4(S, P) do { if (drop) { if (a.dy) FB_GO(true, true, S, P); else FB_GO(true, false, S, P); } \
                           else      { if (a.dy) FB_GO(false, true, S, P); else FB_GO(false, false, S, P); } } while (0)
         if (bf) {                                     // bf16-storage mode (never traced)
-#define FB_GOB(D, Y) hipLaunchKernelGGL((gru2_bwd_fused<D, Y, true, true, false, true>), grid, blk, fb_lds_bytes(true, Y, true, true), a.stream, p)
+#define FB_GOB(D, Y) DEP_LAUNCH((gru2_bwd_fused<D, Y, true, true, false, true>), grid, blk, fb_lds_bytes(true, Y, true, true), a.stream, p)
             if (drop) { if (a.dy) FB_GOB(true, true); else FB_GOB(true, false); } else { if (a.dy) FB_GOB(false, true); else FB_GOB(false, false); }
 #undef FB_GOB
         }
         else if (p.trace && pk && !a.dy) {            // DEP_TRACE=1: the stamped variant (tools/trace_fbwd.py)
-            if (drop) hipLaunchKernelGGL((gru2_bwd_fused<true, false, true, true, true>), grid, blk, fb_lds_bytes(true, false, true), a.stream, p);
-            else hipLaunchKernelGGL((gru2_bwd_fused<false, false, true, true, true>), grid, blk, fb_lds_bytes(true, false, true), a.stream, p);
+            if (drop) DEP_LAUNCH((gru2_bwd_fused<true, false, true, true, true>), grid, blk, fb_lds_bytes(true, false, true), a.stream, p);
+            else DEP_LAUNCH((gru2_bwd_fused<false, false, true, true, true>), grid, blk, fb_lds_bytes(true, false, true), a.stream, p);
         }
         else if (pk) FB_GO4(true, true); else if (sv16) FB_GO4(true, false); else FB_GO4(false, false);
 #undef FB_GO4

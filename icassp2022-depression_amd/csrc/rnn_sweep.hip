@@ -649,7 +649,7 @@ size_t dep_pack_floats(int G, int H) { return (size_t)G * H * H; }
 
 int dep_pack_whh(const float* w_hh, float* wp, float* wpT, int G, int H, hipStream_t s) {
     const long n = (long)G * H * H;
-    hipLaunchKernelGGL(pack_whh_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, wp, wpT, G, H);
+    DEP_LAUNCH(pack_whh_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, wp, wpT, G, H);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -658,13 +658,13 @@ int dep_pack_whh(const float* w_hh, float* wp, float* wpT, int G, int H, hipStre
     do {                                                                                           \
         switch (jpw) {                                                                             \
             case 1: (void)hipFuncSetAttribute((const void*)kern<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)); \
-                    hipLaunchKernelGGL(kern<1>, grid, dim3(nthr), lds, s, P); break;               \
+                    DEP_LAUNCH(kern<1>, grid, dim3(nthr), lds, s, P); break;               \
             case 2: (void)hipFuncSetAttribute((const void*)kern<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)); \
-                    hipLaunchKernelGGL(kern<2>, grid, dim3(nthr), lds, s, P); break;               \
+                    DEP_LAUNCH(kern<2>, grid, dim3(nthr), lds, s, P); break;               \
             case 3: (void)hipFuncSetAttribute((const void*)kern<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)); \
-                    hipLaunchKernelGGL(kern<3>, grid, dim3(nthr), lds, s, P); break;               \
+                    DEP_LAUNCH(kern<3>, grid, dim3(nthr), lds, s, P); break;               \
             default: (void)hipFuncSetAttribute((const void*)kern<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)); \
-                    hipLaunchKernelGGL(kern<4>, grid, dim3(nthr), lds, s, P); break;               \
+                    DEP_LAUNCH(kern<4>, grid, dim3(nthr), lds, s, P); break;               \
         }                                                                                          \
     } while (0)
 
@@ -689,8 +689,8 @@ int dep_launch_sweep_fwd(const dep_sweep_args& a) {
     } else {
         dim3 grid(a.B, a.dirs);
         const size_t lds = (size_t)3 * a.H * sizeof(float);
-        if (a.cell == DEP_CELL_GRU) hipLaunchKernelGGL(gru_fwd_generic, grid, dim3(GEN_T), lds, a.stream, p);
-        else hipLaunchKernelGGL(lstm_fwd_generic, grid, dim3(GEN_T), lds, a.stream, p);
+        if (a.cell == DEP_CELL_GRU) DEP_LAUNCH(gru_fwd_generic, grid, dim3(GEN_T), lds, a.stream, p);
+        else DEP_LAUNCH(lstm_fwd_generic, grid, dim3(GEN_T), lds, a.stream, p);
     }
     DEP_CHECK_LAUNCH();
     return DEP_OK;
@@ -720,8 +720,8 @@ int dep_launch_sweep_bwd(const dep_sweep_bwd_args& a) {
     } else {
         dim3 grid(a.B, a.dirs);
         const size_t lds = (size_t)(G * a.H + 2 * a.H) * sizeof(float);
-        if (a.cell == DEP_CELL_GRU) hipLaunchKernelGGL(gru_bwd_generic, grid, dim3(GEN_T), lds, a.stream, p);
-        else hipLaunchKernelGGL(lstm_bwd_generic, grid, dim3(GEN_T), lds, a.stream, p);
+        if (a.cell == DEP_CELL_GRU) DEP_LAUNCH(gru_bwd_generic, grid, dim3(GEN_T), lds, a.stream, p);
+        else DEP_LAUNCH(lstm_bwd_generic, grid, dim3(GEN_T), lds, a.stream, p);
     }
     DEP_CHECK_LAUNCH();
     return DEP_OK;
@@ -732,7 +732,7 @@ int dep_finish_db(const dep_sweep_bwd_args& a, float* const* db_ih, float* const
     DEP_CHECK_ARG(a.dirs >= 1 && a.dbpart_rows >= a.dirs && a.dbpart_rows % a.dirs == 0);
     const int nwg = a.dbpart_rows / a.dirs;           // rows per direction the sweep that ran has written
     for (int d = 0; d < a.dirs; ++d) {
-        hipLaunchKernelGGL(finish_db_kernel, dim3(dep_cdiv(4 * a.H, 128)), dim3(128), 0, a.stream,
+        DEP_LAUNCH(finish_db_kernel, dim3(dep_cdiv(4 * a.H, 128)), dim3(128), 0, a.stream,
                            a.dbpart + (size_t)d * nwg * 4 * a.H, nwg, a.H, G, a.cell, db_ih[d], db_hh[d]);
         DEP_CHECK_LAUNCH();
     }

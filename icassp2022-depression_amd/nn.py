@@ -199,8 +199,9 @@ class Output:
 
 
 class Loss:
-    def __init__(self, value_dev, backward_fn, reduce=False, health=None):
+    def __init__(self, value_dev, backward_fn, reduce=False, health=None, dz=None):
         self._v = value_dev
+        self.dz = dz                        # dLoss/dz (B, C) the backward starts from (the tensor `backward_fn` reads), or None
         self._bw = backward_fn
         self._reduce = reduce               # data parallel: the local part of a global batch mean
         self._health = health               # model.check_health: the host sync below is where a failed sweep surfaces
@@ -328,7 +329,7 @@ class _HeadLoss:
         val = torch.empty(1, dtype=torch.float32, device=dev)         # dep_reduce_loss overwrites it
         L.reduce_loss(rows, norm, val)
         return Loss(val, (lambda: owner.backward(dz)) if train else None, reduce=train and parallel.world_size() > 1,
-                    health=getattr(owner, 'check_health', None))
+                    health=getattr(owner, 'check_health', None), dz=dz)
 
 
 class CrossEntropyLoss(_HeadLoss):

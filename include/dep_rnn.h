@@ -351,6 +351,14 @@ int dep_vlad_normalize(const float* vkf, const float* a_sum, const float* w2, fl
 int dep_profile_enable(int on);
 int dep_profile_read(double* total_ms, int* counts, int ncat);
 
+/* Launch-instance log (test infrastructure of the parity suite, tests/test_instance_coverage_gpu.py): while enabled, every
+ * kernel launch of the library records its template instance (kernel expression + launcher signature), once per distinct
+ * instance.  dep_instance_log_enable(1) clears and starts, (0) stops.  dep_instance_log_read copies the newline-separated
+ * list into buf (NUL-terminated, truncated to cap; buf may be NULL) and returns the bytes the full list needs; reset != 0
+ * empties the log afterwards.  Process-wide, thread-safe; one relaxed atomic load per launch when off. */
+int dep_instance_log_enable(int on);
+long dep_instance_log_read(char* buf, long cap, int reset);
+
 /* ------------------------------------------------------------------ misc ----------- */
 int dep_fill(float* p, long n, float value, void* stream);
 /* y = a*x + b*y */

@@ -11,6 +11,7 @@ from icassp2022_depression_amd import _lib as L  # noqa: E402
 
 out, B, T, F = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 want_dx = 'dx' in sys.argv[5:]
+nody = 'nody' in sys.argv[5:]                 # GRU: the training step's call form (dpooled only; AudioBiLSTM.backward) -> the HASDY = false instances
 lstm = 'lstm' in sys.argv[5:]                 # the BiLSTM-128 x2 stack of the text model instead of the GRU-256 x2 one
 H, Lyr, dirs, G = (128, 2, 2, 4) if lstm else (256, 2, 1, 3)
 dev = torch.device('cuda:0')
@@ -36,7 +37,7 @@ else:
     rnn = L.Rnn(L.CELL_GRU, B, T, F, H, Lyr, 1, True, 0.5, L.POOL_MEAN, dev)
     pooled = torch.empty(B, H, device=dev)
     rnn.forward(x, W, seed=11, pooled=pooled)
-    rnn.backward(x, W, Gd, dy=dy, dpooled=dpool, dx=dx)
+    rnn.backward(x, W, Gd, dy=None if nody else dy, dpooled=dpool, dx=dx)
 rnn.check()
 torch.cuda.synchronize()
 res = {'g%d' % i: t.cpu().numpy() for i, t in enumerate(Gd)}

@@ -41,6 +41,8 @@ def main():
     ap.add_argument('--load', action='store_true')
     ap.add_argument('--torch-load', action='store_true', help='the side-stream load is torch.matmul instead of dep_gemm_bf16x3')
     ap.add_argument('--fwd-only', action='store_true')
+    ap.add_argument('--model-form', action='store_true', help='GRU: the training step\'s gradient inputs (dpooled only, no dy, no dX): '
+                    'gru2_bwd_fused<.., HASDY = false, ..>, three input slots / prefetch distance 2')
     ap.add_argument('--load-phase', default='both', help='both | bwd : which half of the step the side-stream load overlaps')
     ap.add_argument('--load-kind', default='split', help='split | f32 | torch')
     ap.add_argument('--load-m', type=int, default=4096)
@@ -72,6 +74,7 @@ def main():
     pooled = torch.empty(B, H, device=dev) if a.cell == 'gru' else None
     h_n = torch.empty(Lyr * dirs, B, H, device=dev)
     dx = torch.empty(B, T, F, device=dev)
+    model_form = a.model_form and a.cell == 'gru'
 
     side = torch.cuda.Stream()
     stop = [False]
@@ -128,7 +131,9 @@ def main():
                 torch.cuda.synchronize()                    # the forward ran alone; the load overlaps the backward only
             load_burst(2 + it % 5)
         if not a.fwd_only:
-            rnn.backward(x, W, Gd, dy=dy, dpooled=dpool, dh_n=dhn, dx=dx)
+            rnn.backward(x, W, Gd, dy=None if model_form else dy, dpooled=dpool, dh_n=dhn, dx=None if model_form else dx)
+            if model_form:
+                dx.zero_()
         else:
             dx.zero_(); [t.zero_() for t in Gd]
         try:

@@ -6,7 +6,7 @@ import pytest
 from oracle import ref_numpy as R
 
 torch = pytest.importorskip('torch')
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.oracle]
 
 if torch.cuda.is_available():
     from icassp2022_depression_amd import _lib as L
@@ -262,8 +262,14 @@ def gemm_mode(request):
     L.set_gemm_mode(1, 1 << 28)
 
 
-@pytest.mark.parametrize('cell,B,T,F,H,impl', RNN_CASES)
-def test_rnn_stack_fwd_bwd(cell, B, T, F, H, impl, gemm_mode):
+# call forms (tests/test_fullsize_gpu.py): 'full' = dy + dpooled | dh_n in, dX out; 'model' = what the training step passes
+# (GRU: dpooled only, no dX -> the HASDY = false instances of the fused backward; BiLSTM: dy + dh_n, no dX).  The cluster kernels
+# (impl 3: what the models run) take both forms at every shape; the generic / single-workgroup kernels have one instance each.
+RNN_FORM_CASES = [c + ('full',) for c in RNN_CASES] + [c + ('model',) for c in RNN_CASES if c[5] == 3]
+
+
+@pytest.mark.parametrize('cell,B,T,F,H,impl,form', RNN_FORM_CASES)
+def test_rnn_stack_fwd_bwd(cell, B, T, F, H, impl, form, gemm_mode):
     rng = np.random.default_rng(B * 1000 + T * 100 + F + H + impl)
     Lyr = 2
     dirs = 1 if cell == 'gru' else 2
@@ -285,9 +291,13 @@ def test_rnn_stack_fwd_bwd(cell, B, T, F, H, impl, gemm_mode):
         assert np.abs(host(h_n)[-1] - yr[:, -1]).max() < 1e-4
         dpool = rng.standard_normal((B, H))
         dyv = rng.standard_normal((B, T, H)) * 0.3
-        dxd = torch.full((B, T, F), float('nan'), device=DEV)
-        rnn.backward(xd, Wd, Gd, dy=dev(dyv), dpooled=dev(dpool), dx=dxd)
-        dy_full = dyv.astype(np.float32).astype(np.float64) + dpool.astype(np.float32).astype(np.float64)[:, None, :] / T
+        dxd = torch.full((B, T, F), float('nan'), device=DEV) if form == 'full' else None
+        if form == 'full':
+            rnn.backward(xd, Wd, Gd, dy=dev(dyv), dpooled=dev(dpool), dx=dxd)
+            dy_full = dyv.astype(np.float32).astype(np.float64) + dpool.astype(np.float32).astype(np.float64)[:, None, :] / T
+        else:
+            rnn.backward(xd, Wd, Gd, dpooled=dev(dpool), dx=None)
+            dy_full = np.repeat(dpool.astype(np.float32).astype(np.float64)[:, None, :] / T, T, axis=1)
         dxr, Gr = R.gru_stack_bwd(dy_full, P, prefix, Lyr, caches)
     else:
         yr, hnr, caches = R.bilstm_stack_fwd(x, P, prefix, Lyr)
@@ -295,28 +305,39 @@ def test_rnn_stack_fwd_bwd(cell, B, T, F, H, impl, gemm_mode):
         assert np.abs(host(h_n) - hnr).max() < 1e-4
         dyv = rng.standard_normal((B, T, 2 * H)) * 0.3
         dhn = rng.standard_normal((Lyr * 2, B, H)) * 0.3
-        dxd = torch.full((B, T, F), float('nan'), device=DEV)
+        dxd = torch.full((B, T, F), float('nan'), device=DEV) if form == 'full' else None
         rnn.backward(xd, Wd, Gd, dy=dev(dyv), dh_n=dev(dhn), dx=dxd)
         dxr, Gr = R.bilstm_stack_bwd(dyv.astype(np.float32).astype(np.float64), dhn.astype(np.float32).astype(np.float64),
                                      P, prefix, Lyr, caches)
     rnn.check()
-    assert relerr(host(dxd), dxr) < 1e-4, 'dx'
+    if dxd is not None:
+        assert relerr(host(dxd), dxr) < 1e-4, 'dx'
     for n, g in zip(names, Gd):
         assert relerr(host(g), Gr[n]) < 1e-4, n
 
 
-@pytest.mark.parametrize('cell,impl,H', [('gru', 2, 16), ('gru', 1, 16), ('lstm', 2, 16), ('lstm', 1, 8), ('gru', 3, 128), ('lstm', 3, 128)])
-def test_rnn_interlayer_dropout_matches_oracle_with_same_masks(cell, impl, H):
-    """nn.GRU/LSTM(dropout=p) training mode: the oracle is fed the masks the HIP path drew."""
-    rng = np.random.default_rng(77 + impl + H)
-    B, T, F, Lyr, p, seed = 5, 9, 10, 2, 0.5, 1234
+@pytest.mark.parametrize('cell,impl,H,form,T', [
+    ('gru', 2, 16, 'full', 9), ('gru', 1, 16, 'full', 9), ('lstm', 2, 16, 'full', 9), ('lstm', 1, 8, 'full', 9), ('gru', 3, 128, 'full', 9),
+    ('lstm', 3, 128, 'full', 9),
+    # H = 256: the fused two-layer launches (forward and backward) with the mask draw, in both call forms and at the pipeline's edges
+    # (T = 2 / 3 / 4 / 6: layer 0 two fused steps behind layer 1; even T = PK step pairs, odd T = fp32 rows; model form = three input slots)
+    ('gru', 3, 256, 'full', 9), ('gru', 3, 256, 'model', 9), ('gru', 3, 256, 'model', 2), ('gru', 3, 256, 'model', 3), ('gru', 3, 256, 'model', 4),
+    ('gru', 3, 256, 'model', 6), ('gru', 3, 256, 'full', 6), ('gru', 3, 256, 'model', 20), ('gru', 3, 128, 'model', 9), ('lstm', 3, 128, 'model', 8)])
+def test_rnn_interlayer_dropout_matches_oracle_with_same_masks(cell, impl, H, form, T, gemm_mode):
+    """nn.GRU/LSTM(dropout=p) training mode: the oracle is fed the masks the HIP path drew.  form 'model' = the gradient inputs the
+    training step passes (GRU: dpooled of the mean pool only; BiLSTM: dy + dh_n)."""
+    rng = np.random.default_rng(77 + impl + H + T)
+    B, F, Lyr, p, seed = (37 if H == 256 else 5), 10, 2, 0.5, 1234
     dirs = 1 if cell == 'gru' else 2
     P, names, prefix = make_rnn_params(rng, cell, F, H, Lyr, dirs)
     x = rng.standard_normal((B, T, F)).astype(np.float32).astype(np.float64)
     Wd = [dev(P[n]) for n in names]; Gd = [torch.zeros_like(w) for w in Wd]
-    rnn = L.Rnn(L.CELL_GRU if cell == 'gru' else L.CELL_LSTM, B, T, F, H, Lyr, dirs, True, p, L.POOL_NONE, DEV, impl=impl)
+    model_form = form == 'model'
+    pool = L.POOL_MEAN if (model_form and cell == 'gru') else L.POOL_NONE
+    rnn = L.Rnn(L.CELL_GRU if cell == 'gru' else L.CELL_LSTM, B, T, F, H, Lyr, dirs, True, p, pool, DEV, impl=impl)
     xd = dev(x)
-    rnn.forward(xd, Wd, seed=seed)
+    pooled = torch.empty(B, H, device=DEV) if pool != L.POOL_NONE else None
+    rnn.forward(xd, Wd, seed=seed, pooled=pooled)
     y0 = host(rnn.layer_output(0)); y0d = host(rnn.layer_output_dropped(0))
     mask = host(L.dropout_mask(B * T * H * dirs, p, seed, 16, DEV)).reshape(B, T, H * dirs)   # site = DEP_SITE_RNN0 + 0
     assert set(np.unique(mask)).issubset({0.0, 2.0})
@@ -325,12 +346,23 @@ def test_rnn_interlayer_dropout_matches_oracle_with_same_masks(cell, impl, H):
     dyv = rng.standard_normal((B, T, H * dirs)).astype(np.float32).astype(np.float64)
     if cell == 'gru':
         yr, caches = R.gru_stack_fwd(x, P, prefix, Lyr, masks=[mask])
-        rnn.backward(xd, Wd, Gd, dy=dev(dyv))
+        if model_form:
+            dpool = rng.standard_normal((B, H)).astype(np.float32).astype(np.float64)
+            rnn.backward(xd, Wd, Gd, dpooled=dev(dpool), dx=None)
+            assert np.abs(host(pooled) - yr.mean(1)).max() < 1e-4
+            dyv = np.repeat(dpool[:, None, :] / T, T, axis=1)
+        else:
+            rnn.backward(xd, Wd, Gd, dy=dev(dyv))
         _, Gr = R.gru_stack_bwd(dyv, P, prefix, Lyr, caches, masks=[mask])
     else:
         yr, hnr, caches = R.bilstm_stack_fwd(x, P, prefix, Lyr, masks=[mask])
-        rnn.backward(xd, Wd, Gd, dy=dev(dyv))
-        _, Gr = R.bilstm_stack_bwd(dyv, np.zeros((Lyr * 2, B, H)), P, prefix, Lyr, caches, masks=[mask])
+        dhn = np.zeros((Lyr * 2, B, H))
+        if model_form:
+            dhn = (rng.standard_normal((Lyr * 2, B, H)) * 0.3).astype(np.float32).astype(np.float64)
+            rnn.backward(xd, Wd, Gd, dy=dev(dyv), dh_n=dev(dhn), dx=None)
+        else:
+            rnn.backward(xd, Wd, Gd, dy=dev(dyv))
+        _, Gr = R.bilstm_stack_bwd(dyv, dhn, P, prefix, Lyr, caches, masks=[mask])
     assert np.abs(host(rnn.layer_output()) - yr).max() < 1e-4
     for n, g in zip(names, Gd):
         assert relerr(host(g), Gr[n]) < 1e-4, n

@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp_path, tag, pk, B, T, F, dx, lstm=False, env=None):
+def _run(tmp_path, tag, pk, B, T, F, dx, lstm=False, env=None, nody=False):
     out = str(tmp_path / f'{tag}_{pk}.npz')
     e = dict(os.environ, DEP_DGI_PK=str(pk))
     e.update(env or {})
-    r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, str(B), str(T), str(F)] + (['dx'] if dx else []) + (['lstm'] if lstm else []),
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, str(B), str(T), str(F)] + (['dx'] if dx else []) + (['lstm'] if lstm else []) + (['nody'] if nody else []),
                        env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return np.load(out)
@@ -25,10 +25,12 @@ def _run(tmp_path, tag, pk, B, T, F, dx, lstm=False, env=None):
 
 # B = 416: 26 tiles -> every burst phase 0..3 (the PK flush lags one step for the odd ones); T even, with 0 / 2 steps after the last
 # dirty step; F = 64 / 256: both layers' contractions above the three-term kernel's size threshold; dx: the NN form of layer 0 too
-@pytest.mark.parametrize('B,T,F,dx', [(416, 20, 64, False), (416, 22, 256, True), (160, 6, 256, False), (512, 300, 256, False)])
-def test_pk_gate_gradients_leave_every_gradient_bit_identical(tmp_path, B, T, F, dx):
-    a = _run(tmp_path, 'a', 0, B, T, F, dx)
-    b = _run(tmp_path, 'b', 1, B, T, F, dx)
+# nody: the training step's call form (dpooled only, no dX): gru2_bwd_fused<.., HASDY = false, ..> -- three input slots, prefetch distance 2
+@pytest.mark.parametrize('B,T,F,dx,nody', [(416, 20, 64, False, False), (416, 22, 256, True, False), (160, 6, 256, False, False), (512, 300, 256, False, False),
+                                           (416, 20, 64, False, True), (160, 6, 256, False, True), (40, 2, 256, False, True), (512, 300, 256, False, True)])
+def test_pk_gate_gradients_leave_every_gradient_bit_identical(tmp_path, B, T, F, dx, nody):
+    a = _run(tmp_path, 'a', 0, B, T, F, dx, nody=nody)
+    b = _run(tmp_path, 'b', 1, B, T, F, dx, nody=nody)
     for k in a.files:
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
@@ -37,10 +39,10 @@ def test_pk_gate_gradients_leave_every_gradient_bit_identical(tmp_path, B, T, F,
 # Round 5: dW_ih and dW_hh of a GRU layer whose input is as wide as its state (layer 1 always; layer 0 when F = H) are ONE launch over the
 # shared PK image (gemm_bf16x3_tn_pair).  Same tiles, K chunks and split-K order per contraction: every gradient bit-identical to the two
 # launches (DEP_DW_PAIR=0).  F = 64: only layer 1 pairs; F = 256: both; the benchmark's full shape once.
-@pytest.mark.parametrize('B,T,F,dx', [(416, 20, 64, False), (416, 22, 256, True), (512, 300, 256, False)])
-def test_paired_weight_gradient_launch_leaves_every_gradient_bit_identical(tmp_path, B, T, F, dx):
-    a = _run(tmp_path, 'a', 1, B, T, F, dx, env={'DEP_DW_PAIR': '0'})
-    b = _run(tmp_path, 'b', 1, B, T, F, dx, env={'DEP_DW_PAIR': '1'})
+@pytest.mark.parametrize('B,T,F,dx,nody', [(416, 20, 64, False, False), (416, 22, 256, True, False), (512, 300, 256, False, True)])
+def test_paired_weight_gradient_launch_leaves_every_gradient_bit_identical(tmp_path, B, T, F, dx, nody):
+    a = _run(tmp_path, 'a', 1, B, T, F, dx, env={'DEP_DW_PAIR': '0'}, nody=nody)
+    b = _run(tmp_path, 'b', 1, B, T, F, dx, env={'DEP_DW_PAIR': '1'}, nody=nody)
     for k in a.files:
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
@@ -93,7 +95,8 @@ def test_per_step_stream_bilstm_backward_is_bit_identical_to_the_burst_form(tmp_
         assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
 
 
-def test_16bit_saved_gates_move_no_gradient_by_more_than_1e4_of_its_scale(tmp_path):
+@pytest.mark.parametrize('form', [['dx'], ['nody']])
+def test_16bit_saved_gates_move_no_gradient_by_more_than_1e4_of_its_scale(tmp_path, form):
     """Round 4: the GRU stack saves r, z (unorm16) and n (snorm16) as 16-bit fixed point (|error| <= 7.6e-6 / 1.5e-5) instead of fp32.
     Forward outputs cannot change (the gates are only stored for the backward); every gradient of the cfg2-shaped stack must stay
     within 1e-4 of its tensor's scale of the fp32-gates run (measured: a few 1e-6), and the contractions' operands stay bit-exact
@@ -102,7 +105,7 @@ def test_16bit_saved_gates_move_no_gradient_by_more_than_1e4_of_its_scale(tmp_pa
     for sv in ('0', '1'):
         out = str(tmp_path / f'sv{sv}.npz')
         e = dict(os.environ, DEP_SV16=sv)
-        r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, '512', '300', '256', 'dx'], env=e, capture_output=True,
+        r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, '512', '300', '256'] + form, env=e, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs[sv] = np.load(out)
@@ -115,7 +118,8 @@ def test_16bit_saved_gates_move_no_gradient_by_more_than_1e4_of_its_scale(tmp_pa
     assert worst > 0.0            # the switch really changed the stored gates
 
 
-def test_bf16_storage_mode_has_its_own_tolerance(tmp_path):
+@pytest.mark.parametrize('form', [[], ['nody']])
+def test_bf16_storage_mode_has_its_own_tolerance(tmp_path, form):
     """dep_set_gemm_mode(3) / DEP_GEMM_MODE=bf16s (BASELINE configs[1]'s "bf16", a labelled throughput mode, NEVER the parity path): the
     hidden sequences, hn and the gate gradients live in HBM as bf16 (the saved gates as 16-bit fixed point), state / accumulation /
     the recurrence stay fp32.  Against mode 2 (single bf16 products, fp32 storage) the FORWARD must be bit-identical -- only what is
@@ -125,7 +129,7 @@ def test_bf16_storage_mode_has_its_own_tolerance(tmp_path):
     for mode in ('bf16', 'bf16s'):
         out = str(tmp_path / f'{mode}.npz')
         e = dict(os.environ, DEP_GEMM_MODE=mode)
-        r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, '512', '300', '256'], env=e, capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out, '512', '300', '256'] + form, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs[mode] = np.load(out)
     assert np.array_equal(outs['bf16']['pooled'], outs['bf16s']['pooled'])

@@ -14,7 +14,7 @@ import pytest
 from conftest import load_golden
 
 torch = pytest.importorskip('torch')
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.oracle]
 
 if torch.cuda.is_available():
     from icassp2022_depression_amd import (_common, audio_bilstm_perm, audio_gru_whole, fuse_net_whole, model_checking, nn,

@@ -16,6 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = [
     # cell, iters, extra env, extra args
     ('gru', 20, {}, []),
+    ('gru', 20, {}, ['--model-form']),                            # the training step's call form: gru2_bwd_fused<.., HASDY = false, ..> (three input slots, prefetch distance 2)
+    ('gru', 8, {'DEP_CLUSTER_NOFAST': '1'}, ['--model-form']),
+    ('gru', 8, {}, ['--model-form', '--load', '--load-phase', 'bwd']),
     ('gru', 10, {'DEP_CLUSTER_NOFAST': '1'}, []),
     ('gru', 4, {'DEP_NUM_CUS': '48'}, []),
     ('gru', 6, {'DEP_NUM_CUS': '200'}, []),
