@@ -129,7 +129,6 @@ struct Layout {
     bool cluster;                    // cluster-parallel sweeps (rnn_cluster*.hip)
     bool cluster16;                  // forward with 16-unit members, two workgroups per CU (rnn_cluster16.hip)
     bool dg4;                        // GRU cluster backward: gate gradients as ONE (B*T, 4H) array [dr | dz | dn | dn*r] (dW_hh is then one contraction)
-    bool cluster16_bwd;              // same for the backward (slower than 32-unit members: A/B only, DEP_CLUSTER16_BWD=1)
     bool bf16st;                     // dep_set_gemm_mode(3) on a stack whose kernels have the bf16-storage variants (2-layer GRU, H = 256, fused forward): y, hn as bf16, gate gradients as PKH
     bool sv16;                       // GRU cluster sweeps: saved gates r, z, n as 16-bit fixed point (split-precision mode only; decided per call)
     bool fused2;                     // 2-layer GRU, H = 256: both layers in one launch (rnn_fused2.hip), split-precision mode only
@@ -209,8 +208,7 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     if (d->impl == 3 && !cok) return false;
     lo.cluster = cok && (d->impl == 0 || d->impl == 3);
     lo.cluster16 = lo.cluster && dep_cluster16_ok(d->cell, d->H, d->B);
-    { const char* e = getenv("DEP_CLUSTER16_BWD"); lo.cluster16_bwd = lo.cluster16 && e && e[0] == '1'; }
-    { const char* e = getenv("DEP_DG4"); lo.dg4 = lo.cluster && d->cell == DEP_CELL_GRU && d->dirs == 1 && !lo.cluster16_bwd && !(e && e[0] == '0'); }
+    lo.dg4 = lo.cluster && d->cell == DEP_CELL_GRU && d->dirs == 1;
     lo.xbuf = w; lo.xbuf_bytes = !lo.cluster ? 0 : (d->cell == DEP_CELL_GRU ? dep_cluster_xbuf_bytes(d->cell, d->H, d->B, d->dirs)
                                                                 : dep_cluster_lstm_xbuf_bytes(d->H, d->B, d->dirs));
     if (lo.cluster) lo.nwg = dep_cdiv(d->B, 16);      // the cluster sweeps write one row per tile whatever the tile-MFMA sweep could do at this H
@@ -231,12 +229,10 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
     // 16-bit saved gates: the kernels that implement them are the fused forward, the 32-unit-member forward and the 32-unit-member
     // backward (burst or not); the 16-unit-member kernels and the opt-in fused backward read / write fp32 gates
     {
-        static int sv_env = -1, fb_env = -1;
+        static int sv_env = -1;
         if (sv_env < 0) { const char* e = getenv("DEP_SV16"); sv_env = (e && e[0] == '0') ? 0 : 1; }
-        if (fb_env < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fb_env = (e && e[0] == '1') ? 1 : 0; }
-        (void)fb_env;                                  // (round 5: the all-gather fused backward reads the 16-bit gates too)
         lo.sv16 = sv_env && d->training && lo.cluster &&
-                  (d->cell == DEP_CELL_GRU ? (!lo.cluster16_bwd && (lo.fused2 || !lo.cluster16)) : dep_cluster_lstm_sv16_ok());
+                  (d->cell == DEP_CELL_GRU ? (lo.fused2 || !lo.cluster16) : dep_cluster_lstm_sv16_ok());
         // bf16-STORAGE mode (dep_set_gemm_mode(3); a labelled throughput mode, never the parity path): only where every kernel of the
         // stack has the variant -- the fused 2-layer GRU forward and the burst backward with the 4H-wide gate-gradient rows.  Other
         // stacks run mode 3 exactly like mode 2 (single bf16 products, fp32 storage).
@@ -304,12 +300,9 @@ extern "C" int dep_rnn_set_exclusive(int on) { g_exclusive.store(on ? 1 : 0); re
 extern "C" int dep_rnn_get_exclusive(void) { return dep_exclusive_on() ? 1 : 0; }
 
 // Precision of the recurrent products inside the cluster sweeps: follows the GEMM mode (include/dep_rnn.h,
-// dep_set_gemm_mode): 1 = 3-term bf16 split on the bf16 matrix cores, 0 = exact fp32 MFMA.  DEP_SWEEP_MODE=f32 pins the
-// sweeps to fp32 while leaving the GEMMs alone (A/B).
+// dep_set_gemm_mode): 1 = 3-term bf16 split on the bf16 matrix cores, 0 = exact fp32 MFMA.
 static bool sweep_split_mode() {
-    static int pin = -1;
-    if (pin < 0) { const char* e = getenv("DEP_SWEEP_MODE"); pin = (e && e[0] == 'f') ? 1 : 0; }
-    return !pin && dep_get_gemm_mode() >= 1;        // mode 2 (single bf16 products in the GEMMs) keeps the split sweeps
+    return dep_get_gemm_mode() >= 1;                // mode 2 (single bf16 products in the GEMMs) keeps the split sweeps
 }
 
 // Precision mode of the packed recurrent-weight images a reserve holds (host-side record, no device traffic): the
@@ -366,7 +359,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
                       "and has no fp32 copy of the output sequence (y must be NULL)");
         return DEP_ERR_ARG;
     }
-    record_reserve_mode(reserve, (sweep_split_mode() ? 1 : 0) | (lo.cluster16_bwd ? 2 : 0) | (sv16 ? 4 : 0) | (lo.bf16st ? 8 : 0));
+    record_reserve_mode(reserve, (sweep_split_mode() ? 1 : 0) | (sv16 ? 4 : 0) | (lo.bf16st ? 8 : 0));
     if (lo.fused2 && sweep_split_mode() && excl) {
         // both layers in one launch: layer 1 runs one step behind layer 0 and takes its input straight from the exchanged
         // h0_t (no layer-1 input-projection GEMM, no GI round trip through HBM for it)
@@ -376,11 +369,8 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             const float* srcs[5] = {w0[1], w1[1], w1[0], w0[1], w1[1]};
             float* dsts[5] = {R + lo.wp[0][0], R + lo.wp[1][0], W + lo.wih_img, R + lo.wpT[0][0], R + lo.wpT[1][0]};
             const int kinds[5] = {0, 0, 0, 1, 1};
-            const bool bwd_multi = d->training && !lo.cluster16_bwd;
+            const bool bwd_multi = d->training != 0;
             rc = dep_pack_cluster_split_multi(bwd_multi ? 5 : 3, srcs, dsts, kinds, H, s); if (rc) return rc;
-            if (d->training && lo.cluster16_bwd) {       // the 16-unit-member backward (DEP_CLUSTER16_BWD=1) reads its own image
-                for (int l = 0; l < 2; ++l) { rc = dep_pack_cluster16_bwd(l == 0 ? w0[1] : w1[1], R + lo.wpT[l][0], H, s); if (rc) return rc; }
-            }
         }
         float* gi = W + lo.gi;
         rc = dep_gemm_internal(0, 1, BTr, G * H, d->F, x, d->F, w0[0], d->F, gi, G * H, w0[2], 0.f, 0, 0, nullptr, 0, s);
@@ -460,15 +450,14 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
                 rc = dep_pack_cluster_lstm_split(wl[1], R + lo.wp[l][dd], d->training ? R + lo.wpT[l][dd] : nullptr, H, s);
                 if (rc) return rc;
             } else {
-                const bool split_bwd = lo.cluster && d->cell == DEP_CELL_GRU && !lo.cluster16_bwd && sweep_split_mode();
+                const bool split_bwd = lo.cluster && d->cell == DEP_CELL_GRU && sweep_split_mode();
                 // the fp32 fragment images are only needed by kernels that are not running on split-precision images
                 const bool need_f32 = mfma && !((split_fwd || split_fwd32) && (split_bwd || !d->training));
                 if (need_f32) { rc = dep_pack_whh(wl[1], R + lo.wp[l][dd], R + lo.wpT[l][dd], G, H, s); if (rc) return rc; }
                 if (split_fwd) { rc = dep_pack_cluster16_fwd_split(wl[1], R + lo.wp[l][dd], H, s); if (rc) return rc; }
                 if (split_fwd32) { rc = dep_pack_cluster_fwd_split(wl[1], R + lo.wp[l][dd], H, s); if (rc) return rc; }
                 if (lo.cluster && d->training) {     // the cluster backward wants its own member-sliced image
-                    rc = lo.cluster16_bwd ? dep_pack_cluster16_bwd(wl[1], R + lo.wpT[l][dd], H, s)
-                       : split_bwd ? dep_pack_cluster_bwd_split(wl[1], R + lo.wpT[l][dd], H, s)
+                    rc = split_bwd ? dep_pack_cluster_bwd_split(wl[1], R + lo.wpT[l][dd], H, s)
                                    : dep_pack_cluster_bwd(wl[1], R + lo.wpT[l][dd], G, H, s);
                     if (rc) return rc;
                 }
@@ -548,7 +537,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         const int fm = lookup_reserve_mode(reserve);
         if (fm >= 0 && (fm & 1) != (sweep_split_mode() ? 1 : 0)) {
             dep_set_error("dep_rnn_backward: the reserve was produced by a forward in %s mode, the current mode is %s "
-                          "(dep_set_gemm_mode / DEP_SWEEP_MODE must not change between a forward and its backward)",
+                          "(dep_set_gemm_mode must not change between a forward and its backward)",
                           (fm & 1) ? "bf16x3" : "f32", (fm & 1) ? "f32" : "bf16x3");
             return DEP_ERR_ARG;
         }
@@ -559,11 +548,6 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         if (fm >= 0 && ((fm >> 2) & 1) != ((lo.sv16 && sweep_split_mode()) ? 1 : 0)) {
             dep_set_error("dep_rnn_backward: the reserve holds %s saved gates, this call expects the other format (DEP_SV16 / DEP_EXCLUSIVE changed?)",
                           (fm & 4) ? "16-bit" : "fp32");
-            return DEP_ERR_ARG;
-        }
-        if (fm >= 0 && ((fm >> 1) & 1) != (lo.cluster16_bwd ? 1 : 0)) {
-            dep_set_error("dep_rnn_backward: the reserve holds the %s backward weight image, this call would run the other kernel",
-                          (fm & 2) ? "16-unit-member" : "32-unit-member");
             return DEP_ERR_ARG;
         }
     }
@@ -579,7 +563,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     // per-layer loop below with the sweep launches and layer 1's dX GEMM left out.  DEP_FUSED2_BWD=1 / 0.
     static int fused_bwd_on = -1;
     if (fused_bwd_on < 0) { const char* e = getenv("DEP_FUSED2_BWD"); fused_bwd_on = e ? ((e[0] == '1') ? 1 : 0) : DEP_FUSED2_BWD_DEFAULT; }
-    const bool fused = lo.fused2 && fused_bwd_on && sweep_split_mode() && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && L == 2 && D == 1 && dep_fused2_bwd_fits(B, T);
+    const bool fused = lo.fused2 && fused_bwd_on && sweep_split_mode() && d->cell == DEP_CELL_GRU && L == 2 && D == 1 && dep_fused2_bwd_fits(B, T);
     static int pk_env = -1;
     if (pk_env < 0) { const char* e = getenv("DEP_DGI_PK"); pk_env = (e && e[0] == '0') ? 0 : 1; }
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -587,7 +571,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     auto pk_gru_ok = [&](int l, bool has_dxl, const float* dxl_probe) {
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
         const int Kl = l == 0 ? d->F : D * H;
-        return pk_env && lo.dg4 && lo.cluster && !lo.cluster16_bwd && d->cell == DEP_CELL_GRU && sweep_split_mode() && (dep_get_gemm_mode() == 1 || lo.bf16st) &&
+        return pk_env && lo.dg4 && lo.cluster && d->cell == DEP_CELL_GRU && sweep_split_mode() && (dep_get_gemm_mode() == 1 || lo.bf16st) &&
                (fused || dep_cluster_bwd_pk_ok(H, T)) && (T % 2 == 0) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(weights[(size_t)l * 4]) &&
                al16(dweights[(size_t)l * 4]) && al16(dweights[(size_t)l * 4 + 1]) &&
                dep_gemm_uses_bf16x3(G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(3 * H, H, BTr, T) &&
@@ -621,7 +605,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         rc = dep_launch_fused2_bwd(f, W + lo.xbuf, lo.xbuf_bytes); if (rc) return rc;
     }
     float* pending_ptr = nullptr; long pending_n = 0;      // data parallel: a finished layer's gradient range waiting for the next sweep to be enqueued
-    if (lo.cluster && !lo.cluster16_bwd && !fused) { rc = dep_cluster_reset_flags(W + lo.xbuf, s); if (rc) return rc; }      // every layer's header slot in one memset (the status words stay)
+    if (lo.cluster && !fused) { rc = dep_cluster_reset_flags(W + lo.xbuf, s); if (rc) return rc; }      // every layer's header slot in one memset (the status words stay)
     for (int l = L - 1; l >= 0; --l) {
         const bool top = l == L - 1;
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
@@ -630,7 +614,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         dep_sweep_bwd_args a{};
         a.B = B; a.T = T; a.H = H; a.cell = d->cell; a.dirs = D; a.impl = d->impl;
         // must match the image dep_rnn_forward packed: the precision mode may not change between a forward and its backward
-        a.split = (lo.cluster && !lo.cluster16_bwd && sweep_split_mode()) ? 1 : 0;
+        a.split = (lo.cluster && sweep_split_mode()) ? 1 : 0;
         for (int dd = 0; dd < D; ++dd) {
             const float* const* wl = weights + (size_t)(l * D + dd) * 4;
             a.w_hh[dd] = wl[1]; a.wpT[dd] = R + lo.wpT[l][dd];
@@ -651,7 +635,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         // Round 4: the sweep writes the gate gradients as the PK image (rows (t even, t + 1) = (hi, lo) bf16 pairs of both steps,
         // gemm_bf16x3.hip) -- the three contractions that read them (dX, dW_ih, dW_hh) then stage them without converting; same
         // bytes, same bits.  Only when all three really run the three-term kernel on its vector path.
-        a.split = (lo.cluster && !lo.cluster16_bwd && sweep_split_mode()) ? 1 : 0;
+        a.split = (lo.cluster && sweep_split_mode()) ? 1 : 0;
         float* dxl_probe = l == 0 ? dx : (fused ? nullptr : W + lo.dx[l & 1]);
         const bool pk_gru = fused ? fused_pk : (a.split && pk_gru_ok(l, dxl_probe != nullptr, dxl_probe));
         // the BiLSTM cluster sweep (both directions in one launch, direction-stacked contractions): same image, same conditions
@@ -668,11 +652,10 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         }
         a.bf16st = lo.bf16st ? 1 : 0;
         const int fmt_a = lo.bf16st ? 2 : 1;                       // FMT_PKH / FMT_PK (gemm_bf16x3.hip)
-        a.sv16 = (lo.sv16 && sweep_split_mode() && lo.cluster && (d->cell == DEP_CELL_LSTM || !lo.cluster16_bwd)) ? 1 : 0;
+        a.sv16 = (lo.sv16 && sweep_split_mode() && lo.cluster) ? 1 : 0;
         struct FmtGuard { bool on; ~FmtGuard() { if (on) dep_gemm_set_operand_formats(0, 0); } } fmt_guard{pk};
         if (!fused) {
-            rc = lo.cluster16_bwd ? dep_launch_cluster16_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
-               : (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
+            rc = (lo.cluster && d->cell == DEP_CELL_LSTM) ? dep_launch_cluster_lstm_bwd(a, W + lo.xbuf, lo.xbuf_bytes)
                : lo.cluster ? dep_launch_cluster_bwd(a, W + lo.xbuf, lo.xbuf_bytes) : dep_launch_sweep_bwd(a);
             if (rc) return rc;
         }

@@ -183,12 +183,6 @@ struct dep_sweep_bwd_args {
     hipStream_t stream;
 };
 bool dep_cluster_bwd_pk_ok(int H, int T);
-#define DEP_BWD_AG_DEFAULT 1          /* the GRU-256 backward sweep's exchange: 0 = reduce-scatter of fp32 partials, 1 = all-gather of gate gradients (DEP_BWD_AG overrides) */
-bool dep_cluster_bwd_ag_on();
-#define DEP_LSTM_DF_DEFAULT 3          /* the BiLSTM-128 forward sweep: 0 = h_t through LDS planes (three barriers a step), 1 = direct fragment loads + per-wave flags, burst streams, 2 = + per-step streams, 3 = + the data are their own flag (sentinel slots) (DEP_LSTM_DF overrides) */
-#define DEP_LSTM_SE_DEFAULT 1          /* the BiLSTM-128 backward sweep: 0 = burst streams, one flag per member behind a drain barrier, 1 = per-step streams + per-wave flags (DEP_LSTM_SE overrides) */
-#define DEP_FWD_SX_DEFAULT 1            /* the fused GRU forward's hand-off: 0 = acknowledgement wait + flag + poll, 1 = the exchanged words are their own flag (sentinel slots) (DEP_FWD_SX overrides) */
-#define DEP_FWD_DF_DEFAULT 0           /* the fused GRU forward with direct fragment loads (gru2_fwd_df, rnn_fused2.hip); DEP_FWD_DF overrides */
 #define DEP_FUSED2_BWD_DEFAULT 1      /* both GRU layers' BPTT as one all-gather launch (rnn_fused2_bwd.hip); DEP_FUSED2_BWD overrides */
 bool dep_cluster_lstm_bwd_pk_ok(int T);
 bool dep_cluster_lstm_sv16_ok();
@@ -259,7 +253,6 @@ int dep_comm_enqueue_after(dep_comm* c, float* buf, long n, hipStream_t compute,
 constexpr int DEP_HDR_SLOTS = 4;                              // exchange-header slots at the head of the buffer (rnn_cluster_common.h)
 int dep_cluster_reset_status(void* xbuf, hipStream_t s);      // status, soft flag and EVERY header slot
 int dep_cluster_reset_flags(void* xbuf, hipStream_t s);       // every header slot, status words kept (dep_rnn_backward)
-int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster16_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_bwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_split_multi(int n, const float* const* src, float* const* dst, const int* bwd, int H, hipStream_t s);
@@ -271,7 +264,6 @@ int dep_attn2_bwd(const float* dctx, const float* out, const float* alpha, const
 int dep_pack_cluster_fwd_split(const float* w_hh, float* out, int H, hipStream_t s);
 int dep_pack_cluster_lstm_split(const float* w_hh, float* wp, float* wpT, int H, hipStream_t s);
 int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes);
-int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes);
 
 int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* A, int lda,
                       const float* B, int ldb, float* C, int ldc, const float* bias, float beta,

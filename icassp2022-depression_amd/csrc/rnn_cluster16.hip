@@ -33,22 +33,6 @@ struct F16 {
     long long* trace;
 };
 
-struct B16 {
-    int B, T, H, nbtp, b0;
-    const f32x4* wp;
-    const float* y; int ldy;
-    const float* dy; int lddy;
-    float drop_p, drop_scale; uint64_t seed; uint32_t site;
-    const float* dpooled; float pool_scale;
-    const float* dh_n;
-    const float* sv0; const float* sv1; const float* sv2; const float* sv3;
-    float* dgi; int lddg;
-    float* dghn;
-    float* dbpart;
-    unsigned* status; unsigned* flags; unsigned* hello; float* payload; unsigned payload_bytes;
-    int nofast;
-};
-
 // =============================================================================== forward
 // matvec roles : lane = (utterance j = lane&15, k-quad q = lane>>4), wave w = K quarter
 // finalise roles: thread = (utterance fj = tid>>4, unit fu = tid&15)  -> 64-byte row segments in every global access
@@ -287,153 +271,6 @@ __global__ __launch_bounds__(CT + 64, 4) void gru_fwd_cluster16(F16 p) {
     }
 }
 
-// =============================================================================== backward
-struct StepIn { float r, z, n, hn, hp, dy; };
-
-template <int NTW>      // output tiles per wave = H/64
-__global__ __launch_bounds__(CT) void gru_bwd_cluster16(B16 p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KS = 48, KCB = KS / 16, LDG = KS + LPAD;
-    const int H = p.H, T = p.T, NC = H / 16, NTT = H / 16;
-    const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
-    if (p.b0 + bt * BT >= p.B) return;
-    if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int fj = tid >> 4, fu = tid & 15;
-    const int col = 16 * c + fu;
-    const int b = p.b0 + bt * BT + fj;
-    const bool valid = b < p.B;
-    float* dgs = smem;                                // [16][LDG]
-
-    f32x4 wr[NTW][KCB];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-        for (int k = 0; k < KCB; ++k)
-            wr[i][k] = p.wp[(size_t)((c * NTT + w * NTW + i) * KCB + k) * 64 + lane];
-    float dhrec = (p.dh_n && valid) ? p.dh_n[(size_t)b * H + col] : 0.f;
-    const float dpl = (p.dpooled && valid) ? p.dpooled[(size_t)b * H + col] * p.pool_scale : 0.f;
-    float dbr = 0.f, dbz = 0.f, dbn = 0.f, dbh = 0.f;
-    const size_t pstride = (size_t)p.nbtp * NC * BT * H;
-    const size_t tile_base = (size_t)bt * NC * BT * H;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
-    unsigned* myflag = p.flags + bt * NC + c;
-    unsigned* tflags = p.flags + bt * NC;
-    const int ml = lane & 15, mq = lane >> 4;
-    const int g_lane = (fu >> 2) * 16 + fj, g_e = fu & 3;       // this thread's element inside a published fragment
-    bool dead = false;
-    const int sx = p.nofast ? 0 : cluster_same_xcd(p.hello + bt * NC, NC, c, p.status);
-    if (sx < 0) return;
-    const bool fast = sx == 1;
-
-    auto load_step = [&](int t, StepIn& s) {
-        s.r = s.z = s.n = s.hn = s.hp = s.dy = 0.f;
-        if (valid && t >= 0) {
-            const size_t row = (size_t)b * T + t;
-            const size_t so = row * H + col;
-            s.r = p.sv0[so]; s.z = p.sv1[so]; s.n = p.sv2[so]; s.hn = p.sv3[so];
-            if (t > 0) s.hp = p.y[(row - 1) * p.ldy + col];
-            if (p.dy) s.dy = p.dy[row * p.lddy + col];
-        }
-    };
-    StepIn cur, nxt;
-    load_step(T - 1, cur);
-
-    for (int t = T - 1; t >= 0; --t) {
-        const size_t row = (size_t)b * T + t;
-        float dyv = cur.dy;
-        if (p.dy && p.drop_p > 0.f && valid) dyv *= dep_dropmask1(p.seed, p.site, row * p.lddy + col, p.drop_p, p.drop_scale);
-        const float r = cur.r, z = cur.z, n = cur.n, hn = cur.hn, hp = cur.hp;
-        const float d = dhrec + dpl + dyv;
-        const float dn = d * (1.0f - z) * (1.0f - n * n);
-        const float dz = d * (hp - n) * z * (1.0f - z);
-        const float dr = dn * hn * r * (1.0f - r);
-        const float dnr = dn * r;
-        const float dzt = d * z;
-        dgs[fj * LDG + fu] = dr; dgs[fj * LDG + 16 + fu] = dz; dgs[fj * LDG + 32 + fu] = dnr;
-        if (valid) {
-            float* g = p.dgi + row * p.lddg;
-            g[col] = dr; g[H + col] = dz; g[2 * H + col] = dn;
-            p.dghn[row * H + col] = dnr;
-        }
-        dbr += dr; dbz += dz; dbn += dn; dbh += dnr;
-        __syncthreads();
-        if (t == 0) break;
-        load_step(t - 1, nxt);
-        f32x4 acc[NTW];
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] = zero4();
-        const float* drow = dgs + ml * LDG + mq * 4;
-        f32x4 hv[KCB];
-#pragma unroll
-        for (int k = 0; k < KCB; ++k) hv[k] = ld4(drow + k * 16);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < KCB; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < NTW; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i][k][e], hv[k][e], acc[i], 0, 0, 0);
-        const unsigned epoch = (unsigned)(T - t);
-        const size_t pbase = (size_t)(t & 1) * pstride + tile_base;
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            const size_t fo = pbase + ((size_t)(c * NTT + w * NTW + i) * 64 + lane) * 4;
-            u32x4 v;
-            v.x = __float_as_uint(acc[i][0]); v.y = __float_as_uint(acc[i][1]);
-            v.z = __float_as_uint(acc[i][2]); v.w = __float_as_uint(acc[i][3]);
-            if (fast) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)(fo * 4), 0, 16);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) { if (fast) st_local(myflag, epoch); else st_agent(myflag, epoch); }
-        if (w == 0 && !wait_flags(tflags, NC, epoch, p.status, 3)) dead = true;
-        if (__syncthreads_or(dead)) return;
-        // this thread's column of every member's partial, summed in member order
-        const float* src = p.payload + pbase + ((size_t)c * 64 + g_lane) * 4 + g_e;
-        float part[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) part[m] = (m < NC) ? ldf_agent(src + (size_t)m * NTT * 256) : 0.f;
-        float s = 0.f;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) s += part[m];
-        dhrec = dzt + s;
-        cur = nxt;
-    }
-    // bias-gradient partials dbpart[bt][4][H]: sum over the 16 utterances = lanes differing in bits 4,5 and the 4 waves
-    float a[4] = {dbr, dbz, dbn, dbh};
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k] += __shfl_xor(a[k], 16, 64); a[k] += __shfl_xor(a[k], 32, 64); }
-    if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) smem[(w * 4 + k) * 16 + lane] = a[k];
-    }
-    __syncthreads();
-    if (tid < 64) {
-        const int k = tid >> 4, u = tid & 15;
-        const float s = smem[(0 * 4 + k) * 16 + u] + smem[(1 * 4 + k) * 16 + u] + smem[(2 * 4 + k) * 16 + u] + smem[(3 * 4 + k) * 16 + u];
-        p.dbpart[(size_t)(p.b0 / BT + bt) * 4 * H + k * H + 16 * c + u] = s;
-    }
-}
-
-// member image for the backward: out[((c*(H/16) + jt)*3 + kc)*256 + l*4 + e] = W[(g*H + 16c + u)*H + jt*16 + (l&15)],
-// k = kc*16 + (l>>4)*4 + e, g = k/16, u = k%16
-__global__ void pack_cluster16_bwd_kernel(const float* __restrict__ W, float* __restrict__ out, int H) {
-    const long n = 3L * H * H;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const int e = idx & 3, l = (idx >> 2) & 63;
-    const long blk = idx >> 8;
-    const int kc = blk % 3; const long r = blk / 3;
-    const int jt = r % (H / 16); const int c = r / (H / 16);
-    const int k = kc * 16 + (l >> 4) * 4 + e;
-    const int g = k / 16, u = k % 16;
-    out[idx] = W[(size_t)(g * H + 16 * c + u) * H + jt * 16 + (l & 15)];
-}
-
 // split-precision forward image (see gru_fwd_cluster16<., true>): 16-byte piece
 //   [((((c*3 + g)*4 + w)*KS2 + ks)*2 + plane)*64 + lane]  =  bf16 plane (0 hi, 1 lo) of
 //   W[(g*H + 16c + (lane&15)) * H + 64w + 32ks + 8(lane>>4) + 0..7]          (KS2 = H/128 k-steps of 32 per wave)
@@ -476,13 +313,6 @@ bool dep_cluster16_ok(int cell, int H, int B) {
     return true;
 }
 
-int dep_pack_cluster16_bwd(const float* w_hh, float* out, int H, hipStream_t s) {
-    const long n = 3L * H * H;
-    DEP_LAUNCH(pack_cluster16_bwd_kernel, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, w_hh, out, H);
-    DEP_CHECK_LAUNCH();
-    return DEP_OK;
-}
-
 int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_bytes) {
     // co-residency bounds a launch to two workgroups per CU (512 = 32 tiles = 512 utterances on a full MI355X); larger
     // batches run chunk after chunk
@@ -510,36 +340,6 @@ int dep_launch_cluster16_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_by
         { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
         if (a.split) DEP_LAUNCH((gru_fwd_cluster16<4, true>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
         else DEP_LAUNCH((gru_fwd_cluster16<4, false>), dim3(NC * p.nbtp), dim3(CT + 64), lds, a.stream, p);
-        DEP_CHECK_LAUNCH();
-    }
-    return DEP_OK;
-}
-
-int dep_launch_cluster16_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
-    const int NC = a.H / 16, CH = dep_cluster_chunk(NC, 2, 512), nbt = dep_cdiv(a.B, BT);
-    const int nbtp_max = (dep_cdiv(a.B < CH ? a.B : CH, BT) + 7) / 8 * 8;
-    B16 p{};
-    p.B = a.B; p.T = a.T; p.H = a.H;
-    p.wp = (const f32x4*)a.wpT[0];
-    p.y = a.y; p.ldy = a.ldy; p.dy = a.dy; p.lddy = a.lddy;
-    p.drop_p = a.dy ? a.drop_p : 0.f; p.drop_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    p.seed = a.seed; p.site = a.site;
-    p.dpooled = a.dpooled; p.pool_scale = a.pool_scale; p.dh_n = a.dh_n;
-    p.sv0 = a.sv0; p.sv1 = a.sv1; p.sv2 = a.sv2; p.sv3 = a.sv3;
-    p.dgi = a.dgi; p.lddg = 3 * a.H; p.dghn = a.dghn; p.dbpart = a.dbpart;
-    DEP_CHECK_ARG(a.dbpart_rows >= nbt);
-    const size_t pay = (size_t)2 * nbtp_max * NC * BT * a.H * sizeof(float);
-    DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * NC <= 512);
-    p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
-    p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay; p.nofast = nofast_env();
-    DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
-    const size_t lds = (size_t)(BT * (48 + LPAD) + 64) * sizeof(float);
-    for (int b0 = 0; b0 < a.B; b0 += CH) {
-        const int cb = a.B - b0 < CH ? a.B - b0 : CH;
-        p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
-        // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
-        { const int rc_h = hdr_prepare(xbuf, 0, false, a.stream); if (rc_h) return rc_h; }
-        DEP_LAUNCH(gru_bwd_cluster16<4>, dim3(NC * p.nbtp), dim3(CT), lds, a.stream, p);
         DEP_CHECK_LAUNCH();
     }
     return DEP_OK;

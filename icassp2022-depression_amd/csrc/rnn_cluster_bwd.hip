@@ -37,7 +37,6 @@ struct P2 {
     int ntload;              // non-temporal one-touch input streams (default on; DEP_BWD_NTLD=0: plain loads)
     int wflags;              // DEP_BWD_WFLAGS: every compute wave raises its OWN epoch flag once its own payload stores are acknowledged (no workgroup barrier in front of the flag; the pollers watch 4 NC words)
     int dgpk;                // round 4: write the gate gradients as the PK image the bf16x3 GEMMs read without converting (gemm_bf16x3.hip FMT_PK): rows (t even, t+1) of an utterance hold the (hi, lo) bf16 pairs of both steps; burst kernel, 4H-wide layout, T even
-    int xhalf;               // experiment (DEP_BWD_XHALF=1): the sweep's workgroups on XCDs 0-3 only, two per CU; the launch has twice the blocks and those of XCDs 4-7 leave at once
 };
 
 struct StepIn { float2 r, z, n, hn, hp, dy; };
@@ -88,12 +87,7 @@ __global__ __launch_bounds__(KB ? CT + SVC_THREADS : CT) void gru_bwd_cluster_r1
     constexpr int KS = 96, KCB = KS / 16, LDG = KS + LPAD;
     constexpr int LDGB = KS + 8;                      // bf16 elements per row of a split plane (208-byte rows)
     const int H = p.H, T = p.T, NC = H / 32, NTT = H / 16;
-    int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
-    if (p.xhalf) {                                    // block 8k + x, x < 4  ->  member k / (nbtp/4) of tile (k % (nbtp/4)) * 4 + x: a tile's members share XCD x
-        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-        if (x >= 4) return;
-        c = k / (p.nbtp / 4); bt = (k % (p.nbtp / 4)) * 4 + x;
-    }
+    const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
     if (p.b0 + bt * BT >= p.B) return;
     if (ld_agent(p.status) != 0) return;           // an earlier sweep of this step gave up: the status word is sticky until the next dep_rnn_forward
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1023,19 +1017,7 @@ int dep_launch_cluster_fwd(const dep_sweep_args& a, void* xbuf, size_t xbuf_byte
 
 // May dep_launch_cluster_bwd write the gate gradients as the PK image (dep_sweep_bwd_args.dg_pk)?  Needs the burst-stream kernel
 // (its service waves' flush forms the pairs): H <= 256, bursts not switched off, not the two-per-CU placement experiment.
-bool dep_cluster_bwd_pk_ok(int H, int T) {
-    const char* v = getenv("DEP_BWD_BURST");
-    const int kbv = v ? atoi(v) : 4;
-    const char* x = getenv("DEP_BWD_XHALF");
-    return H <= 256 && T % 2 == 0 && kbv != 0 && kbv != 6 && !(x && x[0] == '1');
-}
-
-// DEP_BWD_AG: 1 = the all-gather exchange for the GRU-256 backward sweep, 0 = the reduce-scatter of fp32 partials
-bool dep_cluster_bwd_ag_on() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DEP_BWD_AG"); v = e ? (e[0] == '1' ? 1 : 0) : DEP_BWD_AG_DEFAULT; }
-    return v != 0;
-}
+bool dep_cluster_bwd_pk_ok(int H, int T) { return H <= 256 && T % 2 == 0; }
 
 int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_bytes) {
     DEP_CHECK_ARG(dep_cluster_ok(a.cell, a.H, a.B, a.dirs) && xbuf && xbuf_bytes >= dep_cluster_xbuf_bytes(a.cell, a.H, a.B, a.dirs));
@@ -1061,35 +1043,24 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.payload_bytes = (unsigned)pay;
     p.trace = trace_env() ? (long long*)(hdr_base(xbuf, a.hdr_slot) + TRACE_OFF) : nullptr;
     DepProfScope prof(DEP_PROF_GRU_BWD, a.stream);
-    static int kb_env = -1;                           // DEP_BWD_BURST=0: the round-1 kernel (every wave streams for itself, every step); 4 (default) or 6: burst length
-    if (kb_env < 0) { const char* v = getenv("DEP_BWD_BURST"); kb_env = v ? atoi(v) : 4; if (kb_env != 0 && kb_env != 4 && kb_env != 6) kb_env = 4; }
-    { static int wf_env = -1; if (wf_env < 0) { const char* v = getenv("DEP_BWD_WFLAGS"); wf_env = (v && v[0] == '0') ? 0 : 1; } p.wflags = wf_env; }     // default on; DEP_BWD_WFLAGS=0: one flag per member behind a workgroup barrier
-    { static int nt_env = -1; if (nt_env < 0) { const char* v = getenv("DEP_BWD_NT"); nt_env = (v && v[0] == '0') ? 0 : 1; } p.ntstream = nt_env; }
-    { static int ntl_env = -1; if (ntl_env < 0) { const char* v = getenv("DEP_BWD_NTLD"); ntl_env = (v && v[0] == '0') ? 0 : 1; } p.ntload = ntl_env; }
+    // burst length 4 (the round-1 schedule KB = 0 serves H = 512 only), per-wave epoch flags, non-temporal one-touch streams:
+    // the measured winners of rounds 2-5 (profiles/r04_ab_pairs.txt, r05_final_ab_switches.txt); the losers live in the git history
+    p.wflags = 1; p.ntstream = 1; p.ntload = 1;
     // (one tile's rows of the widest array must fit a 32-bit buffer offset)
     { const int mxl = p.lddg > p.lddy ? p.lddg : p.lddy; DEP_CHECK_ARG((size_t)(BT * a.T + 1) * (mxl > p.ldy ? mxl : p.ldy) * 4 < 0xffffffffull); }
-    static int xhalf_env = -1;
-    if (xhalf_env < 0) { const char* v = getenv("DEP_BWD_XHALF"); xhalf_env = (v && v[0] == '1') ? 1 : (v && v[0] == '2') ? 2 : 0; }
-    // 1: the whole batch's workgroups on XCDs 0-3, two per CU (round-1 schedule, 48 KB of LDS each); 2 (round 4, tools/exp_corun.py):
-    // placement only -- a batch of at most half a chunk on XCDs 0-3 with ONE burst-stream workgroup per CU, XCDs 4-7 left to another stream
-    const bool xpack = xhalf_env == 1 && a.H == 256 && a.B <= CH;
-    p.xhalf = (xpack || (xhalf_env == 2 && a.H == 256 && a.B <= CH / 2)) ? 1 : 0;
-    const int kb = (a.H >= 512 || xpack) ? 0 : kb_env;             // H = 512: 192 weight registers per compute wave leave no room for a second wave per SIMD
-    // Round 5: the all-gather exchange (AG above).  DEP_BWD_AG=1 selects it for the H = 256 split-precision burst kernel.
-    const bool ag = dep_cluster_bwd_ag_on() && a.H == 256 && a.split && kb == 4 && !p.xhalf;
-    if (ag) p.wflags = 1;                             // the all-gather step publishes per compute wave (no drain barrier)
-    const size_t lds = ag ? burst_lds_bytes_ag(4) + 2048 : xpack ? (size_t)49152 + 2048
-                             : (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
+    const int kb = a.H >= 512 ? 0 : 4;                // H = 512: 192 weight registers per compute wave leave no room for a second wave per SIMD
+    // H = 256, split products: the all-gather exchange of the members' gate gradients (round 5); every other shape / the exact-fp32 mode: the
+    // reduce-scatter of fp32 partial dh
+    const bool ag = a.H == 256 && a.split && kb == 4;
+    const size_t lds = ag ? burst_lds_bytes_ag(4) + 2048
+                          : (kb ? (burst_lds_bytes(kb) > EXCLUSIVE_LDS ? burst_lds_bytes(kb) : EXCLUSIVE_LDS) : EXCLUSIVE_LDS) + 2048;
     p.trall_off = (int)((lds - 2048) / 4);
     static bool attr_b = false;
     if (!attr_b) {
 #define DEP_BWD_ATTR1(N, S, V, X) (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<N, S, V, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((V ? burst_lds_bytes(V) > EXCLUSIVE_LDS ? burst_lds_bytes(V) : EXCLUSIVE_LDS : EXCLUSIVE_LDS) + 2048))
 #define DEP_BWD_ATTR(N, S, V) do { DEP_BWD_ATTR1(N, S, V, false); if (S) DEP_BWD_ATTR1(N, true, V, true); } while (0)
-        (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((burst_lds_bytes(4) > EXCLUSIVE_LDS ? burst_lds_bytes(4) : EXCLUSIVE_LDS) + 2048));
-        DEP_BWD_ATTR(1, false, 0); DEP_BWD_ATTR(1, true, 0); DEP_BWD_ATTR(1, false, 4); DEP_BWD_ATTR(1, true, 4); DEP_BWD_ATTR(1, false, 6); DEP_BWD_ATTR(1, true, 6);
-        DEP_BWD_ATTR(2, false, 0); DEP_BWD_ATTR(4, false, 0); DEP_BWD_ATTR(2, true, 0); DEP_BWD_ATTR(4, true, 0);
-        DEP_BWD_ATTR(2, false, 4); DEP_BWD_ATTR(4, false, 4); DEP_BWD_ATTR(2, true, 4); DEP_BWD_ATTR(4, true, 4);
-        DEP_BWD_ATTR(2, false, 6); DEP_BWD_ATTR(4, false, 6); DEP_BWD_ATTR(2, true, 6); DEP_BWD_ATTR(4, true, 6);
+        DEP_BWD_ATTR(1, false, 4); DEP_BWD_ATTR(1, true, 4);
+        DEP_BWD_ATTR(2, false, 4); DEP_BWD_ATTR(2, true, 4); DEP_BWD_ATTR1(4, false, 4, false);
         DEP_BWD_ATTR(8, false, 0); DEP_BWD_ATTR(8, true, 0);
         (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(burst_lds_bytes_ag(4) + 2048));
         (void)hipFuncSetAttribute((const void*)gru_bwd_cluster_r1<4, true, 4, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(burst_lds_bytes_ag(4) + 2048));
@@ -1106,12 +1077,9 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, a.hdr_slot, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
-        dim3 grid(NC * p.nbtp * (p.xhalf ? 2 : 1));
+        dim3 grid(NC * p.nbtp);
         const dim3 block(kb ? CT + SVC_THREADS : CT);
-#define DEP_BWD_LAUNCH1(N, S, X)                                                                                          \
-        do { if (kb == 4) DEP_LAUNCH((gru_bwd_cluster_r1<N, S, 4, X>), grid, block, lds, a.stream, p);            \
-             else if (kb == 6) DEP_LAUNCH((gru_bwd_cluster_r1<N, S, 6, X>), grid, block, lds, a.stream, p);       \
-             else DEP_LAUNCH((gru_bwd_cluster_r1<N, S, 0, X>), grid, block, lds, a.stream, p); } while (0)
+#define DEP_BWD_LAUNCH1(N, S, X) DEP_LAUNCH((gru_bwd_cluster_r1<N, S, 4, X>), grid, block, lds, a.stream, p)
 #define DEP_BWD_LAUNCH(N, S) do { if (S && a.sv16) DEP_BWD_LAUNCH1(N, true, true); else DEP_BWD_LAUNCH1(N, S, false); } while (0)
         switch (a.H) {                                // NTW = H / 64
             case 64: if (a.split) DEP_BWD_LAUNCH(1, true); else DEP_BWD_LAUNCH(1, false); break;
@@ -1120,8 +1088,7 @@ int dep_launch_cluster_bwd(const dep_sweep_bwd_args& a, void* xbuf, size_t xbuf_
                 if (ag && a.bf16st) DEP_LAUNCH((gru_bwd_cluster_r1<4, true, 4, true, true, true>), grid, block, lds, a.stream, p);
                 else if (ag && a.sv16) DEP_LAUNCH((gru_bwd_cluster_r1<4, true, 4, true, false, true>), grid, block, lds, a.stream, p);
                 else if (ag) DEP_LAUNCH((gru_bwd_cluster_r1<4, true, 4, false, false, true>), grid, block, lds, a.stream, p);
-                else if (a.bf16st) DEP_LAUNCH((gru_bwd_cluster_r1<4, true, 4, true, true>), grid, block, lds, a.stream, p);
-                else if (a.split) DEP_BWD_LAUNCH(4, true); else DEP_BWD_LAUNCH(4, false);
+                else DEP_BWD_LAUNCH(4, false);        // exact-fp32 mode
                 break;
             default:                                  // 512: round-1 schedule only (kb == 0)
                 if (a.split && a.sv16) DEP_LAUNCH((gru_bwd_cluster_r1<8, true, 0, true>), grid, block, lds, a.stream, p);

@@ -76,7 +76,7 @@ __device__ __forceinline__ float2 add2(float2 a, float2 b) { return make_float2(
 // loop's vmcnt(0)), and nobody loads slot (s + 2) % 4 for step s+2 before having gathered this member's step s+1 -- a gather never meets
 // a slot's previous tenant.  The slots are armed in the prologue, in front of the hello rendezvous (which SX therefore always runs).
 constexpr unsigned FX_SENT = 0xffffffffu;
-template <bool DROP, bool TRACE, bool SV16, bool BF = false, bool SX = false>
+template <bool DROP, bool TRACE, bool SV16, bool BF = false>
 __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     static_assert(!BF || SV16, "bf16 storage implies 16-bit gates");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -134,9 +134,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
     const unsigned pstride = (unsigned)p.nbtp * 3 * F_REGION;           // payload words (fits 32 bits: <= 2 x 32 x 3 x 4096)
     const unsigned tile_base = (unsigned)bt * 3 * F_REGION;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
-    unsigned* myflag = p.flags + bt * FNC + c;
-    unsigned* tflags = p.flags + bt * FNC;
-    if constexpr (SX) {
+    {
         // arm this member's words of all four slots (write-through: the placement is not known yet); the hello below is the rendezvous
         if (grp < 2) {
             const int l0 = tid & 63, j0 = l0 & 15, ul0 = jl * 16 + (l0 >> 4) * 4 + 2 * kh;
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         __syncthreads();
     }
     // (with a fallback the hello also runs under DEP_CLUSTER_NOFAST: it is what proves that every member is resident)
-    const int sxh = (p.nofast && !p.soft && !SX) ? 0 : cluster_same_xcd(p.hello + bt * FNC, FNC, c, p.status, p.soft);
+    const int sxh = cluster_same_xcd(p.hello + bt * FNC, FNC, c, p.status, p.soft);
     const int sx = (p.nofast && sxh >= 0) ? 0 : sxh;
     if (sx < 0) return;
     if (p.soft && p.force_soft == 3 && c == FNC - 1 && bt == 0) { if (threadIdx.x == 0) st_agent(p.soft, 1); return; }
@@ -320,7 +318,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         FSTAMP(1);
         bar_lds();                                        // groups 0/1: #1 of step s (partial sums in LDS) | group 2: #2 of step s
         FSTAMP(2);
-        const unsigned pbase = (unsigned)(SX ? (s & 3) : (s & 1)) * pstride + tile_base;
+        const unsigned pbase = (unsigned)(s & 3) * pstride + tile_base;
         if (grp == 2) {                                   // ---- slot Y of group 2 (the others are polling / gathering); placed before the gate block so that
                                                           // the accumulators' live range does not span it
             if (act) {
@@ -381,11 +379,12 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             if (s <= T) {                                 // publish first: it is on the other members' critical path
                 gu64* dst = (gu64*)(p.payload + (pbase + (unsigned)(grp == 0 ? 0 : 2) * F_REGION + j * FH + c * 32 + ul));
                 unsigned w0 = split_word(h.x), w1 = split_word(h.y);
-                if constexpr (SX) { if (w0 == FX_SENT) w0 = 0x7fc07fc0u; if (w1 == FX_SENT) w1 = 0x7fc07fc0u; }       // (NaN inputs only) never the sentinel
+                if (w0 == FX_SENT) w0 = 0x7fc07fc0u;      // (NaN inputs only) never the sentinel
+                if (w1 == FX_SENT) w1 = 0x7fc07fc0u;
                 const u64 bits = (u64)w0 | ((u64)w1 << 32);
                 if (fast) __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else __hip_atomic_store(dst, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if constexpr (SX) {                       // re-arm the slot two steps ahead
+                {                                         // re-arm the slot two steps ahead
                     const unsigned rb = (unsigned)((s + 2) & 3) * pstride + tile_base;
                     gu64* rdst = (gu64*)(p.payload + (rb + (unsigned)(grp == 0 ? 0 : 2) * F_REGION + j * FH + c * 32 + ul));
                     if (fast) __hip_atomic_store(rdst, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -433,10 +432,8 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
         }
         if (grp < 2 && s == T + 1) break;
         FSTAMP(3);
-        if (!SX && grp < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // payload stores acknowledged (SX: nobody waits for that)
         FSTAMP(4);
         bar_lds();                                        // groups 0/1: #2 (every publishing wave drained) | group 2: #3
-        if (!SX && tid == 0) { if (fast) st_local(myflag, (unsigned)s + 1u); else st_agent(myflag, (unsigned)s + 1u); }
         if (grp == 2) {
             // slot Z of group 2 (groups 0 / 1 are in their MFMAs: nothing latency-critical uses the CU's memory pipeline now, and
             // a CU returns loads in issue order across its waves -- DESIGN 4.1c): the member's HBM streams.  Write-out of step s,
@@ -450,13 +447,12 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
             issue_gi(tv, s + 2);
         } else {
             FSTAMP(5);
-            if constexpr (!SX) { if (!wait_flags(tflags, FNC, (unsigned)s + 1u, p.status, 6, p.soft)) return; }      // every wave polls (one poller + a verdict barrier measured no faster)
             FSTAMP(6);
             // gather: h0_s (next layer-0 step; also layer 1's input when there is no dropout) and h1_{s-2} (next layer-1 step)
             const bool need0 = s < T, need2 = s >= 2;    // (h0_{T-1} is still layer 1's last input)
             u32x4 v[2][2];
             unsigned mk[2] = {0u, 0u};                    // DROP: the four mask bits of the piece's units (two bytes: pairs col0 / 2, col0 / 2 + 1)
-            for (unsigned spins = 0;; ++spins) {          // (SX: until no word is the sentinel; otherwise one pass)
+            for (unsigned spins = 0;; ++spins) {          // until no word is the sentinel
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
                 if (rg == 0 ? need0 : need2) {
@@ -470,8 +466,7 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                     }
                 }
             }
-            if constexpr (!SX) break;
-            else {
+            {
                 unsigned mx = 0u;                         // max over the requested words: all-ones <=> one of them is still the sentinel
                 if (need0) { mx = max(max(max(v[0][0].x, v[0][0].y), max(v[0][0].z, v[0][0].w)), max(max(v[0][1].x, v[0][1].y), max(v[0][1].z, v[0][1].w)));
                              if (DROP && ((mk[0] | mk[1]) & 0xfcfcu)) mx = FX_SENT; }
@@ -481,6 +476,10 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
                 if ((spins & 63) == 63 && (ld_agent(p.status) != 0 || (p.soft && ld_agent(p.soft) != 0))) return;
             }
             }
+            // The re-arm store of slot (s + 2) % 4 (issued with this step's publish) must be acknowledged before the member's NEXT publish is
+            // issued.  The gather loads' own wait already covers it on gfx9 (loads and stores share vmcnt), so this costs nothing; it is spelled
+            // out so that the protocol does not hang on the compiler's placement of that wait.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
                 if (rg == 0 ? need0 : need2) {
@@ -528,330 +527,6 @@ __global__ __launch_bounds__(FTHREADS) void gru2_fwd_fused(FF p) {
 
 
 // =====================================================================================================================================
-// Round 5: the fused forward with DIRECT FRAGMENTS (gru2_fwd_df; DEP_FWD_DF).  What the all-gather backward taught (rnn_cluster_bwd.hip AG,
-// rnn_fused2_bwd.hip): the consumers of an exchanged vector do not need it in LDS -- published in MFMA B-fragment order ((hi, lo) bf16
-// pair words, 2 KB per member and layer), each wave reads exactly the fragments of ITS K quarter straight into registers (four 1 KB
-// wave-contiguous loads), so the step loses the gather into LDS planes, the planes themselves (50 KB), the barrier behind the gather and
-// the barrier in front of the single per-member flag (every publishing wave raises its own).  Roles as above, with
-//   wave kq of a group = K quarter kq (the 64 hidden units of source members 2kq, 2kq+1) x the member's two 16-unit tiles x three gates
-//   (the same 96 weight VGPRs and 36 MFMAs; four partials per output meet in LDS);
-//   group 2 (W_ih of layer 1 + every HBM stream) works on h0 of TWO steps ago: it never waits for a flag (the data has been visible since
-//   the last barrier but one), and the slack is what lets it stream: its HBM requests go out once the eight critical waves have issued
-//   their fragment loads (an LDS counter), the layer-0 input projection by DMA two steps ahead.
-// Fused step s (0..T+1):   [poll the two source members' flags -> 4 fragment loads -> 36 MFMAs -> partials to red] -> barrier 1 ->
-//   [gate math of both layers -> h published as pair words (+ the masked h0 for group 2) -> acknowledged -> own flag] -> barrier 2.
-// h0 is triple-buffered (group 2 reads step s-2 while step s+1 may already arrive), h1 double-buffered.
-constexpr int DF_RED = 12 * 6 * 256;          // floats: [wave][tile][gate][half of the lane's four][lane][2]
-constexpr int DF_GSL = 3;                     // slots of the staged layer-0 input projection (DMA two steps ahead)
-constexpr int DF_IARR = BT * 32;              // a DMA'd [16 utterances][32 units] fp32 array (unpadded, pieces XOR-swizzled by row)
-constexpr unsigned DF_MB0 = 4096, DF_MB1 = 2048;      // bytes per member: h0 planes (hi, lo) + masked h0 planes ; h1 planes
-constexpr int DF_RED2 = 4 * 6 * 256;          // group 2's partials exist twice (written in one gate phase, read in the next)
-constexpr size_t DF_LDS_BYTES = (size_t)(DF_RED + DF_RED2 + DF_GSL * 3 * DF_IARR + F_OBUF + F_BIAS + 2 * F_MBUF + 64) * sizeof(float);
-
-struct FD {
-    FF f;
-    unsigned* flags1;        // per-wave epoch flags of the h1 publishers (header slot 3); f.flags: the h0 publishers' (slot 0)
-    unsigned off_h1;         // byte offset of h1's two buffers behind h0's three
-    int dbg;                 // timing experiments (DEP_FWD_DBG; results are garbage): 1 = no projection prefetch, 2 = no write-out
-};
-
-template <bool DROP, bool SV16, bool BF>
-__global__ __launch_bounds__(FTHREADS) void gru2_fwd_df(FD pd) {
-    static_assert(!BF || SV16, "bf16 storage implies 16-bit gates");
-    const FF& p = pd.f;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int T = p.T;
-    const int c = blockIdx.x / p.nbtp, bt = blockIdx.x % p.nbtp;
-    if (p.b0 + bt * BT >= p.B) return;
-    if (ld_agent(p.status) != 0) return;
-    if (p.soft && ld_agent(p.soft) != 0) return;
-    if (p.soft && p.force_soft == 1) { if (threadIdx.x == 0) st_agent(p.soft, 1); return; }
-    if (p.soft && p.force_soft == 2 && c == FNC - 1 && bt == 0)
-        for (int i = 0; i < 8000; ++i) __builtin_amdgcn_s_sleep(127);
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = w >> 2, kq = w & 3;
-    const int shalf = kq >> 1;                        // group 2: which array / gate of a pair this wave streams
-    float* red = smem;
-    float* gbuf = red + DF_RED + DF_RED2;             // [3 slots][gate][16][32, swizzled]: layer-0 input projection of step s in slot s % 3
-    float* red2b = red + DF_RED;                      // second copy of group 2's four waves' partials (parity 1; parity 0 = their slots inside red)
-    float* obuf = gbuf + DF_GSL * 3 * DF_IARR;        // per layer 6 slots: h, r, z, n, hn, dropout(h) (layer 0 only) -- as gru2_fwd_fused
-    float* bias_l = obuf + F_OBUF;
-    float* mbuf = bias_l + F_BIAS;                    // [2 parities][16][36]: dropout mask values of step s in slot s & 1
-    unsigned* sig = reinterpret_cast<unsigned*>(mbuf + 2 * F_MBUF);
-    if (tid < F_BIAS) {
-        const int v = tid / 96, g = (tid / 32) % 3, u = tid & 31;
-        const float* src = v == 0 ? p.b_hh0 : (v == 1 ? p.b_hh1 : p.b_ih1);
-        bias_l[tid] = src[g * FH + c * 32 + u];
-    }
-    if (tid == 0) *sig = 0u;
-    // the group's weight slice: [own tile][gate][k-step of the quarter][hi, lo] -- the SAME image as gru2_fwd_fused's
-    // ([out tile][gate][k-step 0..7 = source member][plane][lane]), indexed by K quarter instead of K half
-    u32x4 wq[2][3][2][2];
-    {
-        const u32x4* wimg = grp == 0 ? p.wp0 : (grp == 1 ? p.wp1 : p.wpi);
-        const int lane = tid & 63;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
-                        wq[i][g][r][pl] = wimg[(size_t)(((((2 * c + i) * 3 + g) * 8 + 2 * kq + r) * 2 + pl)) * 64 + lane];
-    }
-    // per-role state (groups 0 / 1): st0 = (h_prev.x, h_prev.y, pool.x, pool.y)
-    f32x4 st0 = zero4();
-
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.payload, 0, p.payload_bytes, 0x00020000);
-    const unsigned par0 = (unsigned)p.nbtp * FNC * DF_MB0, par1 = (unsigned)p.nbtp * FNC * DF_MB1;
-    unsigned* tflags0 = p.flags + bt * FNC * 4;
-    unsigned* tflags1 = pd.flags1 + bt * FNC * 4;
-    unsigned* myflag = (grp == 0 ? tflags0 : tflags1) + c * 4 + kq;
-    const int sxh = (p.nofast && !p.soft) ? 0 : cluster_same_xcd(p.hello + bt * FNC, FNC, c, p.status, p.soft);
-    const int sx = (p.nofast && sxh >= 0) ? 0 : sxh;
-    if (sx < 0) return;
-    if (p.soft && p.force_soft == 3 && c == FNC - 1 && bt == 0) { if (threadIdx.x == 0) st_agent(p.soft, 1); return; }
-    const bool fast = sx == 1;
-    const int b0t = p.b0 + bt * BT;
-
-    // ---- group 2's streams
-    __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.gi, 0, (unsigned)((size_t)p.B * T * p.ldgi * 4), 0x00020000);
-    typedef __attribute__((address_space(3))) void* ldsp;
-    // layer-0 input projection (incl. b_ih) of step t -> gbuf slot t % 3 by DMA: 3 gates x 2 row halves = 6 wave instructions, wave kq takes
-    // instruction ids kq, kq + 4; lane -> (row lane / 8 of the half, LDS piece lane % 8) fetches the GLOBAL piece (lane % 8) ^ (row % 8)
-    auto stage_gi = [&](int tv, int t) {
-        const int ln = tv & 63, rw = ln >> 3;
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            const int q = qi * 4 + kq;
-            if (q < 6) {
-                const int g = q >> 1, hh = q & 1;
-                float* dst = gbuf + ((t % DF_GSL) * 3 + g) * DF_IARR + hh * 256;
-                if (t < T) {
-                    int b = b0t + hh * 8 + rw; b = b < p.B ? b : p.B - 1;
-                    const unsigned vo = (((unsigned)b * (unsigned)T + (unsigned)t) * (unsigned)p.ldgi + (unsigned)g * FH + (unsigned)c * 32u) * 4u + (unsigned)(((ln & 7) ^ (rw & 7)) * 16);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (ldsp)dst, 16, vo, 0, 0, 0);
-                } else {
-                    *reinterpret_cast<f32x4*>(dst + ln * 4) = zero4();
-                }
-            }
-        }
-    };
-    auto gswz = [](int j, int ul) { return j * 32 + (((ul >> 2) ^ (j & 7)) << 2) + (ul & 3); };
-    auto flush = [&](int tv, int s) {                 // results of fused step s: LDS -> HBM (16-byte stores); as gru2_fwd_fused's general loop
-        const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
-        if (b0t + su >= p.B) return;
-        const unsigned so = ((unsigned)(b0t + su) * T) * FH + c * 32 + sqd * 4;
-        constexpr int dslot0[6] = {0, DROP ? 2 : 1, DROP ? 3 : 2, DROP ? 4 : 3, DROP ? 5 : 4, 1};
-#pragma unroll
-        for (int pr = 0; pr < 6; ++pr) {
-            const int a = pr * 2 + shalf;             // obuf array (wave-uniform): 0..5 layer 0, 6..10 layer 1
-            const bool l0 = a < 6;
-            const int k = l0 ? a : a - 6;
-            const bool on = (l0 ? (s < T) : (s >= 2)) && a < 11 && (k == 0 || (k == 5 ? DROP : p.training != 0));
-            const int t = l0 ? s : s - 2;
-            float* base = l0 ? p.y0 : p.y1;
-            const unsigned slot = l0 ? dslot0[k] : k;
-            if (on) {
-                float* arr = base + (size_t)slot * p.ostride;
-                if (BF || (SV16 && k >= 1 && k <= 3)) {
-                    const float2 q = ld2(obuf + a * OARR + su * OROW + sqd * 2);
-                    *reinterpret_cast<float2*>(reinterpret_cast<unsigned short*>(arr) + (so + (unsigned)t * FH)) = q;
-                } else {
-                    *reinterpret_cast<f32x4*>(arr + (so + (unsigned)t * FH)) = ld4(obuf + a * OARR + su * OROW + sqd * 4);
-                }
-            }
-        }
-    };
-    if (grp == 2) { stage_gi(tid, 0); stage_gi(tid, 1); stage_gi(tid, 2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    if (DROP && grp == 2 && shalf == 1) {             // the mask of step 0
-        const int rem = tid & 127, su = rem >> 3, sqd = rem & 7;
-        const size_t o = ((size_t)(b0t + su) * T + 0) * FH + c * 32 + sqd * 4;
-        *reinterpret_cast<f32x4*>(mbuf + su * OROW + sqd * 4) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
-    }
-    __syncthreads();
-    // Group 2 runs ONE BARRIER out of phase with groups 0 / 1 (it passes one extra barrier here and one fewer at the end, as in gru2_fwd_fused):
-    // its product -- the same code site as theirs -- then falls into THEIR gate phase, when the matrix pipes are idle (all twelve waves multiplying
-    // at once is 108 MFMAs per SIMD in one phase: the first build's 6300-tick step), and its stream slot beside their product phase.
-    if (grp == 2) bar_lds();
-
-    for (int s = 0; s <= T + 1; ++s) {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));                  // launder: everything derived from tv is recomputed per step, not hoisted
-        const int lane = tv & 63;
-        const int lt = tv & 255, jl = lt >> 7, lp = (lt >> 1) & 63, half = lt & 1;
-        const int j = lp & 15, ul = jl * 16 + (lp >> 4) * 4 + 2 * half;       // gate threads: utterance row, unit pair (ul, ul+1) of the member's 32
-        // ---- the group's product.  group 0: W_hh(l0) h0_{s-1} (layer-0 step s) ; group 1: W_hh(l1) h1_{s-3} (layer-1 step s-2) ;
-        //      group 2 (in the others' gate phase of step s): W_ih(l1) dropout(h0_{s-1}) = the input projection of layer-1 step s-1, consumed in step s+1
-        const bool ract = grp == 0 ? (s < T) : (grp == 1 ? s >= 2 : (s >= 1 && s <= T));      // the role has a step to work for
-        const bool mact = grp == 0 ? (s >= 1 && s < T) : (grp == 1 ? s >= 3 : ract);          // ... and a non-zero operand
-        if (ract) {
-            f32x4 acc[2][3];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 3; ++g)          // K quarter 0 starts from the group's bias (group 2 with dropout: after the scale, below)
-                    acc[i][g] = (kq == 0 && !(DROP && grp == 2)) ? ld4(bias_l + grp * 96 + g * 32 + i * 16 + (lane >> 4) * 4) : zero4();
-            if (mact) {
-                // source block: h0 of step s-1 (group 0) / the masked h0 of step s-2 (group 2) / h1 of layer-1 step s-3, published in fused step s-1
-                const unsigned need = (unsigned)s;        // h0_{s-1} / h1 of layer-1 step s-3: both published in fused step s-1
-                if (!wait_flags((grp == 1 ? tflags1 : tflags0) + 8 * kq, 8, need, p.status, 6, p.soft)) return;
-                const unsigned src = (grp == 1 ? pd.off_h1 + (unsigned)((s - 1) & 1) * par1 + (unsigned)(bt * FNC + 2 * kq) * DF_MB1
-                                               : (unsigned)((s - 1) % 3) * par0 + (unsigned)(bt * FNC + 2 * kq) * DF_MB0 + ((DROP && grp == 2) ? 2048u : 0u))
-                                     + (unsigned)lane * 16u;
-                const unsigned mst = grp == 1 ? DF_MB1 : DF_MB0;
-                u32x4 hf[2][2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
-                        hf[r][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src + (unsigned)r * mst + (unsigned)pl * 1024u, 0, 16 /* sc1: served by L2 */);
-                if (grp != 2 && lane == 0) sig_raise(sig);        // this critical wave's requests are in the CU's queue
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const bf16x8 hh = __builtin_bit_cast(bf16x8, hf[r][0]), hl = __builtin_bit_cast(bf16x8, hf[r][1]);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[i][g][r][0]), wl = __builtin_bit_cast(bf16x8, wq[i][g][r][1]);
-                            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hl, acc[i][g], 0, 0, 0);
-                            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, hh, acc[i][g], 0, 0, 0);
-                            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hh, acc[i][g], 0, 0, 0);
-                        }
-                }
-            } else if (grp != 2 && lane == 0) sig_raise(sig);
-            if (DROP && grp == 2) {
-                // the group multiplied W_ih(l1) with the MASKED but UNSCALED planes of h0: the dropout scale goes onto the sums, then b_ih (K quarter 0)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        const f32x4 bb = kq == 0 ? ld4(bias_l + 2 * 96 + g * 32 + i * 16 + (lane >> 4) * 4) : zero4();
-                        acc[i][g] = acc[i][g] * p.drop_scale + bb;
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    float* rb = ((grp == 2 && (s & 1)) ? red2b + ((kq * 2 + i) * 3 + g) * 256 : red + ((w * 2 + i) * 3 + g) * 256) + lane * 2;
-                    st2(rb, f2(acc[i][g][0], acc[i][g][1])); st2(rb + 128, f2(acc[i][g][2], acc[i][g][3]));
-                }
-        } else if (grp != 2 && lane == 0) sig_raise(sig);
-        if (DROP && grp == 2 && shalf == 1 && s + 1 < T) {
-            // layer 0's dropout mask of step s+1 (two of this group's waves draw the member's 128 blocks), into the other parity
-            const int rem = tv & 127, su = rem >> 3, sqd = rem & 7;
-            const size_t o = ((size_t)(b0t + su) * T + (s + 1)) * FH + c * 32 + sqd * 4;
-            *reinterpret_cast<f32x4*>(mbuf + ((s + 1) & 1) * F_MBUF + su * OROW + sqd * 4) = dep_dropmask4(p.seed, p.site, o >> 2, p.drop_p, p.drop_scale);
-        }
-        bar_lds();                                        // groups 0 / 1: barrier 1 (partials in red) | group 2: barrier 2 of step s
-        if (grp == 2 && s == T + 1) break;                // (its one barrier fewer)
-        // ---- gate math (groups 0 and 1), h published at once
-        const bool gact = grp == 0 ? (s < T) : (grp == 1 && s >= 2);
-        if (gact) {
-            const int e2 = half * 128 + ((lp >> 4) * 16 + j) * 2;            // this thread's pair inside a [half][lane][2] tile block
-            float2 tot[3] = {f2(0.f, 0.f), f2(0.f, 0.f), f2(0.f, 0.f)}, gi[3];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)            // fixed order: deterministic
-#pragma unroll
-                for (int g = 0; g < 3; ++g) tot[g] = add2(tot[g], ld2(red + (((grp * 4 + q4) * 2 + jl) * 3 + g) * 256 + e2));
-            if (grp == 0) {
-                const float* gb = gbuf + (s % DF_GSL) * 3 * DF_IARR + gswz(j, ul);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) gi[g] = ld2(gb + g * DF_IARR);
-            } else {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) gi[g] = f2(0.f, 0.f);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) gi[g] = add2(gi[g], ld2((((s - 1) & 1) ? red2b + ((q4 * 2 + jl) * 3 + g) * 256 : red + (((8 + q4) * 2 + jl) * 3 + g) * 256) + e2));      // written in the previous step's gate phase
-            }
-            float2 mk = f2(1.f, 1.f);
-            if (DROP && grp == 0) mk = ld2(mbuf + (s & 1) * F_MBUF + j * OROW + ul);       // this step's mask values (0 or the scale), drawn by group 2
-            float2 r, z, hn, n, h;
-            r.x = fast_sigmoid(gi[0].x + tot[0].x); r.y = fast_sigmoid(gi[0].y + tot[0].y);
-            z.x = fast_sigmoid(gi[1].x + tot[1].x); z.y = fast_sigmoid(gi[1].y + tot[1].y);
-            hn = tot[2];
-            n.x = fast_tanh(gi[2].x + r.x * hn.x); n.y = fast_tanh(gi[2].y + r.y * hn.y);
-            h.x = (1.0f - z.x) * n.x + z.x * st0[0]; h.y = (1.0f - z.y) * n.y + z.y * st0[1];
-            st0[0] = h.x; st0[1] = h.y; st0[2] += h.x; st0[3] += h.y;
-            const float2 hd = f2(h.x * mk.x, h.y * mk.y);
-            if (grp == 0 || s <= T) {                     // layer 0 always publishes (layer 1's input); layer 1 while a layer-1 step follows
-                unsigned hi, lo;
-                split_pair(h.x, h.y, hi, lo);
-                const unsigned pw = (unsigned)(half + 2 * ((lp >> 4) & 1) + 4 * j + 64 * (lp >> 5) + 128 * jl) * 4u;
-                const unsigned po = (grp == 0 ? (unsigned)(s % 3) * par0 + (unsigned)(bt * FNC + c) * DF_MB0
-                                              : pd.off_h1 + (unsigned)(s & 1) * par1 + (unsigned)(bt * FNC + c) * DF_MB1) + pw;
-                unsigned mh = 0u, ml = 0u;
-                if (DROP && grp == 0) split_pair(mk.x != 0.f ? h.x : 0.f, mk.y != 0.f ? h.y : 0.f, mh, ml);
-                if (fast) {
-                    __builtin_amdgcn_raw_buffer_store_b32(hi, rsrc, po, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(lo, rsrc, po + 1024, 0, 0);
-                    if (DROP && grp == 0) { __builtin_amdgcn_raw_buffer_store_b32(mh, rsrc, po + 2048, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(ml, rsrc, po + 3072, 0, 0); }
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(hi, rsrc, po, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(lo, rsrc, po + 1024, 0, 16);
-                    if (DROP && grp == 0) { __builtin_amdgcn_raw_buffer_store_b32(mh, rsrc, po + 2048, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(ml, rsrc, po + 3072, 0, 16); }
-                }
-            }
-            float* ob = obuf + grp * (6 * OARR) + j * OROW + ul;            // results for the streaming waves
-            if constexpr (BF) {
-                typedef float f2v __attribute__((ext_vector_type(2)));
-                typedef __bf16 b2v __attribute__((ext_vector_type(2)));
-                float* o16 = obuf + grp * (6 * OARR) + j * OROW + (ul >> 1);
-                const f2v hv = {h.x, h.y}, nv = {hn.x, hn.y};
-                o16[0] = __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(hv, b2v)));
-                o16[4 * OARR] = __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(nv, b2v)));
-            } else { st2(ob, h); st2(ob + 4 * OARR, hn); }
-            if constexpr (SV16) {
-                float* o16 = obuf + grp * (6 * OARR) + j * OROW + (ul >> 1);
-                o16[OARR] = __uint_as_float(pack_unorm2(r.x, r.y)); o16[2 * OARR] = __uint_as_float(pack_unorm2(z.x, z.y));
-                o16[3 * OARR] = __uint_as_float(pack_snorm2(n.x, n.y));
-            } else {
-                st2(ob + OARR, r); st2(ob + 2 * OARR, z); st2(ob + 3 * OARR, n);
-            }
-            if (DROP && grp == 0) {
-                if constexpr (BF) {
-                    typedef float f2v __attribute__((ext_vector_type(2)));
-                    typedef __bf16 b2v __attribute__((ext_vector_type(2)));
-                    const f2v dv = {hd.x, hd.y};
-                    obuf[j * OROW + (ul >> 1) + 5 * OARR] = __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(dv, b2v)));
-                } else st2(ob + 5 * OARR, hd);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's words are acknowledged
-            if (lane == 0 && (grp == 0 || s <= T)) { if (fast) st_local(myflag, (unsigned)s + 1u); else st_agent(myflag, (unsigned)s + 1u); }
-        }
-        if (grp == 2) {
-            // group 2's stream slot, beside the others' product phase of step s+1: the results of step s go out at once (posted stores disturb
-            // nobody: rnn_fused2_bwd.hip), the projection three steps ahead is requested once the eight critical waves of step s+1 have issued
-            // their fragment loads (an HBM load in the CU's queue holds back every load behind it)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // last slot's requests have landed (the projection of step s+2 is read behind barrier 1 of that step)
-            if (!(pd.dbg & 2)) flush(tv, s);
-            {
-                const unsigned want = 8u * ((unsigned)s + 2u);
-                for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
-            }
-            if (!(pd.dbg & 1)) stage_gi(tv, s + 3);
-        }
-        bar_lds();                                        // groups 0 / 1: barrier 2 (red may be rewritten, obuf is complete) | group 2: barrier 1 of step s+1
-    }
-    if (grp == 2) flush(tid, T + 1);
-    {
-        const int lt = tid & 255, lp = (lt >> 1) & 63;
-        const int b = b0t + (lp & 15), col = c * 32 + (lt >> 7) * 16 + (lp >> 4) * 4 + 2 * (lt & 1);
-        if (b < p.B) {
-            if (grp == 0 && p.hn0) st2(p.hn0 + (size_t)b * FH + col, f2(st0[0], st0[1]));
-            if (grp == 1) {
-                if (p.pooled) st2(p.pooled + (size_t)b * FH + col, f2(st0[2] * p.pool_scale, st0[3] * p.pool_scale));
-                if (p.hn1) st2(p.hn1 + (size_t)b * FH + col, f2(st0[0], st0[1]));
-            }
-        }
-    }
-}
-
 }  // namespace
 
 bool dep_fused2_ok(int cell, int H, int L, int dirs) {
@@ -863,8 +538,7 @@ bool dep_fused2_ok(int cell, int H, int L, int dirs) {
 size_t dep_fused2_xbuf_bytes(int B) {
     const int CH = dep_cluster_chunk(FNC, 1, 256);
     const int nbtp = (dep_cdiv(B < CH ? B : CH, BT) + 7) / 8 * 8;
-    const size_t a = (size_t)4 * nbtp * 3 * F_REGION * sizeof(float), b = (size_t)nbtp * FNC * (3 * DF_MB0 + 2 * DF_MB1);      // gather form (four slots: SX) / direct-fragment form
-    return PAYLOAD_OFF + (a > b ? a : b) + 4096;
+    return PAYLOAD_OFF + (size_t)4 * nbtp * 3 * F_REGION * sizeof(float) + 4096;      // four sentinel-armed slots
 }
 
 int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_bytes) {
@@ -883,7 +557,7 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     DEP_CHECK_ARG(!drop || a.y0d == a.y0 + a.ostride);
     if (a.training) for (int k = 0; k < 4; ++k)
         DEP_CHECK_ARG(a.sv[0][k] == a.y0 + (size_t)(k + (drop ? 2 : 1)) * a.ostride && a.sv[1][k] == a.y1 + (size_t)(k + 1) * a.ostride);
-    const size_t pay = (size_t)4 * nbtp_max * 3 * F_REGION * sizeof(float);      // four slots (SX; the flag form uses two)
+    const size_t pay = (size_t)4 * nbtp_max * 3 * F_REGION * sizeof(float);      // four sentinel-armed slots
     DEP_CHECK_ARG(xbuf && PAYLOAD_OFF + pay <= xbuf_bytes && (size_t)nbtp_max * FNC <= 256);
     DEP_CHECK_ARG(!drop || a.y0d);
     p.status = (unsigned*)xbuf; p.flags = (unsigned*)(hdr_base(xbuf, 0) + FLAG_OFF); p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
@@ -893,73 +567,29 @@ int dep_launch_fused2_fwd(const dep_fused2_args& a, void* xbuf, size_t xbuf_byte
     const bool sv16 = a.training && a.sv16;
     const bool bf = a.training && a.bf16st;
     DEP_CHECK_ARG(!bf || sv16);
-    { static int nt = -1; if (nt < 0) { const char* e = getenv("DEP_FWD_NT"); nt = (e && e[0] == '1') ? 1 : 0; }      // measured: no effect on this launch (its payload, 0.4 MB per XCD, survives anyway) -> off
-      p.ntstore = (nt && (size_t)7 * a.ostride * sizeof(float) < 0xfffffff0ull) ? 1 : 0; }       // a layer's arrays span < 4 GB from its y
+    p.ntstore = 0;                                    // (non-temporal write-out measured: no effect on this launch -- its payload, 0.4 MB per XCD, survives anyway)
     { static int fs = -1; if (fs < 0) { const char* e = getenv("DEP_FORCE_SOFT_FALLBACK"); fs = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; } p.force_soft = fs; }
     static bool attr = false;
     if (!attr) {
-#define F2_ATTR(D, TR, X) do { (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<D, TR, X, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES); \
-                               (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<D, TR, X, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES); } while (0)
+#define F2_ATTR(D, TR, X) (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<D, TR, X, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES)
         (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<true, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gru2_fwd_fused<false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
         F2_ATTR(true, false, false); F2_ATTR(false, false, false); F2_ATTR(true, true, false); F2_ATTR(false, true, false);
         F2_ATTR(true, false, true); F2_ATTR(false, false, true); F2_ATTR(true, true, true); F2_ATTR(false, true, true);
 #undef F2_ATTR
         attr = true;
     }
     DepProfScope prof(DEP_PROF_GRU_FWD, a.stream);
-    static int df = -1;
-    if (df < 0) { const char* e = getenv("DEP_FWD_DF"); df = e ? (e[0] == '1' ? 1 : 0) : DEP_FWD_DF_DEFAULT; }
-    // round 5: the direct-fragment form (gru2_fwd_df).  Not with the phase trace (it has no stamps) nor with non-temporal write-out.
-    if (df && !p.trace && !p.ntstore && (size_t)a.B * a.T * p.ldgi * 4 < 0xfffffff0ull) {      // (32-bit offsets into the projection)
-        static_assert(DEP_HDR_SLOTS >= 4, "the direct-fragment forward keeps h1's flags in header slot 3 (slots 1, 2: the fallback sweeps)");
-        static bool attr_d = false;
-        if (!attr_d) {
-#define DF_ATTR(D, S, X) (void)hipFuncSetAttribute((const void*)gru2_fwd_df<D, S, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS_BYTES)
-            DF_ATTR(true, false, false); DF_ATTR(false, false, false); DF_ATTR(true, true, false); DF_ATTR(false, true, false); DF_ATTR(true, true, true); DF_ATTR(false, true, true);
-#undef DF_ATTR
-            attr_d = true;
-        }
-        for (int b0 = 0; b0 < a.B; b0 += CH) {
-            const int cb = a.B - b0 < CH ? a.B - b0 : CH;
-            FD pd{}; pd.f = p;
-            { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DEP_FWD_DBG"); dbg = e ? atoi(e) : 0; } pd.dbg = dbg; }
-            pd.f.b0 = b0; pd.f.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
-            const size_t payd = (size_t)pd.f.nbtp * FNC * (3 * DF_MB0 + 2 * DF_MB1);
-            DEP_CHECK_ARG(PAYLOAD_OFF + payd <= xbuf_bytes && (size_t)a.B * a.T * p.ldgi * 4 < 0xfffffff0ull);
-            pd.f.payload_bytes = (unsigned)payd; pd.off_h1 = (unsigned)((size_t)3 * pd.f.nbtp * FNC * DF_MB0);
-            pd.flags1 = (unsigned*)(hdr_base(xbuf, 3) + FLAG_OFF);
-            { const int rc_h = hdr_prepare(xbuf, 0, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
-            { const int rc_h = hdr_prepare(xbuf, 3, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
-            const dim3 grid(FNC * pd.f.nbtp), blk(FTHREADS);
-#define DF_GO(D) do { if (bf) DEP_LAUNCH((gru2_fwd_df<D, true, true>), grid, blk, DF_LDS_BYTES, a.stream, pd); \
-                      else if (sv16) DEP_LAUNCH((gru2_fwd_df<D, true, false>), grid, blk, DF_LDS_BYTES, a.stream, pd); \
-                      else DEP_LAUNCH((gru2_fwd_df<D, false, false>), grid, blk, DF_LDS_BYTES, a.stream, pd); } while (0)
-            if (drop) DF_GO(true); else DF_GO(false);
-#undef DF_GO
-            DEP_CHECK_LAUNCH();
-        }
-        return DEP_OK;
-    }
-    // round 5: the sentinel hand-off (SX above).  DEP_FWD_SX=0: acknowledgement wait + flag + poll.
-    static int sx = -1;
-    if (sx < 0) { const char* e = getenv("DEP_FWD_SX"); sx = e ? (e[0] == '1' ? 1 : 0) : DEP_FWD_SX_DEFAULT; }
     for (int b0 = 0; b0 < a.B; b0 += CH) {
         const int cb = a.B - b0 < CH ? a.B - b0 : CH;
         p.b0 = b0; p.nbtp = (dep_cdiv(cb, BT) + 7) / 8 * 8;
         // flags / hello words only: the status word is sticky over every sweep of a step (cleared by dep_rnn_forward)
         { const int rc_h = hdr_prepare(xbuf, 0, a.hdr_clean && b0 == 0, a.stream); if (rc_h) return rc_h; }
         const dim3 grid(FNC * p.nbtp), blk(FTHREADS);
-#define F2_LAUNCH(D, TR) do { if (sx) { if (sv16) DEP_LAUNCH((gru2_fwd_fused<D, TR, true, false, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
-                                        else DEP_LAUNCH((gru2_fwd_fused<D, TR, false, false, true>), grid, blk, F_LDS_BYTES, a.stream, p); } \
-                              else if (sv16) DEP_LAUNCH((gru2_fwd_fused<D, TR, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
+#define F2_LAUNCH(D, TR) do { if (sv16) DEP_LAUNCH((gru2_fwd_fused<D, TR, true>), grid, blk, F_LDS_BYTES, a.stream, p); \
                               else DEP_LAUNCH((gru2_fwd_fused<D, TR, false>), grid, blk, F_LDS_BYTES, a.stream, p); } while (0)
         if (bf) {                                         // bf16-storage mode (never traced)
-            if (sx) { if (drop) DEP_LAUNCH((gru2_fwd_fused<true, false, true, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
-                      else DEP_LAUNCH((gru2_fwd_fused<false, false, true, true, true>), grid, blk, F_LDS_BYTES, a.stream, p); }
-            else if (drop) DEP_LAUNCH((gru2_fwd_fused<true, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
+            if (drop) DEP_LAUNCH((gru2_fwd_fused<true, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
             else DEP_LAUNCH((gru2_fwd_fused<false, false, true, true>), grid, blk, F_LDS_BYTES, a.stream, p);
         } else if (p.trace) {                             // DEP_TRACE=1: the stamped variant (tools/trace_fused.py)
             if (drop) F2_LAUNCH(true, true); else F2_LAUNCH(false, true);

@@ -71,8 +71,6 @@ struct FB {
     const char* sb1; const char* sb0; unsigned sbytes1, sbytes0;
     unsigned o_sv1, o_y1, o_sv0, o_y0;                              // saved gates r (then z, n, hn at + k svstride floats), forward sequence
     long long* trace;                                               // DEP_TRACE=1: stamps of workgroup 0 (tools/trace_fbwd.py), else nullptr
-    int pktop;                                                      // 1: pair write-out at the top of the step (default), 0: behind the issue signal (DEP_FBWD_PKTOP)
-    int dbg;                                                        // timing experiments (DEP_FBWD_DBG; results are garbage): 1 = no input streams, 2 = no write-out
 };
 
 // Registers: 3 waves per SIMD -> 168 VGPRs, 96 of them weights.  Per-thread indices are re-derived every step from a laundered
@@ -176,7 +174,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             for (int hh = 0; hh < (g16 ? 1 : 2); ++hh, ++q) {
                 if ((q & 3) != gwc) continue;             // compile-time
                 float* dst = ibuf + (uu % ISL) * IPAR + iarr_off(a, SV16, HASDY, BF) + hh * 256;
-                if (on && !(p.dbg & 1)) {
+                if (on) {
                     const unsigned so = (k < 4 ? (l1 ? p.o_sv1 : p.o_sv0) + (unsigned)k * p.svstride * 4u : (k == 4 ? (l1 ? p.o_y1 : p.o_y0) : 0u))
                                         + (unsigned)t * (g16 ? BH * 2u : BH * 4u);
                     const unsigned v_ = g16 ? vo[0] : vo[1 + hh];
@@ -350,7 +348,7 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
             // critical waves are in their gate phase (LDS only) for the next ~1300 ticks, and this group's own fragment requests queue behind its
             // stores for a round trip it can afford (its product is due at the step's barrier, ~5000 ticks away).  Behind the signal the request
             // queue pushed back for ~2000 ticks on every even step while the critical waves stood at the barrier (profiles/r05_final_trace_bwd.txt).
-            if (grp == 1 && v >= 2 && !(v & 1) && !(p.dbg & 2) && p.pktop) { PkOut po; flush_pk_prep(tv, v - 2, po); flush_pk_issue(po); }
+            if (grp == 1 && v >= 2 && !(v & 1)) { PkOut po; flush_pk_prep(tv, v - 2, po); flush_pk_issue(po); }
         }
         // (The DMA REQUESTS at the top of the step as well -- distance 1, no signal -- measured 1.06 -> 1.27 ms: HBM loads in the CU's queue hold back the
         // critical waves' polls and fragment loads for their whole round trip; posted stores do not.)
@@ -419,26 +417,11 @@ __global__ __launch_bounds__(BTHREADS) void gru2_bwd_fused(FB p) {
                 const unsigned want = 8u * ((unsigned)v + 1u);
                 for (int spin = 0; spin < 20000 && sig_read(sig) < want; ++spin) __builtin_amdgcn_s_sleep(1);
             };
-            bool pk_done = false;
-            if constexpr (PK) {
-                if (v >= 2 && !(v & 1) && !(p.dbg & 2) && !p.pktop) {         // two separate code paths: the prepared write-out's 36 registers live only in this one
-                    PkOut po;
-                    flush_pk_prep(tv, v - 2, po);
-                    __builtin_amdgcn_sched_barrier(0);
-                    wait_signal();
-                    BSTMP(5);
-                    stage(tv, v + PF, vo);
-                    flush_pk_issue(po);
-                    pk_done = true;
-                }
-            }
-            if (!pk_done) {
-                __builtin_amdgcn_sched_barrier(0);
-                wait_signal();
-                BSTMP(5);
-                stage(tv, v + PF, vo);
-                if constexpr (!PK) { if (!(p.dbg & 2) && v >= 1) flush(tv, v - 1); }
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_signal();
+            BSTMP(5);
+            stage(tv, v + PF, vo);
+            if constexpr (!PK) { if (v >= 1) flush(tv, v - 1); }
         }
         if (PF == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // distance 1: the DMA'd inputs of step v+1 must be in LDS at this barrier
         BSTMP(6);
@@ -530,8 +513,6 @@ int dep_launch_fused2_bwd(const dep_fused2_bwd_args& a, void* xbuf, size_t xbuf_
     p.hello = (unsigned*)(hdr_base(xbuf, 0) + HELLO_OFF);
     p.payload = (float*)((char*)xbuf + PAYLOAD_OFF); p.nofast = nofast_env();
     p.trace = trace_env() ? (long long*)(hdr_base(xbuf, 0) + TRACE_OFF) : nullptr;
-    { static int pt = -1; if (pt < 0) { const char* e = getenv("DEP_FBWD_PKTOP"); pt = (e && e[0] == '0') ? 0 : 1; } p.pktop = pt; }
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DEP_FBWD_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     {   // the input streams' buffer resources: per layer one base below its arrays, 32-bit offsets
         const size_t arr = (size_t)a.B * a.T * BH * sizeof(float);
         auto span = [&](const float* y, const float* sv, const char*& base, unsigned& bytes, unsigned& oy, unsigned& osv) {

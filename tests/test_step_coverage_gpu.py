@@ -144,7 +144,7 @@ def run_fusion_step():
     tf, af = model.pretrained_feature((xa, xt))                       # train mode: dropout active
     S = SAMPLE; Sd = torch.from_numpy(S).to(DEV)
     p = model.dropout
-    assert p == 0.5 and model.training
+    assert p == cfg['dropout'] == 0.3 and model.training             # fuse_net_whole.py's config: 0.3
     masks = {'rnn_text': [_mask(B * T * 2 * Ht, p, seed, 16, (B, T, 2 * Ht), S)],
              'rnn_audio': [_mask(B * T * Ha, p, seed + 1, 16, (B, T, Ha), S)],
              't0': _mask(B * Ht, p, seed, L.SITE_FC0, (B, Ht), S), 't1': _mask(B * Ht, p, seed, L.SITE_FC1, (B, Ht), S),

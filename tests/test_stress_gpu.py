@@ -32,27 +32,13 @@ CASES = [
     ('gru', 8, {}, ['--H', '128']),                               # 32-unit-member forward kernel
     ('gru', 6, {'DEP_FUSED2_BWD': '0'}, []),                      # round 5: the fused two-layer (all-gather) backward is the default; 0 = the two per-layer sweeps + dX GEMM
     ('gru', 6, {'DEP_FUSED2_BWD': '0'}, ['--load', '--load-phase', 'bwd']),
-    ('gru', 8, {'DEP_BWD_AG': '0', 'DEP_FUSED2_BWD': '0'}, []),                          # round 5: the default backward exchange is the all-gather of gate gradients; 0 = the reduce-scatter of fp32 partials
-    ('gru', 6, {'DEP_BWD_AG': '0', 'DEP_FUSED2_BWD': '0'}, ['--load', '--load-phase', 'bwd']),
-    ('gru', 6, {'DEP_FWD_DF': '1'}, []),                          # opt-in direct-fragment fused forward
-    ('gru', 6, {'DEP_FWD_SX': '0'}, []),                          # round 5: the fused forward's hand-off is the sentinel form by default; 0 = acknowledgement wait + flag + poll
-    ('gru', 6, {'DEP_FWD_SX': '0'}, ['--load', '--load-m', '1024', '--two-refs']),
-    ('gru', 8, {'DEP_BWD_BURST': '0', 'DEP_FUSED2_BWD': '0'}, []),                       # round-1 backward schedule (no service waves)
-    ('gru', 8, {'DEP_BWD_BURST': '6', 'DEP_FUSED2_BWD': '0'}, ['--load', '--load-phase', 'bwd']),   # longer bursts, with a co-scheduled kernel
-    ('gru', 6, {'DEP_BWD_BURST': '4', 'DEP_NUM_CUS': '200'}, ['--H', '128']),
     ('gru', 6, {}, ['--H', '64']),                                # two members per tile
     ('gru', 4, {}, ['--H', '512', '--T', '100']),                 # sixteen members per tile, two chunks of 256 utterances
     ('gru', 4, {}, ['--H', '512', '--T', '60', '--load', '--load-phase', 'bwd']),
     ('lstm', 12, {}, []),
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, ['--load']),
     ('lstm', 4, {'DEP_NUM_CUS': '200'}, []),
-    ('lstm', 6, {'DEP_LSTM_BURST': '0'}, []),                     # round-1 BiLSTM schedule (no service waves)
-    ('lstm', 6, {'DEP_LSTM_DF': '0'}, []),                        # round 5: the default BiLSTM forward reads h_t as fragments from the exchange buffer (sentinel hand-off, per-step streams); 0 = through LDS planes
-    ('lstm', 6, {'DEP_LSTM_DF': '0'}, ['--load']),
-    ('lstm', 6, {'DEP_LSTM_DF': '1', 'DEP_LSTM_SE': '0'}, []),    # direct fragments with burst streams; the backward with burst streams + one flag per member
-    ('lstm', 6, {'DEP_LSTM_DF': '2'}, ['--load']),                # per-step streams with per-wave flags (the default adds the sentinel hand-off)
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, []),
-    ('lstm', 6, {'DEP_LSTM_SE': '0'}, ['--load', '--load-phase', 'bwd']),
     ('lstm', 6, {}, ['--load', '--load-phase', 'bwd']),           # burst-stream BiLSTM backward with a co-scheduled kernel
 ]
 
@@ -118,68 +104,6 @@ def test_per_layer_backward_sweeps_pass_the_kernel_parity_suite():
     RNN-stack suite against the oracle (the other shapes run the per-layer kernels in either mode)."""
     e = dict(os.environ, DEP_FUSED2_BWD='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
-                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout
-
-
-@pytest.mark.parametrize('burst', ['0', '6'])
-def test_backward_burst_variants_pass_the_kernel_parity_suite(burst):
-    """gru_bwd_cluster_r1<.., KB>: KB = 4 is the default; the round-1 schedule (0) and the longer bursts (6)
-    stay parity-green -- the GRU part of the RNN-stack suite in a process with DEP_BWD_BURST set, against the oracle."""
-    e = dict(os.environ, DEP_BWD_BURST=burst, DEP_FUSED2_BWD='0')      # (the per-layer sweeps: the fused backward is the default since round 5)
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
-                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout
-
-
-def test_backward_reduce_scatter_exchange_passes_the_kernel_parity_suite():
-    """Round 5: gru_bwd_cluster_r1<.., AG = true> (all-gather of the members' gate gradients, column-sliced W_hh) is the default for
-    H = 256; DEP_BWD_AG=0 selects the reduce-scatter of fp32 partial dh it replaced, which stays parity-green: the GRU part of the
-    RNN-stack suite against the oracle."""
-    e = dict(os.environ, DEP_BWD_AG='0', DEP_FUSED2_BWD='0')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
-                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout
-
-
-def test_direct_fragment_forward_passes_the_kernel_parity_suite():
-    """Round 5: gru2_fwd_df (rnn_fused2.hip; the fused forward reading its exchanged h as MFMA fragments straight from the exchange buffer,
-    opt-in DEP_FWD_DF=1 -- measured slower than the gather form, profiles/r05_s8_*) stays parity-green: the GRU part of the RNN-stack
-    suite against the oracle."""
-    e = dict(os.environ, DEP_FWD_DF='1')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
-                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout
-
-
-def test_flag_handoff_forward_passes_the_kernel_parity_suite():
-    """Round 5: gru2_fwd_fused<.., SX = false> (payload acknowledged -> barrier -> flag -> poll -> gather; DEP_FWD_SX=0) stays parity-green
-    beside the sentinel hand-off that is the default now: the GRU part of the RNN-stack suite against the oracle."""
-    e = dict(os.environ, DEP_FWD_SX='0')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
-                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout
-
-
-def test_lstm_lds_plane_forward_passes_the_kernel_parity_suite():
-    """Round 5: lstm_fwd_cluster<.., DF = 0> (h_t gathered into LDS planes, one flag per member, three barriers a step; DEP_LSTM_DF=0) and
-    lstm_bwd_cluster<.., SE = false> (burst streams, drain barrier; DEP_LSTM_SE=0) stay parity-green beside the per-step-stream defaults."""
-    e = dict(os.environ, DEP_LSTM_DF='0', DEP_LSTM_SE='0')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'lstm',
-                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout
-
-
-def test_lstm_round1_schedule_passes_the_kernel_parity_suite():
-    """lstm_fwd_cluster / lstm_bwd_cluster<.., KB = 0> (every wave streams for itself; DEP_LSTM_BURST=0) stay parity-green."""
-    e = dict(os.environ, DEP_LSTM_BURST='0')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'lstm',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
