@@ -158,6 +158,60 @@ def dominant_sweep(prof, steps, name, B, T, H):
             'layers_per_launch': layers_per_launch, 'sweep_flops': sweep_flops}
 
 
+# the time-parallel contractions of one train step, algorithmic flops (2 M N K, one product per multiply) per GEMM form.
+# GRU stack: layer 0's input projection (layer 1's runs inside the fused forward) and the four weight gradients (layer 1's dX inside the
+# fused backward); BiLSTM stack: direction-stacked projections of both layers, dX of layer 1, dW_ih (direction-stacked) and dW_hh (per
+# direction) of both layers; fusion: the two frozen encoders' forward projections only.
+def gemm_flops_per_step(name, B, T):
+    BT = float(B) * T
+    gru = {'gemm_nt': 2 * BT * 768 * 256, 'gemm_tn': 4 * 2 * BT * 768 * 256}
+    lstm_f = 2 * BT * 1024 * 1024 + 2 * BT * 1024 * 256
+    lstm = {'gemm_nt': lstm_f, 'gemm_nn': 2 * BT * 1024 * 256,
+            'gemm_tn': 2 * BT * 1024 * 1024 + 2 * BT * 1024 * 256 + 2 * (2 * 2 * BT * 512 * 128)}
+    return {'audio_gru': gru, 'text_bilstm': lstm, 'fusion': {'gemm_nt': gru['gemm_nt'] + lstm_f}}[name]
+
+
+SURVEY_8D_BYTES_PER_STEP = {'audio_gru': 0.944e9, 'text_bilstm': 2.517e9, 'fusion': 0.786e9}     # SURVEY 8(d), fp32 storage column
+
+
+def pmc_step_bytes(name):
+    """HBM bytes of one train step from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json) -- only when the record was taken at the
+    kernel digest this library was built from."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        stamp = open(os.path.join(ROOT, 'icassp2022-depression_amd', 'libdep_rnn.so.stamp')).read().strip()
+        return rec.get('step_bytes', {}).get(name) if rec.get('kernel_digest') == stamp else None
+    except Exception:
+        return None
+
+
+def kernel_families(cats, steps, name, B, T, H, split, step_ms):
+    """The two kernel families of a step side by side: recurrent sweeps and time-parallel contractions, each with its
+    algorithmic flops, ms per step, fraction of the dense matrix-pipe peak of the mode and share of the step; `dominant` = the larger one."""
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+    gf = gemm_flops_per_step(name, B, T)
+    fam = {}
+    g_ms = sum(v[0] for k, v in cats.items() if k.startswith('gemm')) / steps
+    g_fl = sum(gf.get(k, 0.0) for k in cats if k.startswith('gemm'))
+    s_ms = sum(v[0] for k, v in cats.items() if 'sweep' in k) / steps
+    s_fl = 0.0
+    for k in cats:
+        if 'sweep' not in k:
+            continue
+        Gk, dk, Hk = (4, 2, 128) if k.startswith('lstm') else (3, 1, H)
+        # both layers' recurrent products; the fused GRU launches also carry layer 1's input projection (forward) / dX (backward)
+        extra = 1.5 if (k.startswith('gru') and cats[k][1] / steps < 1.5) else 1.0
+        s_fl += 2.0 * B * T * (Gk * Hk) * Hk * dk * 2 * extra
+    for key, ms, fl in (('gemm', g_ms, g_fl), ('sweeps', s_ms, s_fl)):
+        if ms > 0:
+            fam[key] = {'ms_per_step': round(ms, 4), 'gflop_per_step': round(fl / 1e9, 1), 'tflops': round(fl / (ms * 1e-3) / 1e12, 2),
+                        'frac_of_mfma_peak': round(fl / (ms * 1e-3) / 1e12 / peak, 4), 'share_of_step': round(ms / step_ms, 4),
+                        'kernels': {k: round(v[0] / steps, 4) for k, v in cats.items() if (k.startswith('gemm') if key == 'gemm' else 'sweep' in k)}}
+    fam['dominant'] = max((k for k in fam), key=lambda k: fam[k]['ms_per_step']) if fam else None
+    fam['peak_tflops'] = round(peak, 1)
+    return fam
+
+
 def time_other_workload(name, dev, L, steps=8, warmup=3):
     """BASELINE configs[2] / [3] in the same invocation: a few train steps after the headline region, so that
     the driver's own `bench.py --gpus 1` run times all three per-GPU workloads."""
@@ -187,7 +241,11 @@ def time_other_workload(name, dev, L, steps=8, warmup=3):
            'gru_forward_path': (None if (not fb or 'gru_fwd_sweep' not in d['cats']) else ('fallback (co-schedule-tolerant sweeps redid the forward)' if any(fb) else
                                                      'exclusive fused two-layer launch' if L.load().dep_rnn_get_exclusive() else 'tolerant sweeps (dep_rnn_set_exclusive(0))')),
            'kernels_ms_per_step': {k: round(v[0] / steps, 4) for k, v in d['cats'].items()},
+           'families': kernel_families(d['cats'], steps, name, B, T, H, split, ms),
+           'step_traffic': {'survey_8d_bytes_per_step': SURVEY_8D_BYTES_PER_STEP[name], 'pmc_bytes_per_step': pmc_step_bytes(name)},
            'workload': '%s.%s train step, B=%d T=%d F=%d H=%d' % (WORKLOADS[name][0], WORKLOADS[name][1], B, T, wl['F'], H)}
+    if res['step_traffic']['pmc_bytes_per_step']:
+        res['step_traffic']['wasted_traffic_ratio'] = round(res['step_traffic']['pmc_bytes_per_step'] / SURVEY_8D_BYTES_PER_STEP[name], 2)
     del wl, step, model
     torch.cuda.empty_cache()
     return res
@@ -534,7 +592,7 @@ def main():
                 'frac': round(frac_mfma if bound == 'mfma' else frac_hbm_alg, 4), 'traffic': traffic, 'traffic_note': traffic_note,
                 'limiter': 'serial hand-off latency of the recurrent steps (see serial_floor); sustained bf16 MFMA rate under the '
                            'package power cap is 1.6-1.7 PFLOP/s (profiles/r03_micro_mfma_rate.txt), the guide peak is kept as `peak`',
-                'step_traffic': {'pmc_bytes_per_step': step_traffic, 'survey_8d_bytes_per_step': 0.944e9 if args.workload == 'audio_gru' else None,
+                'step_traffic': {'pmc_bytes_per_step': step_traffic, 'survey_8d_bytes_per_step': SURVEY_8D_BYTES_PER_STEP[args.workload],
                                  'note': 'sum over all kernels of (2*FETCH_SIZE + WRITE_SIZE) per train step, rocprofv3 --pmc passes'},
                 'mfma_pipe': 'bf16 x3 split (peak = bf16 dense / 3)' if split else 'fp32',
                 'flops_per_launch': sweep_flops, 'avg_launch_ms': round(dom_ms, 4), 'launches_per_step': launches_per_step,
@@ -553,6 +611,9 @@ def main():
                            'fusion': (1.4156e9 + 2.831e9) / 3.0}[args.workload]
     step_tflops = train_flops_per_utt * value / 1e12 / world
     roofline['step_tflops_fp32_equiv'] = round(step_tflops, 2)
+    roofline['families'] = kernel_families(cats, args.steps, args.workload, B, T, H, split, step_ms)
+    if step_traffic:
+        roofline['step_traffic']['wasted_traffic_ratio'] = round(step_traffic / SURVEY_8D_BYTES_PER_STEP[args.workload], 2)
 
     out = {'metric': {'audio_gru': 'utterances/sec (train step) for GRU-256 on (B,T,F)=(512,300,256)',
                       'text_bilstm': 'utterances/sec (train step) for BiLSTM-128x2 on (B,T,F)=(512,300,1024)',
