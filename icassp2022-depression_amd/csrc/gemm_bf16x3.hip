@@ -50,19 +50,21 @@ struct GemmP {
 enum { FMT_F32 = 0, FMT_PK = 1, FMT_PKH = 2, FMT_BF16 = 3 };
 
 
-// Operand tile of ROWS (128 or 256) rows x 32 k, 256 threads: a = tid&7, bq = tid>>3.
+// Operand tile of ROWS (128 or 256) rows x 32 k, NTH threads (256; 512 in the 256 x 256-tile kernel): a = tid&7, bq = tid>>3, RPI = NTH / 8 rows
+// per pass (the comments below spell the 256-thread case, RPI = 32).
 //   !TR (K-contiguous rows): r[i]      = row (mn0 + bq + 32 i),            k  = k0 + a*4 + 0..3     i < ROWS/32
 //    TR (MN-contiguous)    : r[4jj + i] = k row (k0 + a*4 + i),           mn = mn0 + (bq + 32 jj)*4 + 0..3
-template <bool TR, bool VEC, int ROWS, int FMT = FMT_F32>
+template <bool TR, bool VEC, int ROWS, int FMT = FMT_F32, int NTH = 256>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int Kend,
-                                          int tid, float (&r)[ROWS / 32][4], int seqT, int shift, int skip_at = 0, int skip_by = 0) {
+                                          int tid, float (&r)[ROWS * 8 / NTH][4], int seqT, int shift, int skip_at = 0, int skip_by = 0) {
+    constexpr int RPI = NTH / 8;
     const int a = tid & 7, bq = tid >> 3;
     if (!TR) {
 #pragma unroll
-        for (int i = 0; i < ROWS / 32; ++i) {
+        for (int i = 0; i < ROWS / RPI; ++i) {
             // FMT_PK: slots 2j / 2j+1 are the hi-pair / lo-pair rows of logical rows (R, R+1), R = mn0 + 2 bq + 64 j  (FMT_PKH: the hi row only)
             if (FMT == FMT_PKH && (i & 1)) continue;
-            const int mn = (FMT == FMT_PK || FMT == FMT_PKH) ? mn0 + 2 * bq + 64 * (i >> 1) + (i & 1) : mn0 + bq + 32 * i, k = k0 + a * 4;
+            const int mn = (FMT == FMT_PK || FMT == FMT_PKH) ? mn0 + 2 * bq + 2 * RPI * (i >> 1) + (i & 1) : mn0 + bq + RPI * i, k = k0 + a * 4;
             const float* src = P + (size_t)mn * ld + k;
             if (VEC) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -75,11 +77,11 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
         }
     } else {
 #pragma unroll
-        for (int jj = 0; jj < ROWS / 128; ++jj)
+        for (int jj = 0; jj < ROWS / (4 * RPI); ++jj)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (FMT == FMT_PKH && (i & 1)) continue;      // the lo rows are not there
-                const int k = k0 + a * 4 + i, mn = mn0 + (bq + 32 * jj) * 4;
+                const int k = k0 + a * 4 + i, mn = mn0 + (bq + RPI * jj) * 4;
                 bool ok = k < Kend;
                 if (seqT > 0) { const int tt = k % seqT + shift; ok = ok && tt >= 0 && tt < seqT; }
                 // column skip: skip_at is a multiple of the tile's 4-column pieces, so a piece never straddles it
@@ -141,30 +143,31 @@ __device__ __forceinline__ void hi4(f32x4 x, bf16x4& hi) {
 }
 
 // LDS images Sh/Sl: [ROWS rows (m or n)][LDK] bf16, k contiguous
-template <bool TR, int ROWS, int TERMS = 3, int FMT = FMT_F32>
-__device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, const float (&r)[ROWS / 32][4]) {
+template <bool TR, int ROWS, int TERMS = 3, int FMT = FMT_F32, int NTH = 256>
+__device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, const float (&r)[ROWS * 8 / NTH][4]) {
+    constexpr int RPI = NTH / 8;
     const int a = tid & 7, bq = tid >> 3;
     if constexpr (FMT == FMT_BF16) {
         static_assert(TR && TERMS == 1, "FMT_BF16: MN-contiguous operand of the single-product kernel");
         // rows k0 + 4a + i (i < 4) of four columns, two bf16 per word: column e sits in half e & 1 of word e >> 1
 #pragma unroll
-        for (int jj = 0; jj < ROWS / 128; ++jj)
+        for (int jj = 0; jj < ROWS / (4 * RPI); ++jj)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
                 const unsigned w0 = __float_as_uint(r[jj * 4 + 0][e >> 1]), w1 = __float_as_uint(r[jj * 4 + 1][e >> 1]);
                 const unsigned w2 = __float_as_uint(r[jj * 4 + 2][e >> 1]), w3 = __float_as_uint(r[jj * 4 + 3][e >> 1]);
                 const u32x2v h = {__builtin_amdgcn_perm(w1, w0, sel), __builtin_amdgcn_perm(w3, w2, sel)};
-                *reinterpret_cast<u32x2v*>(Sh + ((bq + 32 * jj) * 4 + e) * LDK + a * 4) = h;
+                *reinterpret_cast<u32x2v*>(Sh + ((bq + RPI * jj) * 4 + e) * LDK + a * 4) = h;
             }
     } else if constexpr ((FMT == FMT_PK || FMT == FMT_PKH) && TR) {
         static_assert(FMT != FMT_PKH || TERMS == 1, "FMT_PKH carries no lo planes");
         // rows k0 + 4a + {0,1,2,3} of a thread = hi(k, k+1), lo(k, k+1), hi(k+2, k+3), lo(k+2, k+3) of its four columns: nothing to compute
 #pragma unroll
-        for (int jj = 0; jj < ROWS / 128; ++jj)
+        for (int jj = 0; jj < ROWS / (4 * RPI); ++jj)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int o = ((bq + 32 * jj) * 4 + e) * LDK + a * 4;
+                const int o = ((bq + RPI * jj) * 4 + e) * LDK + a * 4;
                 const u32x2v h = {__float_as_uint(r[jj * 4 + 0][e]), __float_as_uint(r[jj * 4 + 2][e])};
                 *reinterpret_cast<u32x2v*>(Sh + o) = h;
                 if constexpr (TERMS == 3) {
@@ -176,9 +179,9 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
         static_assert(FMT != FMT_PKH || TERMS == 1, "FMT_PKH carries no lo planes");
         // slots 2j / 2j+1 = hi-pair / lo-pair rows of logical rows (R, R+1): low halves belong to R, high halves to R+1
 #pragma unroll
-        for (int j = 0; j < ROWS / 64; ++j) {
+        for (int j = 0; j < ROWS / (2 * RPI); ++j) {
             const unsigned h0 = __float_as_uint(r[2 * j][0]), h1 = __float_as_uint(r[2 * j][1]), h2 = __float_as_uint(r[2 * j][2]), h3 = __float_as_uint(r[2 * j][3]);
-            const int o = (2 * bq + 64 * j) * LDK + a * 4;
+            const int o = (2 * bq + 2 * RPI * j) * LDK + a * 4;
             const u32x2v he = {__builtin_amdgcn_perm(h1, h0, 0x05040100u), __builtin_amdgcn_perm(h3, h2, 0x05040100u)};
             const u32x2v ho = {__builtin_amdgcn_perm(h1, h0, 0x07060302u), __builtin_amdgcn_perm(h3, h2, 0x07060302u)};
             *reinterpret_cast<u32x2v*>(Sh + o) = he; *reinterpret_cast<u32x2v*>(Sh + o + LDK) = ho;
@@ -191,20 +194,20 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
         }
     } else if (!TR) {
 #pragma unroll
-        for (int i = 0; i < ROWS / 32; ++i) {
+        for (int i = 0; i < ROWS / RPI; ++i) {
             f32x4 x = {r[i][0], r[i][1], r[i][2], r[i][3]};
-            const int o = (bq + 32 * i) * LDK + a * 4;
+            const int o = (bq + RPI * i) * LDK + a * 4;
             bf16x4 hi, lo;
             if constexpr (TERMS == 3) { split4(x, hi, lo); *reinterpret_cast<bf16x4*>(Sl + o) = lo; } else hi4(x, hi);
             *reinterpret_cast<bf16x4*>(Sh + o) = hi;
         }
     } else {
 #pragma unroll
-        for (int jj = 0; jj < ROWS / 128; ++jj)
+        for (int jj = 0; jj < ROWS / (4 * RPI); ++jj)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 f32x4 x = {r[jj * 4 + 0][e], r[jj * 4 + 1][e], r[jj * 4 + 2][e], r[jj * 4 + 3][e]};
-                const int o = ((bq + 32 * jj) * 4 + e) * LDK + a * 4;
+                const int o = ((bq + RPI * jj) * 4 + e) * LDK + a * 4;
                 bf16x4 hi, lo;
                 if constexpr (TERMS == 3) { split4(x, hi, lo); *reinterpret_cast<bf16x4*>(Sl + o) = lo; } else hi4(x, hi);
                 *reinterpret_cast<bf16x4*>(Sh + o) = hi;
@@ -376,6 +379,166 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3_tn_pair(
     else gemm_bf16x3_walk<true, false, VEC, BMT, 3, FA, FB>(p0, bid, nblk);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the 256 x 256-tile form.  Measured first (profiles/r06_gemm_clock_ablation.txt): every form runs with the
+// shader clock held at 1.6-2.1 GHz by the power manager; the matrix part (MFMAs + fragment reads) alone is power-bound at 0.9-1.5 PF of
+// products; the OPERAND PATH (L2 -> CU loads, conversion, LDS staging) is not power-bound and takes as long as the matrix part or longer
+// (cfg3's N = 1024 contractions: 0.82 ms against 0.66).  A schedule cannot beat max(operand path, matrix part); fewer operand bytes and
+// conversions per flop can.  So: ONE workgroup of eight waves per CU on a 256 x 256 tile (2 x 4 waves, each the same 128 x 64 = 4 x 2 MFMA
+// tiles as above) -- per flop a third fewer operand bytes through L2 -> registers -> LDS than 256 x 128 and half the conversions of the
+// operand that used to be re-staged per 128-column tile; the two LDS stages alternate (2 x 80 KB = the whole LDS), ONE barrier per k-tile:
+// convert + stage k-tile i+1 from registers, request k-tile i+2, multiply k-tile i.  Same k order, same three products per 16 k, same
+// split-K chunks: every result BIT-IDENTICAL to the 256 x 128 kernel (tests/golden/device_bits.json).
+constexpr int BIG = 256, BIG_NT = 512;
+constexpr int BIG_PLANE = BIG * LDK;                          // bf16 elements of one operand plane of a stage
+constexpr int BIG_STAGE = 4 * BIG_PLANE;                      // Ah, Al, Bh, Bl
+constexpr size_t BIG_LDS_BYTES = (size_t)2 * BIG_STAGE * sizeof(__bf16);      // 163,840 B
+
+struct BigPos {                                               // a position in the (tile, k-tile) iteration space of one workgroup
+    int tile, m0, n0, kbeg, kend, bz, k0; bool valid;
+};
+
+template <bool TA, bool TB, int FA, int FB>
+__device__ __forceinline__ void gemm_big_walk(const GemmP& p, const int block_id, const int block_count, __bf16* smem) {
+    constexpr bool A_TR = TA, B_TR = !TB;
+    constexpr int MI = 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int ntiles = p.gx * p.gy * p.splits;
+    const int x8 = block_id & 7, slot = block_id >> 3, slots = block_count >> 3;
+    const int q = ntiles / 8, r8 = ntiles % 8;
+    const int lo = x8 < r8 ? x8 * (q + 1) : r8 * (q + 1) + (x8 - r8) * q;
+    const int hi = lo + (x8 < r8 ? q + 1 : q);
+    if (lo + slot >= hi) return;
+
+    auto place = [&](BigPos& s, int t) {
+        s.tile = t; s.valid = t < hi;
+        if (!s.valid) return;
+        const int bx = t % p.gx, by = (t / p.gx) % p.gy; s.bz = t / (p.gx * p.gy);
+        s.m0 = by * BIG; s.n0 = bx * BIG; s.kbeg = s.bz * p.kchunk; s.kend = min(p.K, s.kbeg + p.kchunk); s.k0 = s.kbeg;
+    };
+    auto advance = [&](BigPos& s) {
+        if (!s.valid) return;
+        s.k0 += BK;
+        if (s.k0 >= s.kend) place(s, s.tile + slots);
+    };
+    float ra[4][4], rb[4][4];
+    auto fetch = [&](const BigPos& s) {
+        load_tile<A_TR, true, BIG, FA, BIG_NT>(p.A, p.lda, s.m0, p.M, s.k0, s.kend, tid, ra, 0, 0, p.skip_at, p.skip_by);
+        load_tile<B_TR, true, BIG, FB, BIG_NT>(p.B, p.ldb, s.n0, p.N, s.k0, s.kend, tid, rb, p.seqT, p.shiftB);
+    };
+    auto stage_out = [&](int st) {
+        __bf16* base = smem + st * BIG_STAGE;
+        store_tile<A_TR, BIG, 3, FA, BIG_NT>(base, base + BIG_PLANE, tid, ra);
+        store_tile<B_TR, BIG, 3, FB, BIG_NT>(base + 2 * BIG_PLANE, base + 3 * BIG_PLANE, tid, rb);
+    };
+
+    BigPos cur, nxt;
+    place(cur, lo + slot);
+    fetch(cur);
+    stage_out(0);
+    nxt = cur; advance(nxt);
+    if (nxt.valid) fetch(nxt);
+    __syncthreads();
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int it = 0; cur.valid; ++it) {
+        // k-tile it+1: registers -> the other stage (its readers left it at the last barrier); then the request for k-tile it+2
+        if (nxt.valid && !(p.ablate & 8)) stage_out((it + 1) & 1);
+        BigPos nn = nxt; advance(nn);
+        if (nn.valid && !(p.ablate & 4)) fetch(nn);
+        const __bf16* Ah = smem + (it & 1) * BIG_STAGE; const __bf16* Al = Ah + BIG_PLANE;
+        const __bf16* Bh = Ah + 2 * BIG_PLANE; const __bf16* Bl = Bh + BIG_PLANE;
+        if (!(p.ablate & 2))
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 16; ++s2) {
+            const int ko = s2 * 16 + half * 8;
+            bf16x8 ah[MI], al[MI], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int ro = (wm * 128 + i * 32 + l31) * LDK + ko;
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro); al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ro = (wn * 64 + j * 32 + l31) * LDK + ko;
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro); bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (cur.k0 + BK >= cur.kend) {                        // the tile's last k-tile: write it out (its stores drain under the next tile's loads)
+            const bool split = p.part != nullptr;
+            float* outp = split ? p.part + (size_t)cur.bz * p.M * p.N : p.C;
+            const int ldo = split ? p.N : p.ldc;
+            const bool v4 = ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0);
+            const bool addb = !split && p.bias;
+            const bool rmw = !split && p.beta != 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = cur.m0 + wm * 128 + i * 32 + l31;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = cur.n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        acc[i][j][4 * g] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+                        if (m >= p.M || n >= p.N) continue;
+                        float* dst = outp + (size_t)m * ldo + n;
+                        if (v4 && n + 3 < p.N) {
+                            if (addb) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                            if (rmw) v += p.beta * *reinterpret_cast<const f32x4*>(dst);
+                            if (!(p.ablate & 1) || v[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(dst) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < p.N) {
+                                    float x = v[e] + (addb ? p.bias[n + e] : 0.f);
+                                    if (rmw) x += p.beta * dst[e];
+                                    dst[e] = x;
+                                }
+                        }
+                    }
+            }
+        }
+        cur = nxt; nxt = nn;
+        __syncthreads();
+    }
+}
+
+template <bool TA, bool TB, int FA, int FB>
+__global__ __launch_bounds__(BIG_NT, 1) void gemm_bf16x3_big(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 big_smem[];
+    if (p.only_if && *p.only_if == 0) return;
+    gemm_big_walk<TA, TB, FA, FB>(p, blockIdx.x, gridDim.x, big_smem);
+}
+
+// the paired weight-gradient launch (gemm_bf16x3_tn_pair above) on 256 x 256 tiles: slots 2i / 2i+1 of an XCD walk tile list i of problem 0 / 1
+template <int FA, int FB>
+__global__ __launch_bounds__(BIG_NT, 1) void gemm_bf16x3_big_tn_pair(GemmP p0, GemmP p1) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 big_smem[];
+    const int x8 = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bid = ((slot >> 1) << 3) | x8, nblk = gridDim.x >> 1;
+    if (slot & 1) gemm_big_walk<true, false, FA, FB>(p1, bid, nblk, big_smem);
+    else gemm_big_walk<true, false, FA, FB>(p0, bid, nblk, big_smem);
+}
+
 // both problems' split-K partials in one launch (blockIdx.y = problem)
 __global__ void splitk_reduce2_pair(const float* __restrict__ part0, const float* __restrict__ part1, int splits, int M, int N,
                                     float* C0, int ldc0, float* C1, int ldc1) {
@@ -400,346 +563,6 @@ __global__ void splitk_reduce2_pair(const float* __restrict__ part0, const float
     for (; z < splits; ++z) s0 += part[(size_t)z * MN + idx];
     const float s = (s0 + s1) + (s2 + s3);
     if (blockIdx.y) C1[(size_t)m * ldc1 + n] = s; else C0[(size_t)m * ldc0 + n] = s;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Wave-specialised variant (round 3).  What held the kernel above at 5.5-6.3 TB/s of L2 -> CU traffic was not the feed
-// (tools/micro/l2bw.hip: 30 TB/s of L2 hits, 6.3-7.0 TB/s from HBM with the same 16-byte loads) but its prefetch distance:
-// a k-tile's loads are issued one MFMA phase (~1 us) before the conversion that needs them, while a loaded HBM round trip is
-// 1.5-3 us -- every iteration stalled on them (3.9 us per 256x128x32 step for 0.77 us of MFMAs).
-//
-// One workgroup of EIGHT waves per CU, tile 256 x 128 x 32:
-//   * waves 4-7, the PRODUCERS: global loads D k-tiles ahead into D register sets (16-byte loads, 48 KB per set and
-//     workgroup -> up to D x 48 KB in flight per CU), fp32 -> (hi, lo) bf16 split, ds_write into the LDS stage the consumers
-//     will read NEXT step;
-//   * waves 0-3, the CONSUMERS: ds_read_b128 fragments + 48 v_mfma_f32_32x32x16_bf16 per step and wave (a 128 x 64 sub-tile, 128
-//     accumulator registers), epilogue stores at a tile's end.
-//   One LDS-only barrier per step (raw s_barrier: __syncthreads() would drain vmcnt, i.e. the producers' prefetches); the
-//   two LDS stages alternate.  Each SIMD carries one consumer and one producer wave, so the conversions' VALU work and the
-//   loads' address arithmetic fill issue slots beside the other wave's MFMAs instead of in front of them.
-constexpr int WS_BM = 256, WS_NT = 512;
-constexpr int WS_PLANE_A = WS_BM * LDK, WS_PLANE_B = BN * LDK;
-constexpr int WS_STAGE = 2 * (WS_PLANE_A + WS_PLANE_B);               // bf16 elements per stage: Ah, Al, Bh, Bl
-constexpr size_t WS_LDS_BYTES = (size_t)2 * WS_STAGE * sizeof(__bf16);    // 122,880 B
-
-__device__ __forceinline__ void ws_bar() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
-struct WsWalk {
-    int tile, hi, slots, gx, gy, kchunk, K, seqT;
-    int m0, n0, kbeg, kend, bz, k0, t0;      // t0 = k0 % seqT (position inside the sequence, for the row-shifted operand)
-    bool valid;
-    __device__ __forceinline__ void coords() {
-        const int bx = tile % gx, by = (tile / gx) % gy; bz = tile / (gx * gy);
-        m0 = by * WS_BM; n0 = bx * BN; kbeg = bz * kchunk; kend = min(K, kbeg + kchunk); k0 = kbeg;
-        t0 = seqT > 0 ? kbeg % seqT : 0;
-    }
-    __device__ __forceinline__ void init(const GemmP& p, int first, int hi_, int slots_) {
-        tile = first; hi = hi_; slots = slots_; gx = p.gx; gy = p.gy; kchunk = p.kchunk; K = p.K; seqT = p.seqT;
-        valid = tile < hi;
-        if (valid) coords(); else { m0 = n0 = kbeg = kend = bz = k0 = t0 = 0; }
-    }
-    __device__ __forceinline__ bool last_k() const { return k0 + BK >= kend; }
-    __device__ __forceinline__ void advance() {
-        k0 += BK;
-        if (seqT > 0) { t0 += BK; while (t0 >= seqT) t0 -= seqT; }
-        if (k0 >= kend) { tile += slots; valid = tile < hi; if (valid) coords(); }
-    }
-};
-
-// Producer-side tile movers.  The loads are UNCONDITIONAL (addresses clamped into the operand, nothing predicated): a
-// predicated load compiles to a branch plus a copy of the loaded value into the rotating register set, i.e. an
-// s_waitcnt vmcnt(0) behind every single load (seen in the first version of this kernel).  Elements outside the tile's
-// valid range are zeroed when the set is converted, from the coordinates remembered with the set.
-struct WsTag { int mn0a, mn0b, k0, kend; bool fast; };
-
-template <bool TR, bool VEC, int ROWS>
-__device__ __forceinline__ void ws_load(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int Ktot, int tid,
-                                        float (&r)[ROWS / 32][4], int shift) {
-    const int a = tid & 7, bq = tid >> 3;
-    if (!TR) {
-#pragma unroll
-        for (int i = 0; i < ROWS / 32; ++i) {
-            const int mn = min(mn0 + bq + 32 * i, MN - 1);
-            if (VEC) {
-                const int k = min(k0 + a * 4, Ktot - 4);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)mn * ld + k);
-                r[i][0] = v[0]; r[i][1] = v[1]; r[i][2] = v[2]; r[i][3] = v[3];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) r[i][e] = P[(size_t)mn * ld + min(k0 + a * 4 + e, Ktot - 1)];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int jj = 0; jj < ROWS / 128; ++jj)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = min(max(k0 + a * 4 + i + shift, 0), Ktot - 1);
-                float (&rr)[4] = r[jj * 4 + i];
-                if (VEC) {
-                    const int mn = min(mn0 + (bq + 32 * jj) * 4, MN - 4);
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + mn);
-                    rr[0] = v[0]; rr[1] = v[1]; rr[2] = v[2]; rr[3] = v[3];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rr[e] = P[(size_t)k * ld + min(mn0 + (bq + 32 * jj) * 4 + e, MN - 1)];
-                }
-            }
-    }
-}
-
-// zero what lies outside [mn0, MN) x [k0, kend) (and, for the row-shifted operand, outside its sequence), then split + store
-template <bool TR, int ROWS>
-__device__ __forceinline__ void ws_store(__bf16* Sh, __bf16* Sl, int tid, float (&r)[ROWS / 32][4], int mn0, int MN, int k0,
-                                         int kend, int seqT, int shift) {
-    const int a = tid & 7, bq = tid >> 3;
-    if (!TR) {
-#pragma unroll
-        for (int i = 0; i < ROWS / 32; ++i) {
-            const bool okr = mn0 + bq + 32 * i < MN;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (!(okr && k0 + a * 4 + e < kend)) r[i][e] = 0.f;
-        }
-    } else {
-#pragma unroll
-        for (int jj = 0; jj < ROWS / 128; ++jj)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = k0 + a * 4 + i;
-                bool ok = k < kend;
-                if (seqT > 0) { const int tt = k % seqT + shift; ok = ok && tt >= 0 && tt < seqT; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (!(ok && mn0 + (bq + 32 * jj) * 4 + e < MN)) r[jj * 4 + i][e] = 0.f;
-            }
-    }
-    store_tile<TR, ROWS>(Sh, Sl, tid, r);
-}
-
-template <bool TA, bool TB, bool VEC, int D>
-__global__ __launch_bounds__(WS_NT, 1) void gemm_bf16x3_ws(GemmP p) {
-    if (p.only_if && *p.only_if == 0) return;
-    constexpr bool A_TR = TA, B_TR = !TB;
-    extern __shared__ __attribute__((aligned(16))) __bf16 ws_smem[];
-
-    const int ntiles = p.gx * p.gy * p.splits;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    const int q = ntiles / 8, r = ntiles % 8;
-    const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int hi = lo + (xcd < r ? q + 1 : q);
-    if (lo + slot >= hi) return;
-    // number of (tile, k-tile) steps of this workgroup: identical in both roles (they meet at one barrier per step);
-    // rounded up to a multiple of D so that the producers' loop over the rotating register sets has no partial round
-    int G = 0;
-    for (int t = lo + slot; t < hi; t += slots) {
-        const int bz = t / (p.gx * p.gy), kb = bz * p.kchunk, ke = min(p.K, kb + p.kchunk);
-        G += (ke - kb + BK - 1) / BK;
-    }
-    const int Gr = (G + D - 1) / D * D;
-
-    if (threadIdx.x >= 256) {
-        // ------------------------------------------------------------------ producers
-        const int tid = threadIdx.x - 256;
-        WsWalk wl; wl.init(p, lo + slot, hi, slots);
-        float ra[D][WS_BM / 32][4], rb[D][BN / 32][4];
-        WsTag tag[D];
-        // per-thread byte offsets inside an operand tile: loop invariants, so an interior step's loads are
-        // global_load_dwordx4 v, v_off, s[base] with a scalar base that moves per step -- no VALU per load
-        const int la = tid & 7, lbq = tid >> 3;
-        unsigned offA[WS_BM / 32], offB[BN / 32];
-#pragma unroll
-        for (int i = 0; i < WS_BM / 32; ++i)
-            offA[i] = A_TR ? (unsigned)(((la * 4 + (i & 3)) * p.lda + (lbq + 32 * (i >> 2)) * 4) * 4)
-                           : (unsigned)(((lbq + 32 * i) * p.lda + la * 4) * 4);
-#pragma unroll
-        for (int i = 0; i < BN / 32; ++i)
-            offB[i] = B_TR ? (unsigned)(((la * 4 + (i & 3)) * p.ldb + (lbq + 32 * (i >> 2)) * 4) * 4)
-                           : (unsigned)(((lbq + 32 * i) * p.ldb + la * 4) * 4);
-        typedef const char __attribute__((address_space(1)))* gcp;          // global address space: global_load, not flat_load
-        typedef const f32x4 __attribute__((address_space(1)))* gv4p;
-        auto sgpr_ptr = [](const char* q) {          // pin a uniform pointer into SGPRs: the loads below then take the saddr form
-            const unsigned long long u = reinterpret_cast<unsigned long long>(q);
-            const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)u), h = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-            return (gcp)(((unsigned long long)h << 32) | l);
-        };
-        auto issue = [&](auto SET) {
-            constexpr int S = decltype(SET)::value;
-            // interior step: whole tile inside the operands, a full k-tile, no sequence boundary of the row-shifted operand
-            bool fast = VEC && wl.valid && wl.m0 + WS_BM <= p.M && wl.n0 + BN <= p.N && wl.k0 + BK <= wl.kend;
-            if (p.seqT > 0) fast = fast && wl.t0 + min(p.shiftB, 0) >= 0 && wl.t0 + BK - 1 + max(p.shiftB, 0) < p.seqT;
-            // past the last step the walker stays on its last coordinates: the loads stay valid, nobody consumes them
-            tag[S] = WsTag{wl.m0, wl.n0, wl.k0, wl.valid ? wl.kend : 0, fast};
-            if constexpr (VEC) {
-                // ONE load stream for both kinds of step (scalar base + 32-bit lane offset); only the offsets differ.  Two
-                // separate streams would meet in copies of the loaded registers, i.e. in waits for the loads just issued.
-                const char* ba; const char* bb;
-                unsigned va[WS_BM / 32], vb[BN / 32];
-                if (fast) {
-                    ba = reinterpret_cast<const char*>(p.A) + (A_TR ? ((size_t)wl.k0 * p.lda + wl.m0) : ((size_t)wl.m0 * p.lda + wl.k0)) * 4;
-                    bb = reinterpret_cast<const char*>(p.B) + (B_TR ? ((size_t)(wl.k0 + p.shiftB) * p.ldb + wl.n0) : ((size_t)wl.n0 * p.ldb + wl.k0)) * 4;
-#pragma unroll
-                    for (int i = 0; i < WS_BM / 32; ++i) va[i] = offA[i];
-#pragma unroll
-                    for (int i = 0; i < BN / 32; ++i) vb[i] = offB[i];
-                } else {
-                    ba = reinterpret_cast<const char*>(p.A); bb = reinterpret_cast<const char*>(p.B);
-#pragma unroll
-                    for (int i = 0; i < WS_BM / 32; ++i) {
-                        if (A_TR) {
-                            const int k = min(max(wl.k0 + la * 4 + (i & 3), 0), p.K - 1), mn = min(wl.m0 + (lbq + 32 * (i >> 2)) * 4, p.M - 4);
-                            va[i] = (unsigned)(k * p.lda + mn) * 4u;
-                        } else {
-                            const int mn = min(wl.m0 + lbq + 32 * i, p.M - 1), k = min(wl.k0 + la * 4, p.K - 4);
-                            va[i] = (unsigned)(mn * p.lda + k) * 4u;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < BN / 32; ++i) {
-                        if (B_TR) {
-                            const int k = min(max(wl.k0 + la * 4 + (i & 3) + p.shiftB, 0), p.K - 1), mn = min(wl.n0 + (lbq + 32 * (i >> 2)) * 4, p.N - 4);
-                            vb[i] = (unsigned)(k * p.ldb + mn) * 4u;
-                        } else {
-                            const int mn = min(wl.n0 + lbq + 32 * i, p.N - 1), k = min(wl.k0 + la * 4, p.K - 4);
-                            vb[i] = (unsigned)(mn * p.ldb + k) * 4u;
-                        }
-                    }
-                }
-                const gcp ga = sgpr_ptr(ba), gb = sgpr_ptr(bb);
-#pragma unroll
-                for (int i = 0; i < WS_BM / 32; ++i) {
-                    const f32x4 v = *(gv4p)(ga + va[i]);
-                    ra[S][i][0] = v[0]; ra[S][i][1] = v[1]; ra[S][i][2] = v[2]; ra[S][i][3] = v[3];
-                }
-#pragma unroll
-                for (int i = 0; i < BN / 32; ++i) {
-                    const f32x4 v = *(gv4p)(gb + vb[i]);
-                    rb[S][i][0] = v[0]; rb[S][i][1] = v[1]; rb[S][i][2] = v[2]; rb[S][i][3] = v[3];
-                }
-            } else {
-                ws_load<A_TR, false, WS_BM>(p.A, p.lda, wl.m0, p.M, wl.k0, p.K, tid, ra[S], 0);
-                ws_load<B_TR, false, BN>(p.B, p.ldb, wl.n0, p.N, wl.k0, p.K, tid, rb[S], p.shiftB);
-            }
-            if (wl.valid) wl.advance();
-        };
-        auto stage_out = [&](auto SET, int stage) {
-            constexpr int S = decltype(SET)::value;
-            __bf16* base = ws_smem + stage * WS_STAGE;
-            if (tag[S].fast) {
-                store_tile<A_TR, WS_BM>(base, base + WS_PLANE_A, tid, ra[S]);
-                store_tile<B_TR, BN>(base + 2 * WS_PLANE_A, base + 2 * WS_PLANE_A + WS_PLANE_B, tid, rb[S]);
-            } else {
-                ws_store<A_TR, WS_BM>(base, base + WS_PLANE_A, tid, ra[S], tag[S].mn0a, p.M, tag[S].k0, tag[S].kend, 0, 0);
-                ws_store<B_TR, BN>(base + 2 * WS_PLANE_A, base + 2 * WS_PLANE_A + WS_PLANE_B, tid, rb[S], tag[S].mn0b, p.N,
-                                   tag[S].k0, tag[S].kend, p.seqT, p.shiftB);
-            }
-        };
-#define WS_ISSUE(S) issue(std::integral_constant<int, S>{})
-        WS_ISSUE(0);
-        if constexpr (D > 1) WS_ISSUE(1);
-        if constexpr (D > 2) WS_ISSUE(2);
-        if constexpr (D > 3) WS_ISSUE(3);                        // steps 0 .. D-1 in flight
-        stage_out(std::integral_constant<int, 0>{}, 0);          // step 0 -> stage 0
-        WS_ISSUE(0);                                             // step D
-        ws_bar();
-        // step g: the consumers multiply stage g & 1; convert step g+1 (register set (g+1) % D) into the other stage and
-        // refill that set with step g+1+D.  (The last step converts a set nobody reads: cheaper than a conditional that
-        // would make hipcc drain the load queue at the loop head.)
-#define WS_STEP(S, GG) { if (!(p.ablate & 8)) stage_out(std::integral_constant<int, S>{}, ((GG) + 1) & 1); if (!(p.ablate & 4)) WS_ISSUE(S); ws_bar(); }
-        for (int g = 0; g < Gr; g += D) {
-            if constexpr (D == 1) { WS_STEP(0, g) }
-            if constexpr (D == 2) { WS_STEP(1, g) WS_STEP(0, g + 1) }
-            if constexpr (D == 3) { WS_STEP(1, g) WS_STEP(2, g + 1) WS_STEP(0, g + 2) }
-            if constexpr (D == 4) { WS_STEP(1, g) WS_STEP(2, g + 1) WS_STEP(3, g + 2) WS_STEP(0, g + 3) }
-        }
-#undef WS_STEP
-#undef WS_ISSUE
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumers
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-    constexpr int MI = WS_BM / 64;
-    WsWalk wc; wc.init(p, lo + slot, hi, slots);
-    f32x16 acc[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    ws_bar();                                                    // stage 0 is ready
-    for (int g = 0; g < Gr; ++g) {
-        if (g >= G) { ws_bar(); continue; }                      // padding steps of the producers' last round
-        const __bf16* Ah = ws_smem + (g & 1) * WS_STAGE; const __bf16* Al = Ah + WS_PLANE_A;
-        const __bf16* Bh = Ah + 2 * WS_PLANE_A; const __bf16* Bl = Bh + WS_PLANE_B;
-        if (!(p.ablate & 2))
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            const int ko = s * 16 + half * 8;
-            bf16x8 ah[MI], al[MI], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int ro = (wm * (WS_BM / 2) + i * 32 + l31) * LDK + ko;
-                ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro); al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ro = (wn * 64 + j * 32 + l31) * LDK + ko;
-                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro); bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-                }
-        }
-        const bool fin = wc.last_k();
-        const int m0 = wc.m0, n0 = wc.n0, bz = wc.bz;
-        wc.advance();
-        ws_bar();                                                // the producers go on with the next stage while a finished tile is stored
-        if (fin) {
-            const bool split = p.part != nullptr;
-            float* outp = split ? p.part + (size_t)bz * p.M * p.N : p.C;
-            const int ldo = split ? p.N : p.ldc;
-            const bool v4 = ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0);
-            const bool addb = !split && p.bias;
-            const bool rmw = !split && p.beta != 0.f;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = m0 + wm * (WS_BM / 2) + i * 32 + l31;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int n = n0 + wn * 64 + j * 32 + 8 * gq + 4 * half;
-                        f32x4 v = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
-                        acc[i][j][4 * gq] = 0.f; acc[i][j][4 * gq + 1] = 0.f; acc[i][j][4 * gq + 2] = 0.f; acc[i][j][4 * gq + 3] = 0.f;
-                        if (m >= p.M || n >= p.N) continue;
-                        float* dst = outp + (size_t)m * ldo + n;
-                        if (v4 && n + 3 < p.N) {
-                            if (addb) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                            if (rmw) v += p.beta * *reinterpret_cast<const f32x4*>(dst);
-                            *reinterpret_cast<f32x4*>(dst) = v;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < p.N) {
-                                    float x = v[e] + (addb ? p.bias[n + e] : 0.f);
-                                    if (rmw) x += p.beta * dst[e];
-                                    dst[e] = x;
-                                }
-                        }
-                    }
-            }
-        }
-    }
 }
 
 __global__ void splitk_reduce2(const unsigned* only_if, const float* __restrict__ part, int splits, int M, int N, float* C, int ldc,
@@ -782,13 +605,28 @@ void dep_gemm_set_operand_formats(int fmt_a, int fmt_b) { g_fmt_a = fmt_a; g_fmt
 bool dep_gemm_pk_pending() { return g_fmt_a != FMT_F32 || g_fmt_b != FMT_F32; }
 extern "C" int dep_gemm_set_xcds(int lo, int n) { if (lo < 0 || n < 1 || lo + n > 8) return DEP_ERR_ARG; g_xcd_lo = lo; g_xcd_n = n; return DEP_OK; }
 
+static bool big_on() { static int on = -1; if (on < 0) { const char* e = getenv("DEP_GEMM_BIG"); on = (e && e[0] == '0') ? 0 : 1; } return on != 0; }
+static int big_cus() {      // workgroups of the one-per-CU launch: the device's CUs, a multiple of 8
+    static int cus = -1;
+    if (cus < 0) { hipDeviceProp_t pr; int dv = 0; cus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; cus = cus / 8 * 8; if (cus < 8) cus = 8; }
+    return cus;
+}
+static void big_attrs() {
+    static bool done = false;
+    if (done) return;
+#define BIG_A(...) (void)hipFuncSetAttribute((const void*)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIG_LDS_BYTES)
+    BIG_A(gemm_bf16x3_big<false, true, FMT_F32, FMT_F32>); BIG_A(gemm_bf16x3_big<false, false, FMT_F32, FMT_F32>); BIG_A(gemm_bf16x3_big<true, false, FMT_F32, FMT_F32>);
+    BIG_A(gemm_bf16x3_big<true, false, FMT_PK, FMT_PK>); BIG_A(gemm_bf16x3_big<true, false, FMT_PK, FMT_F32>); BIG_A(gemm_bf16x3_big<false, false, FMT_PK, FMT_F32>);
+    BIG_A(gemm_bf16x3_big_tn_pair<FMT_PK, FMT_F32>);
+#undef BIG_A
+    done = true;
+}
+
 // Same contract as dep_gemm_internal (gemm.hip); `splits` is decided by the caller's shared heuristic.
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
                            int splits, int kchunk, float* part, bool vec, hipStream_t s, int terms) {
-    static int abl = -1, persist = -1, bm256 = -1, wsd = -2;
-    if (abl < 0) { const char* e = getenv("DEP_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
-    if (wsd == -2) { const char* e = getenv("DEP_GEMM_WS"); wsd = e ? atoi(e) : 0; if (wsd < 0 || wsd > 4) wsd = 0; }
+    static int abl = -1, persist = -1, bm256 = -1;
     // (32-bit lane offsets: every operand must span less than 4 GB)
     const size_t spanA = (size_t)(transA ? K : M) * lda * 4, spanB = (size_t)(transB ? N : K) * ldb * 4;
     const int fa = g_fmt_a, fb = g_fmt_b;
@@ -803,28 +641,30 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
         }
         DEP_CHECK_ARG(transA ? (K % 2 == 0 && kchunk % 2 == 0) : (M % 2 == 0));
     }
-    if (wsd > 0 && fa == FMT_F32 && fb == FMT_F32 && terms == 3 && M >= 256 && !(transA && g_skip_by) && spanA < (1ull << 32) && spanB < (1ull << 32)) {
-        // wave-specialised kernel: one 8-wave workgroup per CU, 256 x 128 tiles, `wsd` register sets of prefetch
-        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, WS_BM), abl, dep_gemm_predicate(), 0, 8, 0, 0};
-        const int ntiles = p.gx * p.gy * splits;
-        int ncu = 256;
-        { static int cus = -1; if (cus < 0) { hipDeviceProp_t pr; int dv = 0; cus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; } ncu = cus / 8 * 8; if (ncu < 8) ncu = 8; }
-        dim3 g(ntiles < ncu ? (ntiles + 7) / 8 * 8 : ncu);
-        static bool attr = false;
-#define WS_ATTR1(TA, TB, V, DD) (void)hipFuncSetAttribute((const void*)gemm_bf16x3_ws<TA, TB, V, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES)
-#define WS_ATTR(DD) WS_ATTR1(false, true, true, DD); WS_ATTR1(false, true, false, DD); WS_ATTR1(false, false, true, DD); \
-                    WS_ATTR1(false, false, false, DD); WS_ATTR1(true, false, true, DD); WS_ATTR1(true, false, false, DD)
-        if (!attr) { WS_ATTR(2); WS_ATTR(3); WS_ATTR(4); attr = true; }
-#undef WS_ATTR
-#undef WS_ATTR1
-#define WS_L1(TA, TB, DD) do { if (vec) DEP_LAUNCH((gemm_bf16x3_ws<TA, TB, true, DD>), g, dim3(WS_NT), WS_LDS_BYTES, s, p); \
-                               else     DEP_LAUNCH((gemm_bf16x3_ws<TA, TB, false, DD>), g, dim3(WS_NT), WS_LDS_BYTES, s, p); } while (0)
-#define WS_L(TA, TB) do { if (wsd == 2) WS_L1(TA, TB, 2); else if (wsd == 4) WS_L1(TA, TB, 4); else WS_L1(TA, TB, 3); } while (0)
-        if (!transA && transB) WS_L(false, true);
-        else if (!transA && !transB) WS_L(false, false);
-        else WS_L(true, false);
-#undef WS_L
-#undef WS_L1
+    if (abl < 0) {      // measurement hook (profiles/r06_gemm_clock_ablation.txt): the results are garbage, and the process says so once
+        const char* e = getenv("DEP_GEMM_ABLATE"); abl = e ? atoi(e) : 0;
+        if (abl) fprintf(stderr, "libdep_rnn: DEP_GEMM_ABLATE=%d -- parts of the split-precision GEMM are compiled out of the loop, RESULTS ARE GARBAGE (timing only)\n", abl);
+    }
+    if (persist < 0) { const char* e = getenv("DEP_GEMM_PERSIST"); persist = e ? atoi(e) : 768; if (persist < 8) persist = 8; persist = persist / 8 * 8; }
+    if (bm256 < 0) { const char* e = getenv("DEP_GEMM_BM"); bm256 = (e && atoi(e) == 128) ? 0 : 1; }
+    // measured at cfg2: 256-row tiles win 8-10 % on the NN (dX) and TN (dW) forms, lose 6 % on the short-K NT projection
+    // (round 4: long-K projections -- cfg3's F = 1024 layer -- take the 256-row tile too; DEP_GEMM_NT256=0 restores 128 rows for every NT call)
+    static int nt256 = -1;
+    if (nt256 < 0) { const char* e = getenv("DEP_GEMM_NT256"); nt256 = (e && e[0] == '0') ? 0 : 1; }
+    // round 6: 256 x 256 tiles, one eight-wave workgroup per CU (gemm_bf16x3_big above) where the output is at least two of the old tiles wide:
+    // the split-precision forms of the RNN stacks (NT projections, NN dX, TN weight gradients).  DEP_GEMM_BIG=0: the 256 x 128 kernel (A/B; bit-identical).
+    if (big_on() && vec && terms == 3 && M >= 512 && N % BIG == 0 && g_xcd_lo == 0 && g_xcd_n == 8 && spanA < (1ull << 32) && spanB < (1ull << 32) &&
+        ((fa == FMT_F32 && fb == FMT_F32) || (fa == FMT_PK && fb == FMT_F32 && (transA || !transB)) || (fa == FMT_PK && fb == FMT_PK && transA && !transB))) {
+        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, N / BIG, dep_cdiv(M, BIG), abl, dep_gemm_predicate(), 0, 8, transA ? g_skip_at : 0, transA ? g_skip_by : 0};
+        const int ntiles = p.gx * p.gy * splits, per_xcd = (ntiles + 7) / 8, cap = big_cus() / 8;
+        const dim3 g((per_xcd < cap ? per_xcd : cap) * 8);
+        big_attrs();
+#define BIG_L(TA, TB, FA_, FB_) DEP_LAUNCH((gemm_bf16x3_big<TA, TB, FA_, FB_>), g, dim3(BIG_NT), BIG_LDS_BYTES, s, p)
+        if (fa == FMT_F32) { if (!transA && transB) BIG_L(false, true, FMT_F32, FMT_F32); else if (!transA) BIG_L(false, false, FMT_F32, FMT_F32); else BIG_L(true, false, FMT_F32, FMT_F32); }
+        else if (fb == FMT_PK) BIG_L(true, false, FMT_PK, FMT_PK);
+        else if (transA) BIG_L(true, false, FMT_PK, FMT_F32);
+        else BIG_L(false, false, FMT_PK, FMT_F32);
+#undef BIG_L
         DEP_CHECK_LAUNCH();
         if (splits > 1) {
             const long n = (long)M * N;
@@ -833,13 +673,6 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
         }
         return DEP_OK;
     }
-    if (abl < 0) { const char* e = getenv("DEP_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
-    if (persist < 0) { const char* e = getenv("DEP_GEMM_PERSIST"); persist = e ? atoi(e) : 768; if (persist < 8) persist = 8; persist = persist / 8 * 8; }
-    if (bm256 < 0) { const char* e = getenv("DEP_GEMM_BM"); bm256 = (e && atoi(e) == 128) ? 0 : 1; }
-    // measured at cfg2: 256-row tiles win 8-10 % on the NN (dX) and TN (dW) forms, lose 6 % on the short-K NT projection
-    // (round 4: long-K projections -- cfg3's F = 1024 layer -- take the 256-row tile too; DEP_GEMM_NT256=0 restores 128 rows for every NT call)
-    static int nt256 = -1;
-    if (nt256 < 0) { const char* e = getenv("DEP_GEMM_NT256"); nt256 = (e && e[0] == '0') ? 0 : 1; }
     // (a pre-split A operand in the NT form has only the 128-row instantiation: the tile grid must follow -- ADVICE r4)
     const bool big = bm256 && M >= 512 && (!(!transA && transB) || (nt256 && K >= 512)) && !(fa != FMT_F32 && !transA && transB);
     const int BMT = big ? 256 : 128;
@@ -906,6 +739,17 @@ int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A0, const f
     GemmP p0{M, N, K, A0, lda, B0, ldb0, C0, ldc0, nullptr, 0.f, seq_T0, shift0, kchunk, splits, part0, dep_cdiv(N, BN), dep_cdiv(M, 256), 0, nullptr, 0, 8, 0, 0};
     GemmP p1 = p0;
     p1.A = A1; p1.B = B1; p1.ldb = ldb1; p1.C = C1; p1.ldc = ldc1; p1.seqT = seq_T1; p1.shiftB = shift1; p1.part = part1; p1.skip_at = skip_at1; p1.skip_by = skip_by1;
+    if (big_on() && N % BIG == 0) {                               // round 6: 256 x 256 tiles, one workgroup per CU, half of the slots per problem
+        p0.gx = N / BIG; p1.gx = p0.gx;
+        const int ntb = p0.gx * p0.gy * splits, pxb = (ntb + 7) / 8, capb = big_cus() / 8 / 2;
+        big_attrs();
+        DEP_LAUNCH((gemm_bf16x3_big_tn_pair<FMT_PK, FMT_F32>), dim3((pxb < capb ? pxb : capb) * 8 * 2), dim3(BIG_NT), BIG_LDS_BYTES, s, p0, p1);
+        DEP_CHECK_LAUNCH();
+        const long nb = (long)M * N;
+        DEP_LAUNCH(splitk_reduce2_pair, dim3(dep_cdiv(nb, 256), 2), dim3(256), 0, s, part0, part1, splits, M, N, C0, ldc0, C1, ldc1);
+        DEP_CHECK_LAUNCH();
+        return DEP_OK;
+    }
     const int ntiles = p0.gx * p0.gy * splits;
     const int cap = persist * 2 / 3 / 2;                          // two resident workgroups per CU with 256-row tiles, half of the slots per problem
     const int per_xcd = (ntiles + 7) / 8;
