@@ -100,6 +100,9 @@ _SIGS = {
     'dep_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     'dep_instance_log_enable': (C.c_int, [C.c_int]),
     'dep_instance_log_read': (C.c_long, [C.c_char_p, C.c_long, C.c_int]),
+    'dep_order_log_enable': (C.c_int, [C.c_int]),
+    'dep_order_log_note': (C.c_int, [C.c_char_p]),
+    'dep_order_log_read': (C.c_long, [C.c_char_p, C.c_long, C.c_int]),
     'dep_fill': (C.c_int, [_P, C.c_long, C.c_float, _P]),
     'dep_axpby': (C.c_int, [_P, _P, C.c_long, C.c_float, C.c_float, _P]),
     'dep_sigmoid_gate': (C.c_int, [_P, _P, _P, C.c_long, _P]),
@@ -514,3 +517,24 @@ def profile_read():
     ms = (C.c_double * n)(); cnt = (C.c_int * n)()
     load().dep_profile_read(ms, cnt, n)
     return {PROF_CATS[i]: (ms[i], cnt[i]) for i in range(n)}
+
+
+_order_on = [False]
+
+
+def order_log_enable(on=True):
+    """Enqueue-order log (dep_order_log_*): kernel launches, collectives and host notes in host enqueue order."""
+    load().dep_order_log_enable(int(on)); _order_on[0] = bool(on)
+
+
+def order_note(text):
+    if _order_on[0]:
+        load().dep_order_log_note(text.encode())
+
+
+def order_log_read(reset=False):
+    lib = load()
+    n = lib.dep_order_log_read(None, 0, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.dep_order_log_read(buf, n + 1, int(reset))
+    return [l for l in buf.value.decode().split('\n') if l]

@@ -78,8 +78,36 @@ std::atomic<bool> g_ilog_on{false};
 std::mutex g_ilog_mu;
 std::set<std::string> g_ilog;
 }  // namespace
-bool dep_ilog_on() { return g_ilog_on.load(std::memory_order_relaxed); }
+std::atomic<int> g_ilog_any{0};          // bit 0: instance log, bit 1: enqueue-order log (one relaxed load per launch when both are off)
+bool dep_ilog_on() { return g_ilog_any.load(std::memory_order_relaxed) != 0; }
+namespace { std::vector<std::string> g_olog; }
+void dep_olog_add(char kind, const char* text, long n) {
+    if (!(g_ilog_any.load(std::memory_order_relaxed) & 2)) return;
+    std::string e(1, kind); e += ' '; e += text;
+    if (n >= 0) { e += " n="; e += std::to_string(n); }
+    std::lock_guard<std::mutex> lk(g_ilog_mu);
+    g_olog.push_back(std::move(e));
+}
+extern "C" int dep_order_log_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_ilog_mu);
+    if (on) { g_olog.clear(); g_ilog_any.fetch_or(2); } else g_ilog_any.fetch_and(~2);
+    return DEP_OK;
+}
+extern "C" int dep_order_log_note(const char* text) { if (!text) return DEP_ERR_ARG; dep_olog_add('N', text, -1); return DEP_OK; }
+extern "C" long dep_order_log_read(char* buf, long cap, int reset) {
+    std::lock_guard<std::mutex> lk(g_ilog_mu);
+    std::string all;
+    for (const auto& s : g_olog) { all += s; all += '\n'; }
+    if (buf && cap > 0) {
+        const long n = (long)all.size() < cap - 1 ? (long)all.size() : cap - 1;
+        memcpy(buf, all.data(), (size_t)n); buf[n] = 0;
+    }
+    if (reset) g_olog.clear();
+    return (long)all.size() + 1;
+}
 void dep_ilog_note(const char* kern, const char* where) {
+    dep_olog_add('K', kern, -1);
+    if (!g_ilog_on.load(std::memory_order_relaxed)) return;
     std::string k(kern);
     // the kernel as written is enough when it names every template argument; launchers that are templates themselves
     // (kernel<TA, TB, ..>) are told apart by their own signature
@@ -91,7 +119,8 @@ void dep_ilog_note(const char* kern, const char* where) {
     g_ilog.insert(std::move(k));
 }
 extern "C" int dep_instance_log_enable(int on) {
-    if (on) { std::lock_guard<std::mutex> lk(g_ilog_mu); g_ilog.clear(); }
+    std::lock_guard<std::mutex> lk(g_ilog_mu);
+    if (on) { g_ilog.clear(); g_ilog_any.fetch_or(1); } else g_ilog_any.fetch_and(~1);
     g_ilog_on.store(on != 0);
     return DEP_OK;
 }

@@ -96,6 +96,7 @@ extern "C" int dep_comm_rank(const dep_comm* c) { return c ? c->rank : -1; }
 // In-place SUM all-reduce of n fp32 values, enqueued on `stream` (nothing synchronises).
 extern "C" int dep_comm_allreduce(dep_comm* c, float* buf, long n, void* stream) {
     DEP_CHECK_ARG(c && buf && n > 0);
+    dep_olog_add('C', "allreduce", n);
     RCCL_CHECK(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, c->comm, (hipStream_t)stream), "ncclAllReduce");
     return DEP_OK;
 }
@@ -103,6 +104,7 @@ extern "C" int dep_comm_allreduce(dep_comm* c, float* buf, long n, void* stream)
 // Several ranges as ONE grouped RCCL operation (one launch): the layer-0 range and the LayerNorm range of the audio model.
 extern "C" int dep_comm_allreduce_ranges(dep_comm* c, float* const* bufs, const long* counts, int nranges, void* stream) {
     DEP_CHECK_ARG(c && bufs && counts && nranges > 0);
+    { long tot = 0; for (int i = 0; i < nranges; ++i) tot += counts[i] > 0 ? counts[i] : 0; dep_olog_add('C', "allreduce_ranges", tot); }
     RCCL_CHECK(g_rccl.GroupStart(), "ncclGroupStart");
     for (int i = 0; i < nranges; ++i) {
         if (!bufs[i] || counts[i] <= 0) continue;

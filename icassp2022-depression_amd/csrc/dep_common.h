@@ -88,6 +88,8 @@ __device__ __forceinline__ void dep_xcd_tile(int gx, int gy, int gz, int& bx, in
 // oracle-comparing tests launched.  Off (the default): one relaxed atomic load per launch.
 bool dep_ilog_on();
 void dep_ilog_note(const char* kern, const char* where);
+// (dep_order_log_*: the same hook also appends "K <kernel>" to the enqueue-order log while that is on; collectives add "C ..." in comm.hip)
+void dep_olog_add(char kind, const char* text, long n);
 #define DEP_LAUNCH(kern, grid, blk, lds, stream, ...)                                          \
     do {                                                                                       \
         if (dep_ilog_on()) dep_ilog_note(#kern, __PRETTY_FUNCTION__);                          \
@@ -109,6 +111,7 @@ void dep_gemm_set_a_colskip(int at, int by);
 // refuses (DEP_ERR_ARG) a PK operand on any other path.  Reset to (0, 0) after the calls.
 void dep_gemm_set_operand_formats(int fmt_a, int fmt_b);
 bool dep_gemm_pk_pending();
+bool dep_gemm_bf16x3_pair_ok();
 // true when dep_gemm_internal would run the bf16x3 kernel for a contraction of this size (it is the one that honours the skip)
 bool dep_gemm_uses_bf16x3(int M, int N, int K, int seq_T);
 void dep_gemm_set_split_target(long target);      // split-K target of this thread's next contractions (0 = default); gemm.hip

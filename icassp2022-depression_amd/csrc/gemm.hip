@@ -439,7 +439,7 @@ int dep_gemm_tn_pair(int M, int N, int K, const float* A0, const float* A1, int 
     if (on < 0) { const char* e = getenv("DEP_DW_PAIR"); on = (e && e[0] == '0') ? 0 : 1; }
     init_split_mode();
     if (!on || naive_forced() || g_force_exact != 0 || g_split_mode != 1 || (long)M * N * K < g_split_min_macs || M < 512 || dep_gemm_predicate()) return 0;
-    if (!dep_gemm_pk_pending()) return 0;
+    if (!dep_gemm_pk_pending() || !dep_gemm_bf16x3_pair_ok()) return 0;
     auto a16 = [](const void* q, int ld) { return ((uintptr_t)q % 16 == 0) && (ld % 4 == 0); };
     if (!(a16(A0, lda) && a16(A1, lda) && a16(B0, ldb0) && a16(B1, ldb1) && M % 4 == 0 && N % 4 == 0)) return 0;
     int splits = choose_splits(M, N, K);

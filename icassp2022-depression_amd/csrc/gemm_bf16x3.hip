@@ -215,6 +215,8 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
     }
 }
 
+// (Round 6: a 256 x 256-tile, eight-wave, double-buffered form of this kernel measured the same time -- profiles/r06_s4_gemm_256x256_tile_ab.txt,
+// DESIGN 4.7 -- and was deleted again; the NTH parameter of load_tile / store_tile above is what is left of it.)
 // Persistent, cross-tile pipelined: a workgroup walks a strided list of output tiles taken from ITS XCD's contiguous
 // share of the tile order (so tiles processed together on an XCD share operand panels in that L2) and treats
 // (tile, k-tile) as one iteration space: the register prefetch issued in the last k-iteration of a tile already
@@ -379,166 +381,6 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3_tn_pair(
     else gemm_bf16x3_walk<true, false, VEC, BMT, 3, FA, FB>(p0, bid, nblk);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 6: the 256 x 256-tile form.  Measured first (profiles/r06_gemm_clock_ablation.txt): every form runs with the
-// shader clock held at 1.6-2.1 GHz by the power manager; the matrix part (MFMAs + fragment reads) alone is power-bound at 0.9-1.5 PF of
-// products; the OPERAND PATH (L2 -> CU loads, conversion, LDS staging) is not power-bound and takes as long as the matrix part or longer
-// (cfg3's N = 1024 contractions: 0.82 ms against 0.66).  A schedule cannot beat max(operand path, matrix part); fewer operand bytes and
-// conversions per flop can.  So: ONE workgroup of eight waves per CU on a 256 x 256 tile (2 x 4 waves, each the same 128 x 64 = 4 x 2 MFMA
-// tiles as above) -- per flop a third fewer operand bytes through L2 -> registers -> LDS than 256 x 128 and half the conversions of the
-// operand that used to be re-staged per 128-column tile; the two LDS stages alternate (2 x 80 KB = the whole LDS), ONE barrier per k-tile:
-// convert + stage k-tile i+1 from registers, request k-tile i+2, multiply k-tile i.  Same k order, same three products per 16 k, same
-// split-K chunks: every result BIT-IDENTICAL to the 256 x 128 kernel (tests/golden/device_bits.json).
-constexpr int BIG = 256, BIG_NT = 512;
-constexpr int BIG_PLANE = BIG * LDK;                          // bf16 elements of one operand plane of a stage
-constexpr int BIG_STAGE = 4 * BIG_PLANE;                      // Ah, Al, Bh, Bl
-constexpr size_t BIG_LDS_BYTES = (size_t)2 * BIG_STAGE * sizeof(__bf16);      // 163,840 B
-
-struct BigPos {                                               // a position in the (tile, k-tile) iteration space of one workgroup
-    int tile, m0, n0, kbeg, kend, bz, k0; bool valid;
-};
-
-template <bool TA, bool TB, int FA, int FB>
-__device__ __forceinline__ void gemm_big_walk(const GemmP& p, const int block_id, const int block_count, __bf16* smem) {
-    constexpr bool A_TR = TA, B_TR = !TB;
-    constexpr int MI = 4;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 2, wn = w & 3;
-    const int half = lane >> 5, l31 = lane & 31;
-
-    const int ntiles = p.gx * p.gy * p.splits;
-    const int x8 = block_id & 7, slot = block_id >> 3, slots = block_count >> 3;
-    const int q = ntiles / 8, r8 = ntiles % 8;
-    const int lo = x8 < r8 ? x8 * (q + 1) : r8 * (q + 1) + (x8 - r8) * q;
-    const int hi = lo + (x8 < r8 ? q + 1 : q);
-    if (lo + slot >= hi) return;
-
-    auto place = [&](BigPos& s, int t) {
-        s.tile = t; s.valid = t < hi;
-        if (!s.valid) return;
-        const int bx = t % p.gx, by = (t / p.gx) % p.gy; s.bz = t / (p.gx * p.gy);
-        s.m0 = by * BIG; s.n0 = bx * BIG; s.kbeg = s.bz * p.kchunk; s.kend = min(p.K, s.kbeg + p.kchunk); s.k0 = s.kbeg;
-    };
-    auto advance = [&](BigPos& s) {
-        if (!s.valid) return;
-        s.k0 += BK;
-        if (s.k0 >= s.kend) place(s, s.tile + slots);
-    };
-    float ra[4][4], rb[4][4];
-    auto fetch = [&](const BigPos& s) {
-        load_tile<A_TR, true, BIG, FA, BIG_NT>(p.A, p.lda, s.m0, p.M, s.k0, s.kend, tid, ra, 0, 0, p.skip_at, p.skip_by);
-        load_tile<B_TR, true, BIG, FB, BIG_NT>(p.B, p.ldb, s.n0, p.N, s.k0, s.kend, tid, rb, p.seqT, p.shiftB);
-    };
-    auto stage_out = [&](int st) {
-        __bf16* base = smem + st * BIG_STAGE;
-        store_tile<A_TR, BIG, 3, FA, BIG_NT>(base, base + BIG_PLANE, tid, ra);
-        store_tile<B_TR, BIG, 3, FB, BIG_NT>(base + 2 * BIG_PLANE, base + 3 * BIG_PLANE, tid, rb);
-    };
-
-    BigPos cur, nxt;
-    place(cur, lo + slot);
-    fetch(cur);
-    stage_out(0);
-    nxt = cur; advance(nxt);
-    if (nxt.valid) fetch(nxt);
-    __syncthreads();
-
-    f32x16 acc[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    for (int it = 0; cur.valid; ++it) {
-        // k-tile it+1: registers -> the other stage (its readers left it at the last barrier); then the request for k-tile it+2
-        if (nxt.valid && !(p.ablate & 8)) stage_out((it + 1) & 1);
-        BigPos nn = nxt; advance(nn);
-        if (nn.valid && !(p.ablate & 4)) fetch(nn);
-        const __bf16* Ah = smem + (it & 1) * BIG_STAGE; const __bf16* Al = Ah + BIG_PLANE;
-        const __bf16* Bh = Ah + 2 * BIG_PLANE; const __bf16* Bl = Bh + BIG_PLANE;
-        if (!(p.ablate & 2))
-#pragma unroll
-        for (int s2 = 0; s2 < BK / 16; ++s2) {
-            const int ko = s2 * 16 + half * 8;
-            bf16x8 ah[MI], al[MI], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int ro = (wm * 128 + i * 32 + l31) * LDK + ko;
-                ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro); al[i] = *reinterpret_cast<const bf16x8*>(Al + ro);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int ro = (wn * 64 + j * 32 + l31) * LDK + ko;
-                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + ro); bl[j] = *reinterpret_cast<const bf16x8*>(Bl + ro);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (cur.k0 + BK >= cur.kend) {                        // the tile's last k-tile: write it out (its stores drain under the next tile's loads)
-            const bool split = p.part != nullptr;
-            float* outp = split ? p.part + (size_t)cur.bz * p.M * p.N : p.C;
-            const int ldo = split ? p.N : p.ldc;
-            const bool v4 = ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0);
-            const bool addb = !split && p.bias;
-            const bool rmw = !split && p.beta != 0.f;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = cur.m0 + wm * 128 + i * 32 + l31;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = cur.n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
-                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        acc[i][j][4 * g] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
-                        if (m >= p.M || n >= p.N) continue;
-                        float* dst = outp + (size_t)m * ldo + n;
-                        if (v4 && n + 3 < p.N) {
-                            if (addb) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                            if (rmw) v += p.beta * *reinterpret_cast<const f32x4*>(dst);
-                            if (!(p.ablate & 1) || v[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(dst) = v;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < p.N) {
-                                    float x = v[e] + (addb ? p.bias[n + e] : 0.f);
-                                    if (rmw) x += p.beta * dst[e];
-                                    dst[e] = x;
-                                }
-                        }
-                    }
-            }
-        }
-        cur = nxt; nxt = nn;
-        __syncthreads();
-    }
-}
-
-template <bool TA, bool TB, int FA, int FB>
-__global__ __launch_bounds__(BIG_NT, 1) void gemm_bf16x3_big(GemmP p) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 big_smem[];
-    if (p.only_if && *p.only_if == 0) return;
-    gemm_big_walk<TA, TB, FA, FB>(p, blockIdx.x, gridDim.x, big_smem);
-}
-
-// the paired weight-gradient launch (gemm_bf16x3_tn_pair above) on 256 x 256 tiles: slots 2i / 2i+1 of an XCD walk tile list i of problem 0 / 1
-template <int FA, int FB>
-__global__ __launch_bounds__(BIG_NT, 1) void gemm_bf16x3_big_tn_pair(GemmP p0, GemmP p1) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 big_smem[];
-    const int x8 = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int bid = ((slot >> 1) << 3) | x8, nblk = gridDim.x >> 1;
-    if (slot & 1) gemm_big_walk<true, false, FA, FB>(p1, bid, nblk, big_smem);
-    else gemm_big_walk<true, false, FA, FB>(p0, bid, nblk, big_smem);
-}
-
 // both problems' split-K partials in one launch (blockIdx.y = problem)
 __global__ void splitk_reduce2_pair(const float* __restrict__ part0, const float* __restrict__ part1, int splits, int M, int N,
                                     float* C0, int ldc0, float* C1, int ldc1) {
@@ -603,24 +445,14 @@ void dep_gemm_set_a_colskip(int at, int by) { g_skip_at = at; g_skip_by = by; }
 static thread_local int g_fmt_a = FMT_F32, g_fmt_b = FMT_F32;
 void dep_gemm_set_operand_formats(int fmt_a, int fmt_b) { g_fmt_a = fmt_a; g_fmt_b = fmt_b; }
 bool dep_gemm_pk_pending() { return g_fmt_a != FMT_F32 || g_fmt_b != FMT_F32; }
+// can the paired launch run in this thread's / process's configuration?  (An XCD restriction, an ablation setting or DEP_GEMM_BM=128 apply to the
+// single launches only: dep_gemm_tn_pair then reports "not covered" and the caller issues the two contractions itself -- ADVICE r5.)
+bool dep_gemm_bf16x3_pair_ok() {
+    static int plain = -1;
+    if (plain < 0) { const char* a = getenv("DEP_GEMM_ABLATE"); const char* b = getenv("DEP_GEMM_BM"); plain = ((a && atoi(a) != 0) || (b && atoi(b) == 128)) ? 0 : 1; }
+    return plain && g_xcd_lo == 0 && g_xcd_n == 8;
+}
 extern "C" int dep_gemm_set_xcds(int lo, int n) { if (lo < 0 || n < 1 || lo + n > 8) return DEP_ERR_ARG; g_xcd_lo = lo; g_xcd_n = n; return DEP_OK; }
-
-static bool big_on() { static int on = -1; if (on < 0) { const char* e = getenv("DEP_GEMM_BIG"); on = (e && e[0] == '0') ? 0 : 1; } return on != 0; }
-static int big_cus() {      // workgroups of the one-per-CU launch: the device's CUs, a multiple of 8
-    static int cus = -1;
-    if (cus < 0) { hipDeviceProp_t pr; int dv = 0; cus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; cus = cus / 8 * 8; if (cus < 8) cus = 8; }
-    return cus;
-}
-static void big_attrs() {
-    static bool done = false;
-    if (done) return;
-#define BIG_A(...) (void)hipFuncSetAttribute((const void*)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIG_LDS_BYTES)
-    BIG_A(gemm_bf16x3_big<false, true, FMT_F32, FMT_F32>); BIG_A(gemm_bf16x3_big<false, false, FMT_F32, FMT_F32>); BIG_A(gemm_bf16x3_big<true, false, FMT_F32, FMT_F32>);
-    BIG_A(gemm_bf16x3_big<true, false, FMT_PK, FMT_PK>); BIG_A(gemm_bf16x3_big<true, false, FMT_PK, FMT_F32>); BIG_A(gemm_bf16x3_big<false, false, FMT_PK, FMT_F32>);
-    BIG_A(gemm_bf16x3_big_tn_pair<FMT_PK, FMT_F32>);
-#undef BIG_A
-    done = true;
-}
 
 // Same contract as dep_gemm_internal (gemm.hip); `splits` is decided by the caller's shared heuristic.
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
@@ -651,28 +483,6 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     // (round 4: long-K projections -- cfg3's F = 1024 layer -- take the 256-row tile too; DEP_GEMM_NT256=0 restores 128 rows for every NT call)
     static int nt256 = -1;
     if (nt256 < 0) { const char* e = getenv("DEP_GEMM_NT256"); nt256 = (e && e[0] == '0') ? 0 : 1; }
-    // round 6: 256 x 256 tiles, one eight-wave workgroup per CU (gemm_bf16x3_big above) where the output is at least two of the old tiles wide:
-    // the split-precision forms of the RNN stacks (NT projections, NN dX, TN weight gradients).  DEP_GEMM_BIG=0: the 256 x 128 kernel (A/B; bit-identical).
-    if (big_on() && vec && terms == 3 && M >= 512 && N % BIG == 0 && g_xcd_lo == 0 && g_xcd_n == 8 && spanA < (1ull << 32) && spanB < (1ull << 32) &&
-        ((fa == FMT_F32 && fb == FMT_F32) || (fa == FMT_PK && fb == FMT_F32 && (transA || !transB)) || (fa == FMT_PK && fb == FMT_PK && transA && !transB))) {
-        GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, N / BIG, dep_cdiv(M, BIG), abl, dep_gemm_predicate(), 0, 8, transA ? g_skip_at : 0, transA ? g_skip_by : 0};
-        const int ntiles = p.gx * p.gy * splits, per_xcd = (ntiles + 7) / 8, cap = big_cus() / 8;
-        const dim3 g((per_xcd < cap ? per_xcd : cap) * 8);
-        big_attrs();
-#define BIG_L(TA, TB, FA_, FB_) DEP_LAUNCH((gemm_bf16x3_big<TA, TB, FA_, FB_>), g, dim3(BIG_NT), BIG_LDS_BYTES, s, p)
-        if (fa == FMT_F32) { if (!transA && transB) BIG_L(false, true, FMT_F32, FMT_F32); else if (!transA) BIG_L(false, false, FMT_F32, FMT_F32); else BIG_L(true, false, FMT_F32, FMT_F32); }
-        else if (fb == FMT_PK) BIG_L(true, false, FMT_PK, FMT_PK);
-        else if (transA) BIG_L(true, false, FMT_PK, FMT_F32);
-        else BIG_L(false, false, FMT_PK, FMT_F32);
-#undef BIG_L
-        DEP_CHECK_LAUNCH();
-        if (splits > 1) {
-            const long n = (long)M * N;
-            DEP_LAUNCH(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, dep_gemm_predicate(), part, splits, M, N, C, ldc, bias, beta);
-            DEP_CHECK_LAUNCH();
-        }
-        return DEP_OK;
-    }
     // (a pre-split A operand in the NT form has only the 128-row instantiation: the tile grid must follow -- ADVICE r4)
     const bool big = bm256 && M >= 512 && (!(!transA && transB) || (nt256 && K >= 512)) && !(fa != FMT_F32 && !transA && transB);
     const int BMT = big ? 256 : 128;
@@ -739,17 +549,6 @@ int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A0, const f
     GemmP p0{M, N, K, A0, lda, B0, ldb0, C0, ldc0, nullptr, 0.f, seq_T0, shift0, kchunk, splits, part0, dep_cdiv(N, BN), dep_cdiv(M, 256), 0, nullptr, 0, 8, 0, 0};
     GemmP p1 = p0;
     p1.A = A1; p1.B = B1; p1.ldb = ldb1; p1.C = C1; p1.ldc = ldc1; p1.seqT = seq_T1; p1.shiftB = shift1; p1.part = part1; p1.skip_at = skip_at1; p1.skip_by = skip_by1;
-    if (big_on() && N % BIG == 0) {                               // round 6: 256 x 256 tiles, one workgroup per CU, half of the slots per problem
-        p0.gx = N / BIG; p1.gx = p0.gx;
-        const int ntb = p0.gx * p0.gy * splits, pxb = (ntb + 7) / 8, capb = big_cus() / 8 / 2;
-        big_attrs();
-        DEP_LAUNCH((gemm_bf16x3_big_tn_pair<FMT_PK, FMT_F32>), dim3((pxb < capb ? pxb : capb) * 8 * 2), dim3(BIG_NT), BIG_LDS_BYTES, s, p0, p1);
-        DEP_CHECK_LAUNCH();
-        const long nb = (long)M * N;
-        DEP_LAUNCH(splitk_reduce2_pair, dim3(dep_cdiv(nb, 256), 2), dim3(256), 0, s, part0, part1, splits, M, N, C0, ldc0, C1, ldc1);
-        DEP_CHECK_LAUNCH();
-        return DEP_OK;
-    }
     const int ntiles = p0.gx * p0.gy * splits;
     const int cap = persist * 2 / 3 / 2;                          // two resident workgroups per CU with 256-row tiles, half of the slots per problem
     const int per_xcd = (ntiles + 7) / 8;

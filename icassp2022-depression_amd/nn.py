@@ -220,7 +220,9 @@ class Loss:
     def backward(self):
         if self._bw is None:
             raise RuntimeError('loss computed under evaluate(): nothing to backpropagate')
+        L.order_note('backward begin')
         self._bw()
+        L.order_note('backward end')
 
     def __float__(self):
         return self.item()
@@ -412,6 +414,7 @@ class _AdamBase:
 
     def step(self):
         self._step += 1
+        L.order_note('optimizer step')
         for g in self.param_groups:
             b1, b2 = g['betas']
             for owner, s, e in self._ranges(g):

@@ -106,6 +106,8 @@ def all_reduce_grads(model):
     """SUM all-reduce of the model's single contiguous live-gradient bucket (torch.distributed transport)."""
     d = _dist()
     if d and model._grad_ready:
+        from . import _lib as L
+        L.order_note('C torch.distributed all_reduce of the live bucket (on the compute stream)')
         d.all_reduce(model.live_grad_bucket(), op=d.ReduceOp.SUM)
 
 
@@ -240,6 +242,7 @@ def finish_grad_sync(model, in_call, post):
                 'dep_comm_allreduce_ranges')
     ev2 = torch.cuda.Event(); ev2.record(cs)
     cur.wait_event(ev2)
+    L.order_note('join: the compute stream waits for the communication stream')
 
 
 def reduce_zero_contribution(model, in_call, post):

@@ -359,6 +359,15 @@ int dep_profile_read(double* total_ms, int* counts, int ncat);
 int dep_instance_log_enable(int on);
 long dep_instance_log_read(char* buf, long cap, int reset);
 
+/* Enqueue-order log (test infrastructure of the data-parallel path, tests/test_dp_gpu.py): while enabled, every kernel launch and every
+ * collective the library enqueues ("K <kernel>" / "C <what> n=<floats>") is appended IN HOST ENQUEUE ORDER, together with the notes the
+ * host adds through dep_order_log_note ("N <text>": the stream joins, the phases of a train step).  The two launches that need every CU
+ * (the fused GRU forward / backward) must never have a collective enqueued in front of them that is not joined: the test asserts that on
+ * this log.  dep_order_log_enable(1) clears and starts, (0) stops; dep_order_log_read as dep_instance_log_read (newline-separated). */
+int dep_order_log_enable(int on);
+int dep_order_log_note(const char* text);
+long dep_order_log_read(char* buf, long cap, int reset);
+
 /* ------------------------------------------------------------------ misc ----------- */
 int dep_fill(float* p, long n, float value, void* stream);
 /* y = a*x + b*y */

@@ -126,6 +126,61 @@ def test_native_rccl_comm_overlapped_backward_single_rank():
         assert torch.equal(grads[(name, False)], grads[(name, True)]), name
 
 
+def test_no_collective_is_enqueued_in_front_of_a_launch_that_needs_every_cu():
+    """VERDICT r5 item 8.  The fused GRU forward AND (since round 5) the fused GRU backward fill every CU (12 x 168 VGPRs, 162 KB LDS): an RCCL
+    kernel resident on a CU when they dispatch would break the co-residency their hand-off relies on (the forward then leaves through the
+    on-device fallback, status 5 would be the backward's).  DESIGN section 6 argues that by ENQUEUE ORDER no collective can be running then;
+    this holds that argument against the library's enqueue-order log (dep_order_log_*) on the native RCCL path with a one-rank communicator,
+    three cfg2-shaped train steps:
+      * every collective of a step is enqueued AFTER that step's fused backward launch (the in-call ranges behind their layer's weight-gradient
+        GEMMs, the rest in finish_grad_sync) -- none between `backward begin` and the fused launch;
+      * after the step's last collective the compute stream JOINS the communication stream before the optimizer step, so everything the next
+        step's fused forward could meet has completed: between a step's join and the next fused forward no collective is enqueued."""
+    from icassp2022_depression_amd import audio_gru_whole as ma, nn, parallel, _lib as L
+    assert parallel.init_native_comm(force_single=True) is not None
+    try:
+        cfg = dict(ma.config); cfg.update(embedding_size=256, hidden_dims=256, dropout=0.5)
+        model = ma.AudioBiLSTM(cfg, seed=3); model.train()
+        opt = nn.AdamW(ma.get_param_group(model), lr=1e-4)
+        crit = nn.CrossEntropyLoss()
+        x = torch.randn(64, 40, 256, device='cuda'); y = np.random.default_rng(6).integers(0, 2, 64)
+        parallel.set_global_count(64)
+        def step():
+            opt.zero_grad(); loss = crit(model(x), y); loss.backward(); opt.step()
+        step(); torch.cuda.synchronize()
+        L.order_log_enable(True)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        log = L.order_log_read(reset=True); L.order_log_enable(False)
+    finally:
+        parallel.destroy_native_comm()
+    kinds = []
+    for e in log:
+        if e.startswith('K ') and 'gru2_fwd_fused' in e: kinds.append('FWD')
+        elif e.startswith('K ') and 'gru2_bwd_fused' in e: kinds.append('BWD')
+        elif e.startswith('C '): kinds.append('C')
+        elif e.startswith('N join'): kinds.append('JOIN')
+        elif e.startswith('N backward begin'): kinds.append('BB')
+        elif e.startswith('N optimizer step'): kinds.append('OPT')
+    assert kinds.count('FWD') == 3 and kinds.count('BWD') == 3 and kinds.count('C') >= 3, (kinds, log[:40])     # the exclusive launches ran; collectives were enqueued
+    state = 'clean'                 # 'clean': no collective outstanding that the compute stream has not joined
+    for k in kinds:
+        if k == 'C':
+            state = 'outstanding'
+        elif k == 'JOIN':
+            state = 'clean'
+        elif k in ('FWD', 'BWD'):
+            assert state == 'clean', ('a collective is enqueued and not joined in front of', k, kinds)
+        elif k == 'OPT':
+            assert state == 'clean', ('the optimizer step is enqueued before the gradient collectives were joined', kinds)
+    # ... and structurally: BB -> BWD -> C+ -> JOIN -> OPT in every step
+    seq = [k for k in kinds if k != 'FWD']
+    per_step = ''.join({'BB': 'b', 'BWD': 'W', 'C': 'c', 'JOIN': 'j', 'OPT': 'o'}[k] for k in seq)
+    import re
+    assert re.fullmatch(r'(bWc+jo){3}', per_step), per_step
+
+
 # ------------------------------------------------------------------------------------------- the other train() loops (VERDICT r2)
 def _run_generic(case, rank, world, port, q, dropout):
     """One rank of `case`'s train() on the reference-made train/eval fixture of that script."""
