@@ -600,7 +600,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     auto pk_gru_ok = [&](int l, bool has_dxl, const float* dxl_probe) {
         const float* in = l == 0 ? x : (lo.drop ? R + lo.ydrop[l - 1] : R + lo.y[l - 1]);
         const int Kl = l == 0 ? d->F : D * H;
-        return pk_env && lo.dg4 && lo.cluster && d->cell == DEP_CELL_GRU && sweep_split_mode() && (dep_get_gemm_mode() == 1 || lo.bf16st) &&
+        return pk_env && lo.dg4 && lo.cluster && d->cell == DEP_CELL_GRU && sweep_split_mode() && dep_get_gemm_mode() >= 1 &&
                (fused || dep_cluster_bwd_pk_ok(H, T)) && (T % 2 == 0) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(weights[(size_t)l * 4]) &&
                al16(dweights[(size_t)l * 4]) && al16(dweights[(size_t)l * 4 + 1]) &&
                dep_gemm_uses_bf16x3(G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(3 * H, H, BTr, T) &&
@@ -668,7 +668,7 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
         float* dxl_probe = l == 0 ? dx : (fused ? nullptr : W + lo.dx[l & 1]);
         const bool pk_gru = fused ? fused_pk : (a.split && pk_gru_ok(l, dxl_probe != nullptr, dxl_probe));
         // the BiLSTM cluster sweep (both directions in one launch, direction-stacked contractions): same image, same conditions
-        bool pk_lstm = pk_env && lo.cluster && d->cell == DEP_CELL_LSTM && D == 2 && lo.wstack[l] != 0 && a.split && dep_get_gemm_mode() == 1 &&
+        bool pk_lstm = pk_env && lo.cluster && d->cell == DEP_CELL_LSTM && D == 2 && lo.wstack[l] != 0 && a.split && dep_get_gemm_mode() >= 1 &&
                        dep_cluster_lstm_bwd_pk_ok(T) && (BTr % 2 == 0) && (Kl % 4 == 0) && al16(in) && al16(W + lo.dwstack) &&
                        dep_gemm_uses_bf16x3(D * G * H, Kl, BTr, 0) && dep_gemm_uses_bf16x3(4 * H, H, BTr, T) &&
                        (!dxl_probe || (dep_gemm_uses_bf16x3(BTr, Kl, D * G * H, 0) && al16(dxl_probe)));
@@ -680,7 +680,10 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
             return DEP_ERR_ARG;
         }
         a.bf16st = lo.bf16st ? 1 : 0;
-        const int fmt_a = lo.bf16st ? 2 : 1;                       // FMT_PKH / FMT_PK (gemm_bf16x3.hip)
+        // FMT_PKH / FMT_PK (gemm_bf16x3.hip).  Round 6: the single-product modes (dep_set_gemm_mode(2 / 3)) read the sweep's PK image through its hi rows
+        // on every stack (the same bf16 values their on-the-fly conversion formed: bit-identical, without the fp32 staging path that made
+        // cfg3's weight gradients slower in that mode than with three products)
+        const int fmt_a = (lo.bf16st || dep_get_gemm_mode() >= 2) ? 2 : 1;
         a.sv16 = (lo.sv16 && sweep_split_mode() && lo.cluster) ? 1 : 0;
         struct FmtGuard { bool on; ~FmtGuard() { if (on) dep_gemm_set_operand_formats(0, 0); } } fmt_guard{pk};
         if (!fused) {
