@@ -215,8 +215,8 @@ __device__ __forceinline__ void store_tile(__bf16* Sh, __bf16* Sl, int tid, cons
     }
 }
 
-// (Round 6: a 256 x 256-tile, eight-wave, double-buffered form of this kernel measured the same time -- profiles/r06_s4_gemm_256x256_tile_ab.txt,
-// DESIGN 4.7 -- and was deleted again; the NTH parameter of load_tile / store_tile above is what is left of it.)
+// (Round 6: a 256 x 256-tile, eight-wave, double-buffered form of this kernel -- lock-step and ping-pong builds -- measured the same time / slower:
+// profiles/r06_s4_gemm_256x256_tile_ab.txt, r06_s6_gemm_pingpong_ab.txt, DESIGN 4.7 -- and was deleted again; the NTH parameter of load_tile / store_tile above is what is left of it.)
 // Persistent, cross-tile pipelined: a workgroup walks a strided list of output tiles taken from ITS XCD's contiguous
 // share of the tile order (so tiles processed together on an XCD share operand panels in that L2) and treats
 // (tile, k-tile) as one iteration space: the register prefetch issued in the last k-iteration of a tile already
