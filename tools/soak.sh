@@ -4,7 +4,7 @@
 out=${1:-gpurun_out/soak.txt}
 {
 echo "# tests/stress_handoff.py on the final kernels (one MI355X, full-size stacks: B=512, T=300 unless noted; every iteration bit for bit against the"
-echo "# first one (--two-refs: or against the fallback path's reference), status word read after every step).  Round 5 kernels: fused all-gather backward, paired dW launch, PK gate gradients,"
+echo "# first one (--two-refs: or against the fallback path's reference), status word read after every step).  Final kernels (rounds 5-6): fused all-gather backward, paired dW launch, PK gate gradients,"
 echo "# 16-bit saved gates (GRU), non-temporal streams, sentinel hand-off of the fused GRU forward and the BiLSTM forward, per-step streams in both BiLSTM sweeps."
 run() { note=$1; shift; python tests/stress_handoff.py "$@" 2>/dev/null | grep '^{' | tail -1 | python -c "
 import json,sys
