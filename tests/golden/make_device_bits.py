@@ -40,25 +40,42 @@ CASES = [
 ]
 
 
-def digests(case):
-    name, B, T, F, flags, env = case
+def _sha(path, name):
+    z = np.load(path)
+    res = {}
+    for k in sorted(z.files):
+        a = np.ascontiguousarray(z[k])
+        assert np.isfinite(a).all(), (name, k)
+        res[k] = hashlib.sha256(a.tobytes()).hexdigest()[:24]
+    return res
+
+
+def all_digests(cases=None):
+    """{case name: {array: sha256}} of `cases` (default: all) -- the cases that share an environment run in ONE pk_probe.py process."""
+    cases = CASES if cases is None else cases
+    by_env = {}
+    for c in cases:
+        by_env.setdefault(tuple(sorted(c[5].items())), []).append(c)
+    rec = {}
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, 'o.npz')
-        e = dict(os.environ); e.update(env)
-        r = subprocess.run([sys.executable, os.path.join(TESTS, 'pk_probe.py'), out, str(B), str(T), str(F)] + flags, env=e,
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        z = np.load(out)
-        res = {}
-        for k in sorted(z.files):
-            a = np.ascontiguousarray(z[k])
-            assert np.isfinite(a).all(), (name, k)
-            res[k] = hashlib.sha256(a.tobytes()).hexdigest()[:24]
-        return res
+        for env, group in by_env.items():
+            plan = [[os.path.join(d, c[0] + '.npz'), c[1], c[2], c[3], c[4]] for c in group]
+            pf = os.path.join(d, 'plan_%d.json' % len(rec))
+            json.dump(plan, open(pf, 'w'))
+            e = dict(os.environ); e.update(dict(env))
+            r = subprocess.run([sys.executable, os.path.join(TESTS, 'pk_probe.py'), '--batch', pf], env=e, capture_output=True, text=True, timeout=1200)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+            for c, pl in zip(group, plan):
+                rec[c[0]] = _sha(pl[0], c[0])
+    return rec
+
+
+def digests(case):
+    return all_digests([case])[case[0]]
 
 
 if __name__ == '__main__':
-    rec = {c[0]: digests(c) for c in CASES}
+    rec = all_digests()
     dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, 'device_bits.json')
     json.dump({'library': os.environ.get('DEP_LIB_PATH', 'in-tree'), 'cases': rec}, open(dst, 'w'), indent=1, sort_keys=True)
     print('wrote', dst, len(rec), 'cases')

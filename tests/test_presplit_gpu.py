@@ -27,8 +27,7 @@ def _run(tmp_path, tag, pk, B, T, F, dx, lstm=False, env=None, nody=False):
 # B = 416: 26 tiles -> every burst phase 0..3 (the PK flush lags one step for the odd ones); T even, with 0 / 2 steps after the last
 # dirty step; F = 64 / 256: both layers' contractions above the three-term kernel's size threshold; dx: the NN form of layer 0 too
 # nody: the training step's call form (dpooled only, no dX): gru2_bwd_fused<.., HASDY = false, ..> -- three input slots, prefetch distance 2
-@pytest.mark.parametrize('B,T,F,dx,nody', [(416, 20, 64, False, False), (416, 22, 256, True, False), (160, 6, 256, False, False), (512, 300, 256, False, False),
-                                           (416, 20, 64, False, True), (160, 6, 256, False, True), (40, 2, 256, False, True), (512, 300, 256, False, True)])
+@pytest.mark.parametrize('B,T,F,dx,nody', [(416, 20, 64, False, False), (416, 22, 256, True, False), (160, 6, 256, False, True), (40, 2, 256, False, True), (512, 300, 256, False, True)])
 def test_pk_gate_gradients_leave_every_gradient_bit_identical(tmp_path, B, T, F, dx, nody):
     a = _run(tmp_path, 'a', 0, B, T, F, dx, nody=nody)
     b = _run(tmp_path, 'b', 1, B, T, F, dx, nody=nody)
@@ -69,16 +68,21 @@ sys.path.insert(0, os.path.join(HERE, 'golden'))
 import make_device_bits as _bits  # noqa: E402
 
 
+_BITS_NOW = {}
+
+
 @pytest.mark.parametrize('case', _bits.CASES, ids=[c[0] for c in _bits.CASES])
 def test_gradients_are_bit_identical_to_the_recorded_device_bits(case):
     rec = json.load(open(os.path.join(HERE, 'golden', 'device_bits.json')))['cases'][case[0]]
-    got = _bits.digests(case)
+    if not _BITS_NOW:                                 # all sixteen cases in two pk_probe.py processes (one per environment), once per session
+        _BITS_NOW.update(_bits.all_digests())
+    got = _BITS_NOW[case[0]]
     assert sorted(got) == sorted(rec)
     bad = [k for k in got if got[k] != rec[k]]
     assert not bad, bad
 
 
-@pytest.mark.parametrize('form', [['dx'], ['nody']])
+@pytest.mark.parametrize('form', [['nody']])
 def test_16bit_saved_gates_move_no_gradient_by_more_than_1e4_of_its_scale(tmp_path, form):
     """Round 4: the GRU stack saves r, z (unorm16) and n (snorm16) as 16-bit fixed point (|error| <= 7.6e-6 / 1.5e-5) instead of fp32.
     Forward outputs cannot change (the gates are only stored for the backward); every gradient of the cfg2-shaped stack must stay
@@ -101,7 +105,7 @@ def test_16bit_saved_gates_move_no_gradient_by_more_than_1e4_of_its_scale(tmp_pa
     assert worst > 0.0            # the switch really changed the stored gates
 
 
-@pytest.mark.parametrize('form', [[], ['nody']])
+@pytest.mark.parametrize('form', [['nody']])
 def test_bf16_storage_mode_has_its_own_tolerance(tmp_path, form):
     """dep_set_gemm_mode(3) / DEP_GEMM_MODE=bf16s (BASELINE configs[1]'s "bf16", a labelled throughput mode, NEVER the parity path): the
     hidden sequences, hn and the gate gradients live in HBM as bf16 (the saved gates as 16-bit fixed point), state / accumulation /
@@ -139,7 +143,7 @@ def test_bf16_product_mode_reads_the_pk_image_and_keeps_its_tolerance(tmp_path, 
     for tag, env in (('x3', {}), ('bf16', {'DEP_GEMM_MODE': 'bf16'}), ('bf16_rows', {'DEP_GEMM_MODE': 'bf16', 'DEP_DGI_PK': '0'})):
         out = str(tmp_path / f'{tag}.npz')
         e = dict(os.environ); e.update(env)
-        shape = ['512', '300', '1024'] if 'lstm' in form else ['512', '300', '256']
+        shape = ['416', '22', '1024'] if 'lstm' in form else ['512', '300', '256']      # (the BiLSTM case at a short T: its contractions are above the split threshold there too)
         r = subprocess.run([sys.executable, os.path.join(HERE, 'pk_probe.py'), out] + shape + form, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs[tag] = np.load(out)

@@ -15,17 +15,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 CASES = [
     # cell, iters, extra env, extra args
-    ('gru', 20, {}, []),
-    ('gru', 20, {}, ['--model-form']),                            # the training step's call form: gru2_bwd_fused<.., HASDY = false, ..> (three input slots, prefetch distance 2)
+    ('gru', 12, {}, []),
+    ('gru', 12, {}, ['--model-form']),                            # the training step's call form: gru2_bwd_fused<.., HASDY = false, ..> (three input slots, prefetch distance 2)
     ('gru', 8, {'DEP_CLUSTER_NOFAST': '1'}, ['--model-form']),
     ('gru', 8, {}, ['--model-form', '--load', '--load-phase', 'bwd']),
-    ('gru', 10, {'DEP_CLUSTER_NOFAST': '1'}, []),
+    ('gru', 6, {'DEP_CLUSTER_NOFAST': '1'}, []),
     ('gru', 4, {'DEP_NUM_CUS': '48'}, []),
     ('gru', 6, {'DEP_NUM_CUS': '200'}, []),
-    ('gru', 12, {}, ['--load', '--load-phase', 'bwd']),            # what an overlapped all-reduce does: load beside the backward
+    ('gru', 8, {}, ['--load', '--load-phase', 'bwd']),            # what an overlapped all-reduce does: load beside the backward
     ('gru', 8, {'DEP_CLUSTER_NOFAST': '1'}, ['--load', '--load-phase', 'bwd']),
     ('gru', 8, {'DEP_CLUSTER16': '0', 'DEP_FUSED2': '0'}, ['--load']),   # co-scheduling-tolerant forward (one 4-wave workgroup per CU) + load on both halves
-    ('gru', 10, {'DEP_FUSED2': '0'}, []),                         # per-layer forward kernels (16-unit members) instead of the fused 2-layer launch
+    ('gru', 6, {'DEP_FUSED2': '0'}, []),                         # per-layer forward kernels (16-unit members) instead of the fused 2-layer launch
     ('gru', 6, {'DEP_FUSED2': '0', 'DEP_CLUSTER_NOFAST': '1'}, []),
     ('gru', 8, {}, ['--load', '--H', '128']),
     ('gru', 8, {'DEP_GEMM_MODE': 'f32'}, []),                    # exact-fp32 sweeps (different member kernels)
@@ -35,7 +35,7 @@ CASES = [
     ('gru', 6, {}, ['--H', '64']),                                # two members per tile
     ('gru', 4, {}, ['--H', '512', '--T', '100']),                 # sixteen members per tile, two chunks of 256 utterances
     ('gru', 4, {}, ['--H', '512', '--T', '60', '--load', '--load-phase', 'bwd']),
-    ('lstm', 12, {}, []),
+    ('lstm', 8, {}, []),
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, ['--load']),
     ('lstm', 4, {'DEP_NUM_CUS': '200'}, []),
     ('lstm', 6, {'DEP_CLUSTER_NOFAST': '1'}, []),
@@ -92,8 +92,8 @@ def test_shared_gpu_mode_runs_the_tolerant_forward_and_passes_the_parity_suite()
     """DEP_EXCLUSIVE=0 (what dep_rnn_set_exclusive(0) selects after a fallback was noticed): the GRU part of the RNN-stack suite
     on the per-layer 32-unit-member forward, against the oracle."""
     e = dict(os.environ, DEP_EXCLUSIVE='0')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
-                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru and bf16x3',
+                        '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))      # (the exact-fp32 cases run the per-layer kernels in any mode)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
 
@@ -103,7 +103,7 @@ def test_per_layer_backward_sweeps_pass_the_kernel_parity_suite():
     DEP_FUSED2_BWD=0 selects the two per-layer sweeps + layer 1's dX GEMM it replaced, which stay parity-green: the GRU part of the
     RNN-stack suite against the oracle (the other shapes run the per-layer kernels in either mode)."""
     e = dict(os.environ, DEP_FUSED2_BWD='0')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru',
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_kernels_gpu.py'), '-q', '-x', '-k', 'rnn and gru and bf16x3',
                         '-p', 'no:cacheprovider'], env=e, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
