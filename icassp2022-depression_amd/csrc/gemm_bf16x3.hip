@@ -381,6 +381,156 @@ __global__ __launch_bounds__(NT, (BMT == 256 ? 2 : 3)) void gemm_bf16x3_tn_pair(
     else gemm_bf16x3_walk<true, false, VEC, BMT, 3, FA, FB>(p0, bid, nblk);
 }
 
+// Round 6: the weight-gradient contractions fed by LDS-DMA.   C[m][n] = sum_k A[k][m] B[k][n],  A = the sweeps' PK gate-gradient
+// image (M contiguous), B = fp32 rows (N contiguous, optionally the layer's own output shifted one step along its sequence).
+// The kernel above stages operands global -> registers -> (convert) -> LDS with one k-tile of register prefetch; its workgroups spend most of a k-tile
+// waiting for that one round trip (the loads alone cost 0.4 of cfg3's 1.06 ms).  Here
+//   * a 256 x 256 output tile, eight waves (2 x 4, each 128 x 64): a third fewer operand bytes per flop through L2 -> LDS than 256 x 128;
+//   * stages of 16 k-rows; every stage row of either operand is ONE `buffer_load_dwordx4 ... lds` (1 KiB, lane-linear): no staging registers, no
+//     conversion pass, no ds_write, and -- no destination registers -- no compiler-placed vmcnt wait: four stages in LDS (128 KiB), three in flight,
+//     counted `s_waitcnt vmcnt(8)` (never 0 in the loop), ONE workgroup barrier per slot;
+//   * A's fragments are four k-pair words of four consecutive PK rows (ds_read2_b32, conflict-free: a lane group reads 32 consecutive words);
+//     B's are eight fp32 of eight consecutive rows, split into (hi, lo) by the consuming wave exactly as the staging pass of the kernel above does;
+//   * the two wave groups (waves 0-3 / 4-7: one of each per SIMD) run ONE BARRIER apart: while one issues its 24 MFMAs the other reads and splits
+//     its fragments, so a SIMD's matrix pipe always has a wave feeding it.
+// Split-K chunks, the order of k inside a chunk, operand roles, the three products per 16 k and their order are those of the kernel above: the
+// partial sums -- and after the same reduce the weight gradients -- are bit-identical (tests/golden/device_bits.json).
+// A pair (dW_ih / dW_hh of a GRU layer: same A) runs as neighbouring slots of one XCD, like gemm_bf16x3_tn_pair.
+// Measured (tools/micro/gemm_tn_dma.hip, profiles/r06_s14_*): cfg2 pair 0.345 ms (shipped 0.41-0.42), cfg3 1024 x 1024 0.80 ms (1.06-1.14).
+__device__ unsigned g_dma_zero[256];               // a row of zeros: the source of a B row whose shifted step falls outside its sequence
+typedef __attribute__((address_space(3))) void* dma_ldsp;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int DM_BM = 256, DM_BN = 256, DM_SK = 16, DM_NTH = 512, DM_NST = 4;
+constexpr int DM_ROWW = 256, DM_STW = 2 * DM_SK * DM_ROWW, DM_PPW = 2 * DM_SK / 8;
+constexpr size_t DM_LDS_BYTES = (size_t)DM_NST * DM_STW * 4;
+
+__global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1, int np) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned dsm[];
+    constexpr int NST = DM_NST, SK = DM_SK, ROWW = DM_ROWW, STW = DM_STW, PPW = DM_PPW;
+    const int x8 = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int prob = np == 2 ? (slot & 1) : 0;
+    const GemmP& p = prob ? p1 : p0;
+    if (p.only_if && *p.only_if == 0) return;
+    const int gx = p.N / DM_BN, gy = p.M / DM_BM;
+    int t;
+    {
+        const int s2 = np == 2 ? (slot >> 1) : slot;
+        const int ntiles = gx * gy * p.splits;
+        const int q = ntiles / 8, r = ntiles % 8;
+        const int lo = x8 < r ? x8 * (q + 1) : r * (q + 1) + (x8 - r) * q;
+        const int hi = lo + (x8 < r ? q + 1 : q);
+        t = lo + s2;
+        if (t >= hi) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3, half = lane >> 5, l31 = lane & 31;
+    const int grp = wm;
+    const int bx = t % gx, by = (t / gx) % gy, bz = t / (gx * gy);
+    const int m0 = by * DM_BM, n0 = bx * DM_BN, kb = bz * p.kchunk, ke = min(p.K, kb + p.kchunk);
+    const int nst = (ke - kb) / SK;                // (the launcher checked: every chunk is a multiple of 16 rows)
+    const int mphys = m0 + ((p.skip_by && m0 >= p.skip_at) ? p.skip_by : 0);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xfffffff0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0xfffffff0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)g_dma_zero, 0, 1024u, 0x00020000);
+    // this wave's B rows of a stage are k0 + w and k0 + w + 8: their steps inside the sequence, carried along (no division in the loop)
+    int tt0 = 0, tt1 = 0;
+    if (p.seqT > 0) { tt0 = (kb + w) % p.seqT; tt1 = (kb + w + 8) % p.seqT; }
+    int issued = 0;                                // stages issued so far (they are issued in order)
+    auto issue = [&]() {
+        unsigned* base = dsm + (issued % NST) * STW;
+        const int k0 = kb + issued * SK;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const bool isA = q < SK / 8;           // compile-time: stage rows [0, 16) are A's, [16, 32) B's; wave w takes rows w, w + 8 of each
+            const int r = w + 8 * q;
+            unsigned* dst = base + r * ROWW;
+            if (isA) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (dma_ldsp)dst, 16, (unsigned)lane * 16u, ((unsigned)(k0 + r) * (unsigned)p.lda + (unsigned)mphys) * 4u, 0, 0);
+            } else {
+                const int kr = k0 + r - SK;
+                const int tt = (q == SK / 8 ? tt0 : tt1) + p.shiftB;
+                const bool ok = p.seqT <= 0 || (tt >= 0 && tt < p.seqT);
+                if (ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (dma_ldsp)dst, 16, (unsigned)lane * 16u, ((unsigned)(kr + p.shiftB) * (unsigned)p.ldb + (unsigned)n0) * 4u, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (dma_ldsp)dst, 16, (unsigned)lane * 16u, 0u, 0, 0);
+            }
+        }
+        if (p.seqT > 0) {
+            tt0 += SK; tt1 += SK;
+            while (tt0 >= p.seqT) tt0 -= p.seqT;
+            while (tt1 >= p.seqT) tt1 -= p.seqT;
+        }
+        ++issued;
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) if (st < nst) issue();
+    if (NST - 1 <= nst) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                  // stage 0 is complete
+    if (grp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
+    for (int it = 0; it < nst; ++it) {
+        const bool more = it + NST - 1 < nst;
+        if (more) issue();                         // stage it + 3, into the buffer of stage it - 1 (both groups finished reading it before the barrier in front of this slot)
+        const unsigned* sa = dsm + (it % NST) * STW;
+        const unsigned* sb = sa + SK * ROWW;
+        bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned* q0 = sa + (half * 8) * ROWW + wm * 128 + i * 32 + l31;
+            u32x4 h = {q0[0], q0[2 * ROWW], q0[4 * ROWW], q0[6 * ROWW]};
+            u32x4 l = {q0[ROWW], q0[3 * ROWW], q0[5 * ROWW], q0[7 * ROWW]};
+            ah[i] = __builtin_bit_cast(bf16x8, h); al[i] = __builtin_bit_cast(bf16x8, l);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* q0 = reinterpret_cast<const float*>(sb) + (half * 8) * ROWW + wn * 64 + j * 32 + l31;
+            f32x4 x0 = {q0[0], q0[ROWW], q0[2 * ROWW], q0[3 * ROWW]}, x1 = {q0[4 * ROWW], q0[5 * ROWW], q0[6 * ROWW], q0[7 * ROWW]};
+            bf16x4 h0, l0, h1, l1;
+            split4(x0, h0, l0); split4(x1, h1, l1);
+            bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        // every wave's pieces of stage it + 1 must have landed before the barrier in front of group 0's next read slot: group 1 is in its read slot then,
+        // group 0 in its MFMA slot
+        if (grp == 1) { if (more) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>(); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        // (b_hi a_lo), (b_lo a_hi), (b_hi a_hi) per accumulator, in that order -- the kernel above's; consecutive instructions go to different accumulators
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 1 ? bl[j] : bh[j], term == 0 ? al[i] : ah[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) { if (more) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>(); }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    float* outp = p.part + (size_t)bz * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 128 + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(outp + (size_t)m * p.N + n) = v;
+            }
+    }
+}
+
 // both problems' split-K partials in one launch (blockIdx.y = problem)
 __global__ void splitk_reduce2_pair(const float* __restrict__ part0, const float* __restrict__ part1, int splits, int M, int N,
                                     float* C0, int ldc0, float* C1, int ldc1) {
@@ -452,6 +602,22 @@ bool dep_gemm_bf16x3_pair_ok() {
     if (plain < 0) { const char* a = getenv("DEP_GEMM_ABLATE"); const char* b = getenv("DEP_GEMM_BM"); plain = ((a && atoi(a) != 0) || (b && atoi(b) == 128)) ? 0 : 1; }
     return plain && g_xcd_lo == 0 && g_xcd_n == 8;
 }
+// may this TN contraction (A = PK image, B = fp32 rows, split-K) take the LDS-DMA kernel?  DEP_GEMM_TN_DMA=0: the register-staged kernel everywhere.
+static bool tn_dma_ok(int M, int N, int K, int lda, int ldb, int splits, int kchunk, const float* part, int skip_at, int skip_by) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("DEP_GEMM_TN_DMA"); off = (e && e[0] == '0') ? 1 : 0; }
+    return !off && dep_gemm_bf16x3_pair_ok() && M % DM_BM == 0 && N % DM_BN == 0 && splits > 1 && part && kchunk % DM_SK == 0 && K % DM_SK == 0 &&
+           lda % 4 == 0 && ldb % 4 == 0 && (skip_by == 0 || skip_at % DM_BM == 0);
+}
+static int tn_dma_launch(const GemmP& p0, const GemmP& p1, int np, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_bf16x3_tn_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DM_LDS_BYTES); attr = true; }
+    const int ntiles = (p0.M / DM_BM) * (p0.N / DM_BN) * p0.splits;
+    const dim3 g((unsigned)((ntiles + 7) / 8 * 8 * np));
+    DEP_LAUNCH(gemm_bf16x3_tn_dma, g, dim3(DM_NTH), DM_LDS_BYTES, s, p0, p1, np);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
 extern "C" int dep_gemm_set_xcds(int lo, int n) { if (lo < 0 || n < 1 || lo + n > 8) return DEP_ERR_ARG; g_xcd_lo = lo; g_xcd_n = n; return DEP_OK; }
 
 // Same contract as dep_gemm_internal (gemm.hip); `splits` is decided by the caller's shared heuristic.
@@ -487,6 +653,15 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     const bool big = bm256 && M >= 512 && (!(!transA && transB) || (nt256 && K >= 512)) && !(fa != FMT_F32 && !transA && transB);
     const int BMT = big ? 256 : 128;
     GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl, dep_gemm_predicate(), g_xcd_lo, g_xcd_n, transA ? g_skip_at : 0, transA ? g_skip_by : 0};
+    if (transA && !transB && fa == FMT_PK && fb == FMT_F32 && terms == 3 && vec && !abl && tn_dma_ok(M, N, K, lda, ldb, splits, kchunk, part, p.skip_at, p.skip_by)) {
+        // Round 6: the weight-gradient contractions whose shape fits take the LDS-DMA kernel (bit-identical partial sums); the reduce below is shared
+        const int rc = tn_dma_launch(p, p, 1, s);
+        if (rc) return rc;
+        const long n = (long)M * N;
+        DEP_LAUNCH(splitk_reduce2, dim3(dep_cdiv(n, 256)), dim3(256), 0, s, dep_gemm_predicate(), part, splits, M, N, C, ldc, bias, beta);
+        DEP_CHECK_LAUNCH();
+        return DEP_OK;
+    }
     // persistent launch: at most `persist` workgroups (a multiple of 8: one share per XCD), each walks a list of tiles
     const int ntiles = p.gx * p.gy * splits;
     const int cap = big ? persist * 2 / 3 : persist;              // 2 resident workgroups per CU with 256-row tiles, 3 otherwise
@@ -549,6 +724,14 @@ int dep_gemm_bf16x3_tn_pair_launch(int M, int N, int K, const float* A0, const f
     GemmP p0{M, N, K, A0, lda, B0, ldb0, C0, ldc0, nullptr, 0.f, seq_T0, shift0, kchunk, splits, part0, dep_cdiv(N, BN), dep_cdiv(M, 256), 0, nullptr, 0, 8, 0, 0};
     GemmP p1 = p0;
     p1.A = A1; p1.B = B1; p1.ldb = ldb1; p1.C = C1; p1.ldc = ldc1; p1.seqT = seq_T1; p1.shiftB = shift1; p1.part = part1; p1.skip_at = skip_at1; p1.skip_by = skip_by1;
+    if (tn_dma_ok(M, N, K, lda, ldb0, splits, kchunk, part0, skip_at1, skip_by1) && ldb1 % 4 == 0) {
+        const int rc = tn_dma_launch(p0, p1, 2, s);
+        if (rc) return rc;
+        const long n = (long)M * N;
+        DEP_LAUNCH(splitk_reduce2_pair, dim3(dep_cdiv(n, 256), 2), dim3(256), 0, s, part0, part1, splits, M, N, C0, ldc0, C1, ldc1);
+        DEP_CHECK_LAUNCH();
+        return DEP_OK;
+    }
     const int ntiles = p0.gx * p0.gy * splits;
     const int cap = persist * 2 / 3 / 2;                          // two resident workgroups per CU with 256-row tiles, half of the slots per problem
     const int per_xcd = (ntiles + 7) / 8;
