@@ -231,6 +231,11 @@ bool make_layout(const dep_rnn_desc* d, Layout& lo) {
         const size_t b2 = 2 * dep_gemm_workspace_bytes(1, 0, (int)(G * H), (int)H, (int)lo.BT);
         if (b2 > gb) gb = b2;
     }
+    {   // ... and the forward's use of the same scratch: the stage image of a layer's (direction-stacked) W_ih (gemm_bf16x3_nt_dma)
+        const size_t mx = D * H > (size_t)d->F ? D * H : (size_t)d->F;
+        const size_t b3 = (size_t)D * G * H * mx * sizeof(float);
+        if (b3 > gb) gb = b3;
+    }
     lo.gemm = w; lo.gemm_bytes = gb; w += al(gb / sizeof(float) + 64);
     // impl: 0 auto (cluster > tile-MFMA > generic), 1 generic, 2 tile-MFMA, 3 cluster (must be supported)
     const bool cok = d->cell == DEP_CELL_GRU ? dep_cluster_ok(d->cell, d->H, d->B, d->dirs) : dep_cluster_lstm_ok(d->H, d->B, d->dirs);
@@ -402,7 +407,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             rc = dep_pack_cluster_split_multi(bwd_multi ? 5 : 3, srcs, dsts, kinds, H, s); if (rc) return rc;
         }
         float* gi = W + lo.gi;
-        rc = dep_gemm_internal(0, 1, BTr, G * H, d->F, x, d->F, w0[0], d->F, gi, G * H, w0[2], 0.f, 0, 0, nullptr, 0, s);
+        rc = dep_gemm_internal(0, 1, BTr, G * H, d->F, x, d->F, w0[0], d->F, gi, G * H, w0[2], 0.f, 0, 0, W + lo.gemm, lo.gemm_bytes, s);      // (scratch: the weight's stage image)
         if (rc) return rc;
         dep_fused2_args f{};
         f.B = B; f.T = T; f.training = d->training;
@@ -430,7 +435,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             if (l == 1) {
                 const float* in = lo.drop ? R + lo.ydrop[0] : R + lo.y[0];
                 dep_gemm_set_predicate(soft);
-                rc = dep_gemm_internal(0, 1, BTr, G * H, H, in, H, wl[0], H, gi, G * H, wl[2], 0.f, 0, 0, nullptr, 0, s);
+                rc = dep_gemm_internal(0, 1, BTr, G * H, H, in, H, wl[0], H, gi, G * H, wl[2], 0.f, 0, 0, W + lo.gemm, lo.gemm_bytes, s);
                 dep_gemm_set_predicate(nullptr);
                 if (rc) return rc;
             }
@@ -500,13 +505,13 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
                 bias = tb;
             }
             rc = dep_gemm_internal(0, 1, BTr, G * H, Kl, in, Kl, wl[0], Kl, gi + (size_t)dd * G * H, D * G * H, bias,
-                                   0.f, 0, 0, nullptr, 0, s);
+                                   0.f, 0, 0, W + lo.gemm, lo.gemm_bytes, s);
             if (rc) return rc;
             // the bias scratch is reused by the next direction: stream order keeps this safe
         }
         if (stacked) {
             rc = dep_gemm_internal(0, 1, BTr, D * G * H, Kl, in, Kl, R + lo.wstack[l], Kl, gi, D * G * H, R + lo.bstack[l],
-                                   0.f, 0, 0, nullptr, 0, s);
+                                   0.f, 0, 0, W + lo.gemm, lo.gemm_bytes, s);
             if (rc) return rc;
         }
         dep_sweep_args a{};

@@ -323,7 +323,7 @@ bool naive_forced() {
 // always exact.  Default: DEP_GEMM_MODE env ("f32" -> 0), else 1.
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
-                           int splits, int kchunk, float* part, bool vec, hipStream_t s, int terms);
+                           int splits, int kchunk, float* part, bool vec, hipStream_t s, int terms, void* ws, size_t ws_bytes);
 static std::atomic<int> g_split_mode{-1};            // process-global (documented in dep_rnn.h)
 static std::atomic<long> g_split_min_macs{1L << 28};
 static thread_local const unsigned* g_only_if = nullptr;
@@ -406,7 +406,7 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     init_split_mode();
     if (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs))
         return dep_gemm_bf16x3_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
-                                      splits, kchunk, p.part, vec, s, (g_force_exact != 2 && g_split_mode >= 2) ? 1 : 3);     // the public bf16x3 entry is always 3 terms
+                                      splits, kchunk, p.part, vec, s, (g_force_exact != 2 && g_split_mode >= 2) ? 1 : 3, ws, ws_bytes);     // the public bf16x3 entry is always 3 terms
 #define LAUNCH(TA, TB)                                                                    \
     do {                                                                                   \
         if (vec) DEP_LAUNCH((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \

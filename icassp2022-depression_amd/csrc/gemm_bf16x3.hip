@@ -531,6 +531,161 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
     }
 }
 
+// Round 6: the NT projections  C[m][n] = sum_k X[m][k] W[n][k] + bias[n]  (the layers' input projections) fed by LDS-DMA.
+//   X : fp32 rows (K contiguous); a wave owns 32 rows x ALL 256 columns of the tile, so every element of X is split into (hi, lo) by exactly one wave
+//       (the split of the staging pass above, same bits).  A stage row is 64 bytes: a DMA piece is 16 rows x 64 B, and the 16-byte chunk a lane
+//       fetches is XOR-swizzled through the SOURCE address (chunk ^ (row >> 2) & 3) -- the LDS image is lane-linear -- so that the b128 fragment reads of
+//       32 consecutive rows are conflict-free.
+//   W : pre-split once per call into a STAGE IMAGE (pack_w_stage_image): per 256-column tile and 16-k stage one contiguous 16 KiB block that IS the LDS
+//       image, [plane hi / lo][k octet][256 n] x 8 bf16: its DMA pieces are contiguous 1 KiB reads, its fragment reads conflict-free b128, nothing to convert.
+// 128 x 256 tiles, four waves, three 24 KiB stages, counted vmcnt, one barrier per stage; TWO such workgroups per CU (2 x 76 KiB LDS) desynchronise by
+// themselves: one's write-out runs beside the other's MFMAs.  Persistent over an XCD-contiguous tile list ((tile, stage) is one iteration space: the next
+// tile's first stages are in flight during this tile's last; the write-out's stores drain behind the next tile's MFMAs -- the counted vmcnt allows for them).
+// Per element: k ascending, (w_hi x_lo), (w_lo x_hi), (w_hi x_hi) per 16 k, bias added to the finished sum -- the kernel above's sequence.
+// The MFMA takes X as its first operand (a lane then owns one COLUMN and 16 rows: a store instruction writes 2 rows x 128 contiguous bytes -- full lines;
+// with W first a lane's 16-byte stores touch 32 rows x 32 bytes per instruction and the write-out, which bounds the K = 256 projections, is a third slower).
+// Measured (tools/micro/gemm_nt_dma.hip, profiles/r06_s17_*): cfg2 0.24 ms (kernel above 0.29-0.33), cfg3 layer 0 0.85 (1.08-1.16), layer 1 0.31 (0.39).
+constexpr int NTD_TH = 256, NTD_NST = 3, NTD_STW = 2048 + 4096, NTD_PPW = 6, NTD_SK = 16, NTD_BM = 128, NTD_BN = 256, NTD_MAXN = 1024;
+constexpr size_t NTD_LDS_BYTES = (size_t)NTD_NST * NTD_STW * 4 + NTD_MAXN * 4;
+
+struct NtdP {
+    const float* X; int ldx;
+    const unsigned* Wimg;         // [N / 256][K / 16][4096 words]
+    const float* bias;
+    float* C; int ldc;
+    int M, N, K, gx;
+    const unsigned* only_if;
+};
+
+__global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
+    if (p.only_if && *p.only_if == 0) return;
+    extern __shared__ __attribute__((aligned(1024))) unsigned dsm[];
+    constexpr int NST = NTD_NST, STW = NTD_STW, PPW = NTD_PPW, SK = NTD_SK;
+    float* bias_l = reinterpret_cast<float*>(dsm + NST * STW);
+    const int x8 = blockIdx.x & 7, slot = blockIdx.x >> 3, SL = gridDim.x >> 3;
+    int lo, hi;
+    {
+        const int ntiles = p.gx * (p.M / NTD_BM);
+        const int q = ntiles / 8, r = ntiles % 8;
+        lo = x8 < r ? x8 * (q + 1) : r * (q + 1) + (x8 - r) * q;
+        hi = lo + (x8 < r ? q + 1 : q);
+    }
+    if (lo + slot >= hi) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nst = p.K / SK;
+    for (int i = tid; i < p.N; i += NTD_TH) bias_l[i] = p.bias ? p.bias[i] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, 0xfffffff0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wimg, 0, 0xfffffff0u, 0x00020000);
+    // X piece q (0 / 1) of wave w: rows 32 w + 16 q + lane / 4; LDS chunk position lane % 4 holds the row's chunk (lane % 4) ^ ((row >> 2) & 3)
+    unsigned xrel[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = 32 * w + 16 * q + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        xrel[q] = ((unsigned)row * (unsigned)p.ldx) * 4u + (unsigned)c * 16u;
+    }
+    // issue side of the (tile, stage) space
+    int ti = lo + slot, si = 0, icount = 0;
+    bool iv = true;
+    unsigned ixoff = (unsigned)(ti / p.gx) * (unsigned)NTD_BM * (unsigned)p.ldx * 4u, iwoff = (unsigned)(ti % p.gx) * (unsigned)nst * 16384u;
+    auto issue = [&]() {
+        unsigned* base = dsm + (icount % NST) * STW;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (dma_ldsp)(base + (32 * w + 16 * q) * 16), 16, xrel[q], ixoff + (unsigned)si * 64u, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (dma_ldsp)(base + 2048 + (w * 4 + q) * 256), 16, (unsigned)lane * 16u, iwoff + (unsigned)si * 16384u + (unsigned)(w * 4 + q) * 1024u, 0, 0);
+        ++icount;
+        if (++si == nst) {
+            si = 0; ti += SL; iv = ti < hi;
+            if (iv) { ixoff = (unsigned)(ti / p.gx) * (unsigned)NTD_BM * (unsigned)p.ldx * 4u; iwoff = (unsigned)(ti % p.gx) * (unsigned)nst * 16384u; }
+        }
+    };
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) if (iv) issue();
+    const int xrow = 32 * w + l31;
+    const int xs = (xrow >> 2) & 3;
+    const int xp0 = xrow * 16 + (((2 * half) ^ xs) << 2), xp1 = xrow * 16 + (((2 * half + 1) ^ xs) << 2);      // word offsets of the lane's two chunks inside a stage
+    int tc = lo + slot, sc = 0, ccount = 0, since = 100;
+    while (tc < hi) {
+        // this wave's pieces of the stage about to be read have landed: one younger stage of its own may still be in flight -- and, in the first wait behind a
+        // write-out, that tile's 128 stores (issued after the pieces waited for); vmcnt counts at most 63: 6 + 57 lets most of them stay in flight
+        ++since;
+        if (icount <= ccount + 1) wait_vm<0>();
+        else if (since == 1 || since == 2) wait_vm<PPW + 57>();      // (both stages waited for here were issued in front of the write-out)
+        else wait_vm<PPW>();
+        __builtin_amdgcn_s_barrier();              // everybody's pieces landed; everybody finished reading the stage before
+        if (iv) issue();                           // into the buffer of the stage before
+        const unsigned* sx = dsm + (ccount % NST) * STW;
+        const unsigned* sw = sx + 2048;
+        bf16x8 ah, al, bh[8], bl[8];
+        {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(sx + xp0), x1 = *reinterpret_cast<const f32x4*>(sx + xp1);
+            bf16x4 h0, l0, h1, l1;
+            split4(x0, h0, l0); split4(x1, h1, l1);
+            ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bh[j] = *reinterpret_cast<const bf16x8*>(sw + ((0 * 2 + half) * 256 + j * 32 + l31) * 4);
+            bl[j] = *reinterpret_cast<const bf16x8*>(sw + ((1 * 2 + half) * 256 + j * 32 + l31) * 4);
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 0 ? al : ah, term == 1 ? bl[j] : bh[j], acc[j], 0, 0, 0);
+        if (sc == nst - 1) {                       // the tile is complete: write it out, start the next from zero
+            // lane owns column n = j*32 + l31; register 4 g + e holds row 8 g + 4 half + e
+            const int n0 = (tc % p.gx) * NTD_BN, mb = (tc / p.gx) * NTD_BM + 32 * w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + j * 32 + l31;
+                const float bv = bias_l[n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + 8 * (r >> 2) + 4 * half + (r & 3);
+                    p.C[(size_t)m * p.ldc + n] = acc[j][r] + bv;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+            since = 0;
+        }
+        ++ccount;
+        if (++sc == nst) { sc = 0; tc += SL; }
+    }
+}
+
+// W (N x K fp32, row stride ldw) -> the stage image: block (n tile, stage) = [plane][k octet][256 n] x 8 bf16
+__global__ void pack_w_stage_image(const float* W, int ldw, int N, int K, unsigned* img) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one (n, k octet)
+    const int oct = K / 8;
+    if (i >= (long)N * oct) return;
+    const int n = (int)(i / oct), o = (int)(i % oct);
+    const float* src = W + (size_t)n * ldw + o * 8;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+    bf16x4 h0, l0, h1, l1;
+    split4(x0, h0, l0); split4(x1, h1, l1);
+    const int ntile = n >> 8, nn = n & 255, stage = o >> 1, half = o & 1;
+    unsigned* blk = img + ((size_t)ntile * (K / 16) + stage) * 4096;
+    const u32x2v a = __builtin_bit_cast(u32x2v, h0), b = __builtin_bit_cast(u32x2v, h1), c = __builtin_bit_cast(u32x2v, l0), d = __builtin_bit_cast(u32x2v, l1);
+    u32x4 hv = {a[0], a[1], b[0], b[1]}, lv = {c[0], c[1], d[0], d[1]};
+    *reinterpret_cast<u32x4*>(blk + ((0 * 2 + half) * 256 + nn) * 4) = hv;
+    *reinterpret_cast<u32x4*>(blk + ((1 * 2 + half) * 256 + nn) * 4) = lv;
+}
+
 // both problems' split-K partials in one launch (blockIdx.y = problem)
 __global__ void splitk_reduce2_pair(const float* __restrict__ part0, const float* __restrict__ part1, int splits, int M, int N,
                                     float* C0, int ldc0, float* C1, int ldc1) {
@@ -618,12 +773,34 @@ static int tn_dma_launch(const GemmP& p0, const GemmP& p1, int np, hipStream_t s
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
+// may this NT projection take the LDS-DMA kernel?  `ws` holds the weight's stage image.  DEP_GEMM_NT_DMA=0: the register-staged kernel everywhere.
+static bool nt_dma_ok(int M, int N, int K, int lda, int ldb, int ldc, const float* A, const float* B, const float* C, const float* bias, float beta, int splits,
+                      void* ws, size_t ws_bytes) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("DEP_GEMM_NT_DMA"); off = (e && e[0] == '0') ? 1 : 0; }
+    auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    return !off && dep_gemm_bf16x3_pair_ok() && M % NTD_BM == 0 && N % NTD_BN == 0 && N <= NTD_MAXN && K % NTD_SK == 0 && K >= 3 * NTD_SK && splits == 1 && beta == 0.f &&
+           lda % 4 == 0 && ldb % 4 == 0 && a16(A) && a16(B) && C && ws && a16(ws) && ws_bytes >= (size_t)N * K * 4 && dep_gemm_predicate() == nullptr &&
+           (size_t)M * lda * 4 < 0xfffffff0ull;
+}
+static int nt_dma_launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, void* ws, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_bf16x3_nt_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTD_LDS_BYTES); attr = true; }
+    DEP_LAUNCH(pack_w_stage_image, dim3((unsigned)dep_cdiv((long)N * (K / 8), 256)), dim3(256), 0, s, B, ldb, N, K, (unsigned*)ws);
+    DEP_CHECK_LAUNCH();
+    NtdP p{A, lda, (const unsigned*)ws, bias, C, ldc, M, N, K, N / NTD_BN, dep_gemm_predicate()};
+    const int per_xcd = dep_cdiv((M / NTD_BM) * p.gx, 8);
+    const dim3 g((unsigned)((per_xcd < 64 ? per_xcd : 64) * 8));      // two resident workgroups per CU, 32 CUs per XCD
+    DEP_LAUNCH(gemm_bf16x3_nt_dma, g, dim3(NTD_TH), NTD_LDS_BYTES, s, p);
+    DEP_CHECK_LAUNCH();
+    return DEP_OK;
+}
 extern "C" int dep_gemm_set_xcds(int lo, int n) { if (lo < 0 || n < 1 || lo + n > 8) return DEP_ERR_ARG; g_xcd_lo = lo; g_xcd_n = n; return DEP_OK; }
 
 // Same contract as dep_gemm_internal (gemm.hip); `splits` is decided by the caller's shared heuristic.
 int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, float beta, int seq_T, int shiftB,
-                           int splits, int kchunk, float* part, bool vec, hipStream_t s, int terms) {
+                           int splits, int kchunk, float* part, bool vec, hipStream_t s, int terms, void* ws, size_t ws_bytes) {
     static int abl = -1, persist = -1, bm256 = -1;
     // (32-bit lane offsets: every operand must span less than 4 GB)
     const size_t spanA = (size_t)(transA ? K : M) * lda * 4, spanB = (size_t)(transB ? N : K) * ldb * 4;
@@ -653,6 +830,9 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     const bool big = bm256 && M >= 512 && (!(!transA && transB) || (nt256 && K >= 512)) && !(fa != FMT_F32 && !transA && transB);
     const int BMT = big ? 256 : 128;
     GemmP p{M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB, kchunk, splits, part, dep_cdiv(N, BN), dep_cdiv(M, BMT), abl, dep_gemm_predicate(), g_xcd_lo, g_xcd_n, transA ? g_skip_at : 0, transA ? g_skip_by : 0};
+    if (!transA && transB && fa == FMT_F32 && fb == FMT_F32 && terms == 3 && vec && !abl && seq_T <= 0 &&
+        nt_dma_ok(M, N, K, lda, ldb, ldc, A, B, C, bias, beta, splits, ws, ws_bytes))
+        return nt_dma_launch(M, N, K, A, lda, B, ldb, C, ldc, bias, ws, s);      // Round 6: the input projections whose shape fits take the LDS-DMA kernel
     if (transA && !transB && fa == FMT_PK && fb == FMT_F32 && terms == 3 && vec && !abl && tn_dma_ok(M, N, K, lda, ldb, splits, kchunk, part, p.skip_at, p.skip_by)) {
         // Round 6: the weight-gradient contractions whose shape fits take the LDS-DMA kernel (bit-identical partial sums); the reduce below is shared
         const int rc = tn_dma_launch(p, p, 1, s);
