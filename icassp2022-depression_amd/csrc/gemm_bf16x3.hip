@@ -578,6 +578,7 @@ __global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, 0xfffffff0u, 0x00020000);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wimg, 0, 0xfffffff0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0xfffffff0u, 0x00020000);
     // X piece q (0 / 1) of wave w: rows 32 w + 16 q + lane / 4; LDS chunk position lane % 4 holds the row's chunk (lane % 4) ^ ((row >> 2) & 3)
     unsigned xrel[2];
 #pragma unroll
@@ -654,7 +655,8 @@ __global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + 8 * (r >> 2) + 4 * half + (r & 3);
-                    p.C[(size_t)m * p.ldc + n] = acc[j][r] + bv;
+                    // non-temporal: the projection is read once, by the next kernel, long after it has left this L2 (A/B: -6 ... -8 % on the K = 256 projections)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r] + bv), rc, ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u, 0, 2 /* nt */);
                 }
             }
 #pragma unroll
@@ -781,7 +783,7 @@ static bool nt_dma_ok(int M, int N, int K, int lda, int ldb, int ldc, const floa
     auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     return !off && dep_gemm_bf16x3_pair_ok() && M % NTD_BM == 0 && N % NTD_BN == 0 && N <= NTD_MAXN && K % NTD_SK == 0 && K >= 3 * NTD_SK && splits == 1 && beta == 0.f &&
            lda % 4 == 0 && ldb % 4 == 0 && a16(A) && a16(B) && C && ws && a16(ws) && ws_bytes >= (size_t)N * K * 4 && dep_gemm_predicate() == nullptr &&
-           (size_t)M * lda * 4 < 0xfffffff0ull;
+           (size_t)M * lda * 4 < 0xfffffff0ull && (size_t)M * ldc * 4 < 0xfffffff0ull;
 }
 static int nt_dma_launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, void* ws, hipStream_t s) {
     static bool attr = false;

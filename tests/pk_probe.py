@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from icassp2022_depression_amd import _lib as L  # noqa: E402
 
 def run_case(out, B, T, F, flags):
+    if os.environ.get('PROBE_INSTANCES'):
+        L.instance_log_enable(True)
     want_dx = 'dx' in flags
     nody = 'nody' in flags                 # GRU: the training step's call form (dpooled only; AudioBiLSTM.backward) -> the HASDY = false instances
     lstm = 'lstm' in flags                 # the BiLSTM-128 x2 stack of the text model instead of the GRU-256 x2 one
@@ -42,6 +44,8 @@ def run_case(out, B, T, F, flags):
     rnn.check()
     torch.cuda.synchronize()
     res = {'g%d' % i: t.cpu().numpy() for i, t in enumerate(Gd)}
+    if os.environ.get('PROBE_INSTANCES'):              # which kernel template instances the case launched (dep_instance_log_*)
+        res['instances'] = np.array(sorted(L.instance_log_read(reset=True)))
     if lstm:
         res['h_n'] = h_n.cpu().numpy()
     else:

@@ -93,6 +93,32 @@ def test_gemm_bf16_products_mode_has_its_own_tolerance(tA, tB, M, N, K):
     assert (np.abs(host(c) - ref) / scale).max() < 1.5e-5          # and the default mode is back
 
 
+# Round 6: with scratch for the weight's stage image the three-term NT projection takes the LDS-DMA kernel (gemm_bf16x3_nt_dma: M % 128 == 0,
+# N % 256 == 0, N <= 1024, K % 16 == 0, K >= 48); without scratch the register-staged kernel runs.  Same products in the same order: bit-identical --
+# and both inside the split's error bound against the float64 product.  Row-strided operands and outputs (lda > K, ldc > N), no bias, the K minimum.
+@pytest.mark.parametrize('M,N,K,lda,ldc,bias', [(1280, 768, 256, 256, 768, True), (2560, 1024, 1024, 1024, 1024, True), (4096, 256, 48, 64, 260, False),
+                                                (2048, 512, 1040, 1040, 512, True), (33024, 768, 256, 260, 768, True)])
+def test_nt_projection_fed_by_lds_dma_is_bit_identical_to_the_staged_kernel(M, N, K, lda, ldc, bias):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, lda)).astype(np.float32); B = (rng.standard_normal((N, K)) * K ** -0.5).astype(np.float32)
+    bv = rng.standard_normal(N).astype(np.float32)
+    a, b, bi = dev(A), dev(B), (dev(bv) if bias else None)
+    c0 = torch.full((M, ldc), 7.0, device=DEV); c1 = torch.full((M, ldc), 7.0, device=DEV)
+    L.gemm_split(0, 1, M, N, K, a, lda, b, K, c0, ldc, bias=bi)                                   # no scratch: the register-staged kernel
+    i0 = ' '.join(L.instance_log_read())                                                          # (conftest.py switched the launch-instance log on for this test)
+    ws = torch.empty(N * K + 64, device=DEV)
+    L.gemm_split(0, 1, M, N, K, a, lda, b, K, c1, ldc, bias=bi, ws=ws)
+    i1 = ' '.join(L.instance_log_read())
+    assert 'nt_dma' not in i0 and 'gemm_bf16x3_nt_dma' in i1, (i0, i1)
+    assert torch.equal(c0, c1)
+    if ldc > N:
+        assert bool((c1[:, N:] == 7.0).all())                                                    # nothing written beside the tile
+    A64 = A[:, :K].astype(np.float64); B64 = B.astype(np.float64)
+    ref = A64 @ B64.T + (bv.astype(np.float64) if bias else 0.0)
+    scale = np.abs(A64) @ np.abs(B64).T
+    assert (np.abs(host(c1[:, :N]) - ref) / scale).max() < 1.5e-5
+
+
 def test_gemm_bf16x3_shift_and_splitk_match_exact_kernel():
     rng = np.random.default_rng(15)
     Bsz, T, M, N = 9, 300, 96, 64

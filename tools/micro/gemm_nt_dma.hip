@@ -51,7 +51,7 @@ struct P {
     const unsigned* Wimg;         // [N / 256][K / 16][4096 words]
     const float* bias;
     float* C; int ldc;
-    int M, N, K, gx, gy;
+    int M, N, K, gx, gy, nt;
 };
 
 // persistent: a workgroup walks the tiles lo + slot, lo + slot + SL, .. of its XCD's share; (tile, stage) is ONE iteration space, so the first stages of
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(NTH2, 2) void nt_dma2(P p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, 0xfffffff0u, 0x00020000);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wimg, 0, 0xfffffff0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0xfffffff0u, 0x00020000);
     unsigned xrel[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(NTH2, 2) void nt_dma2(P p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = mb + 8 * (r >> 2) + 4 * half + (r & 3);
-                        p.C[(size_t)m * p.ldc + n] = acc[j][r] + bv;
+                        if (p.nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r] + bv), rc, ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u, 0, 2 /* nt */);
+                        else p.C[(size_t)m * p.ldc + n] = acc[j][r] + bv;
                     }
                 }
             } else {
@@ -369,7 +371,8 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
     const double flops = 2.0 * M * N * (double)K;
     printf("pack + projection %.4f ms = %.0f TFLOP/s of products (x3) = %.0f TFLOP/s fp32-equivalent\n", ms, 3 * flops / ms / 1e9, flops / ms / 1e9);
-    for (int sw = 1; sw >= 0; --sw) {
+    for (int sw = 2; sw >= 0; --sw) {
+        p.nt = sw == 2;
         const size_t lds2 = (size_t)NST2 * STW2 * 4 + 4096;
         CK(hipFuncSetAttribute((const void*)nt_dma2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         CK(hipFuncSetAttribute((const void*)nt_dma2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -385,7 +388,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 20; ++i) once2();
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms2; CK(hipEventElapsedTime(&ms2, e0, e1)); ms2 /= 20;
-        printf("v2 (128 x 256 tiles, two workgroups per CU%s): pack + projection %.4f ms = %.0f TFLOP/s of products\n", sw ? ", roles swapped: dword stores of full lines" : "", ms2, 3 * flops / ms2 / 1e9);
+        printf("v2 (128 x 256 tiles, two workgroups per CU%s): pack + projection %.4f ms = %.0f TFLOP/s of products\n", sw == 2 ? ", roles swapped, nt stores" : (sw ? ", roles swapped: dword stores of full lines" : ""), ms2, 3 * flops / ms2 / 1e9);
     }
     const int cnt = 256; std::vector<int> hm(cnt), hn(cnt);
     for (int i = 0; i < cnt; ++i) { hm[i] = (int)(((long)i * 7919 + 13) % M); hn[i] = (i * 101 + 3) % N; }

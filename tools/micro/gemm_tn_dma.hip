@@ -259,6 +259,144 @@ __global__ __launch_bounds__(NTH) void tn_dma_pp(P p) {
     }
 }
 
+// v2: as v1, but a stage's four DMA pieces are issued BETWEEN the MFMAs of the wave's MFMA slot (an LDS-DMA piece costs 100-185 cycles of issue in a slot
+// that is busy with ds_reads and VALU, ~60 among bare MFMAs whose execution hides it), not at the head of its read slot.
+template <int NST, int HEADQ>
+__global__ __launch_bounds__(NTH) void tn_dma_pp2(P p, long long* trace) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned smem[];
+    constexpr int SK = 16, ROWW = 256, STW = 2 * SK * ROWW, PPW = 2 * SK / 8;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3, half = lane >> 5, l31 = lane & 31;
+    const int grp = wm;
+    int prob, t;
+    if (!map_block(p, prob, t)) return;
+    const int bx = t % p.gx, by = (t / p.gx) % p.gy, bz = t / (p.gx * p.gy);
+    const int m0 = by * BM, n0 = bx * BN, kb = bz * p.kchunk, ke = min(p.K, kb + p.kchunk);
+    const int nst = (ke - kb) / SK;
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xfffffff0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(prob ? p.B1 : p.B), 0, 0xfffffff0u, 0x00020000);
+    auto piece = [&](int st, int q) {
+        unsigned* base = smem + (st % NST) * STW;
+        const int k0 = kb + st * SK;
+        const bool isA = q < SK / 8;
+        const int r = w + 8 * q;
+        const int kr = k0 + (isA ? r : r - SK);
+        unsigned* dst = base + r * ROWW;
+        if (isA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (ldsp)dst, 16, (unsigned)lane * 16u, ((unsigned)kr * (unsigned)p.lda + (unsigned)m0) * 4u, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (ldsp)dst, 16, (unsigned)lane * 16u, ((unsigned)kr * (unsigned)p.ldb + (unsigned)n0) * 4u, 0, 0);
+    };
+    auto issue = [&](int st) {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) piece(st, q);
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) if (st < nst) issue(st);
+    if (NST - 1 <= nst) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                  // stage 0 is complete
+    if (grp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
+    long long ts[5] = {0, 0, 0, 0, 0}; long long acc_t[4] = {0, 0, 0, 0};
+#define STAMP(i) do { if (trace) ts[i] = (long long)__builtin_readcyclecounter(); } while (0)
+    for (int it = 0; it < nst; ++it) {
+        const bool more = it + NST - 1 < nst;
+        STAMP(0);
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < HEADQ; ++q) piece(it + NST - 1, q);      // the first HEADQ pieces of stage it + 3 at the head of the read slot, the rest among the MFMAs
+        }
+        const unsigned* sa = smem + (it % NST) * STW;
+        const unsigned* sb = sa + SK * ROWW;
+        bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned* q0 = sa + (half * 8) * ROWW + wm * 128 + i * 32 + l31;
+            u32x4 h = {q0[0], q0[2 * ROWW], q0[4 * ROWW], q0[6 * ROWW]};
+            u32x4 l = {q0[ROWW], q0[3 * ROWW], q0[5 * ROWW], q0[7 * ROWW]};
+            ah[i] = __builtin_bit_cast(bf16x8, h); al[i] = __builtin_bit_cast(bf16x8, l);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* q0 = reinterpret_cast<const float*>(sb) + (half * 8) * ROWW + wn * 64 + j * 32 + l31;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = q0[e * ROWW];
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2v v = {x[2 * e], x[2 * e + 1]};
+                hw[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+                const f32x2v d = {x[2 * e] - __uint_as_float(hw[e] << 16), x[2 * e + 1] - __uint_as_float(hw[e] & 0xffff0000u)};
+                lw[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2v));
+            }
+            u32x4 h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
+            bh[j] = __builtin_bit_cast(bf16x8, h); bl[j] = __builtin_bit_cast(bf16x8, l);
+        }
+        // every wave's pieces of stage it + 1 must have landed before the barrier in front of group 0's next read slot: group 1 is in its read slot then,
+        // group 0 in its MFMA slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STAMP(1);
+        if (grp == 1) { if (it + NST - 2 < nst) wait_vm<(NST - 3) * PPW + HEADQ>(); else wait_vm<0>(); }      // (stage it + 3: HEADQ pieces so far)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        STAMP(2);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 1 ? bl[j] : bh[j], term == 0 ? al[i] : ah[i], acc[i][j], 0, 0, 0);
+                if (i == 1 || i == 3) {
+                    const int q = HEADQ + term * 2 + (i >> 1);
+                    if (q < PPW && more) piece(it + NST - 1, q);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+        STAMP(3);
+        if (grp == 0) { if (more) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>(); }
+        __builtin_amdgcn_s_barrier();
+        STAMP(4);
+        if (trace && it >= 50 && it < 150) { for (int q = 0; q < 4; ++q) acc_t[q] += ts[q + 1] - ts[q]; }
+    }
+    if (trace && blockIdx.x == 0 && (tid == 0 || tid == 256)) { for (int q = 0; q < 4; ++q) trace[(tid >> 8) * 4 + q] = acc_t[q]; }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    float* outp = (prob ? p.part1 : p.part) + (size_t)bz * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 128 + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(outp + (size_t)m * p.N + n) = v;
+            }
+    }
+}
+
+template <int NST, int HEADQ>
+static float run_pp2(const P& p, int reps) {
+    const size_t lds = (size_t)NST * 2 * 16 * 256 * 4;
+    CK(hipFuncSetAttribute((const void*)tn_dma_pp2<NST, HEADQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 g((unsigned)((p.gx * p.gy * p.splits + 7) / 8 * 8 * (p.pair ? 2 : 1)));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((tn_dma_pp2<NST, HEADQ>), g, dim3(NTH), lds, 0, p, (long long*)nullptr);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((tn_dma_pp2<NST, HEADQ>), g, dim3(NTH), lds, 0, p, (long long*)nullptr);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
 template <int NST>
 static float run_pp(const P& p, int reps) {
     const size_t lds = (size_t)NST * 2 * 16 * 256 * 4;
@@ -351,10 +489,23 @@ int main(int argc, char** argv) {
     }
     printf("TN %d x %d, K = %d, splits %d (k chunk %d), %d workgroups of 512\n", M, N, K, p.splits, p.kchunk, p.gx * p.gy * p.splits);
     const double flops = 2.0 * M * N * (double)K * (p.pair ? 2 : 1);
-    struct { const char* name; float ms; } res[7];
+    struct { const char* name; float ms; } res[9];
     res[4] = {"ping-pong, 3 stages", run_pp<3>(p, 20)};
     res[5] = {"ping-pong, 5 stages", run_pp<5>(p, 20)};
     res[6] = {"ping-pong, 4 stages", run_pp<4>(p, 20)};
+    res[7] = {"ping-pong, 4 stages, 2 pieces at the head", run_pp2<4, 2>(p, 20)};
+    res[8] = {"ping-pong, 4 stages, DMA among the MFMAs", run_pp2<4, 0>(p, 20)};
+    {
+        long long* tr; CK(hipMalloc(&tr, 64)); CK(hipMemset(tr, 0, 64));
+        const size_t lds = (size_t)4 * 2 * 16 * 256 * 4;
+        const dim3 g((unsigned)((p.gx * p.gy * p.splits + 7) / 8 * 8 * (p.pair ? 2 : 1)));
+        hipLaunchKernelGGL((tn_dma_pp2<4, 2>), g, dim3(NTH), lds, 0, p, tr);
+        CK(hipDeviceSynchronize());
+        long long h[8]; CK(hipMemcpy(h, tr, 64, hipMemcpyDeviceToHost));
+        for (int gq = 0; gq < 2; ++gq)
+            printf("trace, group %d wave (ticks per stage, stages 50-149): issue + fragment reads + split %lld | vmcnt + barrier %lld | 24 MFMAs (+ DMA issue) %lld | vmcnt + barrier %lld\n",
+                   gq, h[gq * 4] / 100, h[gq * 4 + 1] / 100, h[gq * 4 + 2] / 100, h[gq * 4 + 3] / 100);
+    }
     // check this variant
     reduce_parts<<<(unsigned)(((long)M * N + 255) / 256), 256>>>(part, p.splits, (long)M * N, C);
     const int cnt = 64; std::vector<int> hm(cnt), hn(cnt);
@@ -371,6 +522,6 @@ int main(int argc, char** argv) {
     res[1] = {"16 rows x 3 stages", run<16, 3>(p, 20)};
     res[2] = {"32 rows x 2 stages", run<32, 2>(p, 20)};
     res[3] = {"16 rows x 2 stages", run<16, 2>(p, 20)};
-    for (auto& r : res) printf("%-20s %.4f ms = %.0f TFLOP/s of products (x3) = %.0f TFLOP/s fp32-equivalent\n", r.name, r.ms, 3 * flops / r.ms / 1e9, flops / r.ms / 1e9);
+    for (auto& r : res) printf("%-42s %.4f ms = %.0f TFLOP/s of products (x3) = %.0f TFLOP/s fp32-equivalent\n", r.name, r.ms, 3 * flops / r.ms / 1e9, flops / r.ms / 1e9);
     return 0;
 }
