@@ -62,10 +62,9 @@ def test_pk_gate_gradients_of_the_bilstm_stack_are_bit_identical_too(tmp_path, B
 # Round 6: the weight-gradient contractions (gemm_bf16x3_tn_dma) and the input projections (gemm_bf16x3_nt_dma) are fed by LDS-DMA where the shape
 # fits (256 x 256 / 128 x 256 tiles, K chunks of 16 rows).  Same K chunks, same order of k, same three products per 16 k in the same order: every output
 # and every gradient bit-identical to the register-staged kernels (DEP_GEMM_TN_DMA=0 DEP_GEMM_NT_DMA=0) -- and the DMA kernels must really have run.
-# (the projection kernel wants B T % 128 == 0, the weight-gradient kernel a split-K contraction, i.e. B T >= 1024 with a multiple of 16 rows: the last
-# case of each stack is below that and takes the projection kernel only)
-@pytest.mark.parametrize('B,T,F,dx,nody,lstm,tn', [(512, 300, 256, False, True, False, True), (384, 24, 256, True, False, False, True), (48, 16, 256, False, True, False, False),
-                                                   (512, 300, 1024, False, False, True, True), (32, 8, 1024, True, False, True, False)])
+# (the projection kernel wants B T % 128 == 0 and an unsplit contraction, the weight-gradient kernel a split-K one with chunks of 16 rows)
+@pytest.mark.parametrize('B,T,F,dx,nody,lstm,tn', [(512, 300, 256, False, True, False, True), (384, 24, 256, True, False, False, True), (64, 32, 256, False, True, False, True),
+                                                   (512, 300, 1024, False, False, True, True), (128, 32, 1024, True, False, True, True)])
 def test_dma_fed_contractions_leave_every_output_and_gradient_bit_identical(tmp_path, B, T, F, dx, nody, lstm, tn):
     a = _run(tmp_path, 'a', 1, B, T, F, dx, lstm=lstm, env={'DEP_GEMM_TN_DMA': '0', 'DEP_GEMM_NT_DMA': '0', 'PROBE_INSTANCES': '1'}, nody=nody)
     b = _run(tmp_path, 'b', 1, B, T, F, dx, lstm=lstm, env={'PROBE_INSTANCES': '1'}, nody=nody)
