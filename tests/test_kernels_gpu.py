@@ -119,6 +119,44 @@ def test_nt_projection_fed_by_lds_dma_is_bit_identical_to_the_staged_kernel(M, N
     assert (np.abs(host(c1[:, :N]) - ref) / scale).max() < 1.5e-5
 
 
+def test_dma_fed_contractions_repeat_bit_for_bit():
+    """The LDS-DMA kernels order their stage reads by counted vmcnt waits and barriers only: a misplaced count shows up as a RARE wrong tile.  The projection
+    (cfg2's shape) 40 times and the GRU stack's backward (weight-gradient pairs over the PK image) 12 times on the same inputs: every repeat bit-identical."""
+    rng = np.random.default_rng(3)
+    M, N, K = 153600, 768, 256
+    a = torch.randn(M, K, device=DEV); b = dev(rng.standard_normal((N, K)) / 16.0); bi = dev(rng.standard_normal(N))
+    ws = torch.empty(N * K + 64, device=DEV)
+    c0 = torch.empty(M, N, device=DEV); c = torch.empty(M, N, device=DEV)
+    L.gemm_split(0, 1, M, N, K, a, K, b, K, c0, N, bias=bi, ws=ws)
+    assert 'gemm_bf16x3_nt_dma' in ' '.join(L.instance_log_read())
+    for _ in range(40):
+        c.fill_(0.0)
+        L.gemm_split(0, 1, M, N, K, a, K, b, K, c, N, bias=bi, ws=ws)
+        assert torch.equal(c, c0)
+    del a, c, c0
+    B, T, F, H = 512, 300, 256, 256
+    g = torch.Generator().manual_seed(5)
+    W = []
+    for l in range(2):
+        for shp in ((3 * H, F if l == 0 else H), (3 * H, H), (3 * H,), (3 * H,)):
+            W.append(((torch.rand(*shp, generator=g) * 2 - 1) / 16.0).to(DEV))
+    x = torch.randn(B, T, F, generator=g).to(DEV); dpool = torch.randn(B, H, generator=g).to(DEV)
+    rnn = L.Rnn(L.CELL_GRU, B, T, F, H, 2, 1, True, 0.5, L.POOL_MEAN, DEV)
+    pooled = torch.empty(B, H, device=DEV)
+    rnn.forward(x, W, seed=11, pooled=pooled)
+    first = None
+    for _ in range(12):
+        Gd = [torch.full_like(w, float('nan')) for w in W]
+        rnn.backward(x, W, Gd, dpooled=dpool)
+        rnn.check()
+        if first is None:
+            first = Gd
+            assert 'gemm_bf16x3_tn_dma' in ' '.join(L.instance_log_read())
+        else:
+            for u, v in zip(first, Gd):
+                assert torch.equal(u, v)
+
+
 def test_gemm_bf16x3_shift_and_splitk_match_exact_kernel():
     rng = np.random.default_rng(15)
     Bsz, T, M, N = 9, 300, 96, 64
