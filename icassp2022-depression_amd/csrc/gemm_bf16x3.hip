@@ -402,18 +402,23 @@ typedef __attribute__((address_space(3))) void* dma_ldsp;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-constexpr int DM_BM = 256, DM_BN = 256, DM_SK = 16, DM_NTH = 512, DM_NST = 4;
-constexpr int DM_ROWW = 256, DM_STW = 2 * DM_SK * DM_ROWW, DM_PPW = 2 * DM_SK / 8;
-constexpr size_t DM_LDS_BYTES = (size_t)DM_NST * DM_STW * 4;
+constexpr int DM_BM = 256, DM_SK = 16, DM_NTH = 512, DM_NST = 4, DM_PPW = 4;
+constexpr int dm_nst(int BN) { return BN == 256 ? DM_NST : 3; }       // 128-column tiles: three 24 KiB stages, TWO workgroups per CU (114 registers)
+constexpr size_t dm_lds_bytes(int BN) { return (size_t)dm_nst(BN) * (DM_SK * 256 + DM_SK * BN) * 4; }
 
+// BN = 256: waves 2 x 4, each 128 x 64.  BN = 128 (dW_hh of the BiLSTM-128 layers: N = H = 128): waves 4 x 2, each 64 x 64; a stage row of B is 512 bytes,
+// copied by the low half of a wave (same row assignment, same piece count: the vmcnt arithmetic does not change).
+template <int BN>
 __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1, int np) {
     extern __shared__ __attribute__((aligned(1024))) unsigned dsm[];
-    constexpr int NST = DM_NST, SK = DM_SK, ROWW = DM_ROWW, STW = DM_STW, PPW = DM_PPW;
+    constexpr int NST = dm_nst(BN), SK = DM_SK, PPW = DM_PPW;
+    constexpr int WN = BN / 64, WM = 8 / WN, MI = DM_BM / WM / 32;       // 4, 2, 4  |  2, 4, 2
+    constexpr int ROWA = 256, ROWB = BN, STW = SK * ROWA + SK * ROWB;
     const int x8 = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int prob = np == 2 ? (slot & 1) : 0;
     const GemmP& p = prob ? p1 : p0;
     if (p.only_if && *p.only_if == 0) return;
-    const int gx = p.N / DM_BN, gy = p.M / DM_BM;
+    const int gx = p.N / BN, gy = p.M / DM_BM;
     int t;
     {
         const int s2 = np == 2 ? (slot >> 1) : slot;
@@ -425,10 +430,10 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
         if (t >= hi) return;
     }
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 2, wn = w & 3, half = lane >> 5, l31 = lane & 31;
-    const int grp = wm;
+    const int wm = w / WN, wn = w % WN, half = lane >> 5, l31 = lane & 31;
+    const int grp = w >> 2;                        // waves 0-3 / 4-7: one wave of each group per SIMD
     const int bx = t % gx, by = (t / gx) % gy, bz = t / (gx * gy);
-    const int m0 = by * DM_BM, n0 = bx * DM_BN, kb = bz * p.kchunk, ke = min(p.K, kb + p.kchunk);
+    const int m0 = by * DM_BM, n0 = bx * BN, kb = bz * p.kchunk, ke = min(p.K, kb + p.kchunk);
     const int nst = (ke - kb) / SK;                // (the launcher checked: every chunk is a multiple of 16 rows)
     const int mphys = m0 + ((p.skip_by && m0 >= p.skip_at) ? p.skip_by : 0);
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0xfffffff0u, 0x00020000);
@@ -443,17 +448,19 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
         const int k0 = kb + issued * SK;
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
-            const bool isA = q < SK / 8;           // compile-time: stage rows [0, 16) are A's, [16, 32) B's; wave w takes rows w, w + 8 of each
-            const int r = w + 8 * q;
-            unsigned* dst = base + r * ROWW;
+            const bool isA = q < 2;                // compile-time: wave w copies rows w, w + 8 of A's 16 stage rows, then of B's
+            const int r = w + 8 * (q & 1);
             if (isA) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (dma_ldsp)dst, 16, (unsigned)lane * 16u, ((unsigned)(k0 + r) * (unsigned)p.lda + (unsigned)mphys) * 4u, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (dma_ldsp)(base + r * ROWA), 16, (unsigned)lane * 16u, ((unsigned)(k0 + r) * (unsigned)p.lda + (unsigned)mphys) * 4u, 0, 0);
             } else {
-                const int kr = k0 + r - SK;
-                const int tt = (q == SK / 8 ? tt0 : tt1) + p.shiftB;
+                const int kr = k0 + r;
+                const int tt = ((q & 1) ? tt1 : tt0) + p.shiftB;
                 const bool ok = p.seqT <= 0 || (tt >= 0 && tt < p.seqT);
-                if (ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (dma_ldsp)dst, 16, (unsigned)lane * 16u, ((unsigned)(kr + p.shiftB) * (unsigned)p.ldb + (unsigned)n0) * 4u, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (dma_ldsp)dst, 16, (unsigned)lane * 16u, 0u, 0, 0);
+                unsigned* dst = base + SK * ROWA + r * ROWB;
+                if (BN == 256 || lane < 32) {      // (a 512-byte row: the low half of the wave)
+                    if (ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (dma_ldsp)dst, 16, (unsigned)lane * 16u, ((unsigned)(kr + p.shiftB) * (unsigned)p.ldb + (unsigned)n0) * 4u, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (dma_ldsp)dst, 16, (unsigned)lane * 16u, 0u, 0, 0);
+                }
             }
         }
         if (p.seqT > 0) {
@@ -463,9 +470,9 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
         }
         ++issued;
     };
-    f32x16 acc[4][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -479,19 +486,19 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
         const bool more = it + NST - 1 < nst;
         if (more) issue();                         // stage it + 3, into the buffer of stage it - 1 (both groups finished reading it before the barrier in front of this slot)
         const unsigned* sa = dsm + (it % NST) * STW;
-        const unsigned* sb = sa + SK * ROWW;
-        bf16x8 ah[4], al[4], bh[2], bl[2];
+        const unsigned* sb = sa + SK * ROWA;
+        bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned* q0 = sa + (half * 8) * ROWW + wm * 128 + i * 32 + l31;
-            u32x4 h = {q0[0], q0[2 * ROWW], q0[4 * ROWW], q0[6 * ROWW]};
-            u32x4 l = {q0[ROWW], q0[3 * ROWW], q0[5 * ROWW], q0[7 * ROWW]};
+        for (int i = 0; i < MI; ++i) {
+            const unsigned* q0 = sa + (half * 8) * ROWA + wm * (DM_BM / WM) + i * 32 + l31;
+            u32x4 h = {q0[0], q0[2 * ROWA], q0[4 * ROWA], q0[6 * ROWA]};
+            u32x4 l = {q0[ROWA], q0[3 * ROWA], q0[5 * ROWA], q0[7 * ROWA]};
             ah[i] = __builtin_bit_cast(bf16x8, h); al[i] = __builtin_bit_cast(bf16x8, l);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float* q0 = reinterpret_cast<const float*>(sb) + (half * 8) * ROWW + wn * 64 + j * 32 + l31;
-            f32x4 x0 = {q0[0], q0[ROWW], q0[2 * ROWW], q0[3 * ROWW]}, x1 = {q0[4 * ROWW], q0[5 * ROWW], q0[6 * ROWW], q0[7 * ROWW]};
+            const float* q0 = reinterpret_cast<const float*>(sb) + (half * 8) * ROWB + wn * 64 + j * 32 + l31;
+            f32x4 x0 = {q0[0], q0[ROWB], q0[2 * ROWB], q0[3 * ROWB]}, x1 = {q0[4 * ROWB], q0[5 * ROWB], q0[6 * ROWB], q0[7 * ROWB]};
             bf16x4 h0, l0, h1, l1;
             split4(x0, h0, l0); split4(x1, h1, l1);
             bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 1 ? bl[j] : bh[j], term == 0 ? al[i] : ah[i], acc[i][j], 0, 0, 0);
@@ -518,8 +525,8 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
     if (grp == 0) __builtin_amdgcn_s_barrier();
     float* outp = p.part + (size_t)bz * p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 128 + i * 32 + l31;
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (DM_BM / WM) + i * 32 + l31;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -763,15 +770,21 @@ bool dep_gemm_bf16x3_pair_ok() {
 static bool tn_dma_ok(int M, int N, int K, int lda, int ldb, int splits, int kchunk, const float* part, int skip_at, int skip_by) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("DEP_GEMM_TN_DMA"); off = (e && e[0] == '0') ? 1 : 0; }
-    return !off && dep_gemm_bf16x3_pair_ok() && M % DM_BM == 0 && N % DM_BN == 0 && splits > 1 && part && kchunk % DM_SK == 0 && K % DM_SK == 0 &&
+    return !off && dep_gemm_bf16x3_pair_ok() && M % DM_BM == 0 && N % 128 == 0 && splits > 1 && part && kchunk % DM_SK == 0 && K % DM_SK == 0 &&
            lda % 4 == 0 && ldb % 4 == 0 && (skip_by == 0 || skip_at % DM_BM == 0);
 }
 static int tn_dma_launch(const GemmP& p0, const GemmP& p1, int np, hipStream_t s) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_bf16x3_tn_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DM_LDS_BYTES); attr = true; }
-    const int ntiles = (p0.M / DM_BM) * (p0.N / DM_BN) * p0.splits;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16x3_tn_dma<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dm_lds_bytes(256));
+        (void)hipFuncSetAttribute((const void*)gemm_bf16x3_tn_dma<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dm_lds_bytes(128));
+        attr = true;
+    }
+    const int BN = p0.N % 256 == 0 ? 256 : 128;
+    const int ntiles = (p0.M / DM_BM) * (p0.N / BN) * p0.splits;
     const dim3 g((unsigned)((ntiles + 7) / 8 * 8 * np));
-    DEP_LAUNCH(gemm_bf16x3_tn_dma, g, dim3(DM_NTH), DM_LDS_BYTES, s, p0, p1, np);
+    if (BN == 256) DEP_LAUNCH(gemm_bf16x3_tn_dma<256>, g, dim3(DM_NTH), dm_lds_bytes(256), s, p0, p1, np);
+    else DEP_LAUNCH(gemm_bf16x3_tn_dma<128>, g, dim3(DM_NTH), dm_lds_bytes(128), s, p0, p1, np);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
