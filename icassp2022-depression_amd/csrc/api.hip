@@ -377,6 +377,8 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
     float* R = (float*)reserve; float* W = (float*)workspace;
     const int B = d->B, T = d->T, H = d->H, D = d->dirs, G = lo.G, L = d->L;
     const int BTr = (int)lo.BT;
+    // the unsplit projections' scratch (the weight's stage image of gemm_bf16x3_nt_dma): the split-K region, idle during the forward
+    struct ScratchGuard { ScratchGuard(void* q, size_t n) { dep_gemm_set_scratch(q, n); } ~ScratchGuard() { dep_gemm_set_scratch(nullptr, 0); } } scratch_guard(W + lo.gemm, lo.gemm_bytes);
     const bool mfma = lo.cluster || dep_sweep_use_mfma(H, d->impl);
     const bool excl = dep_exclusive_on();
     const bool use16 = lo.cluster16 && excl;                        // the 16-unit-member forward fills the CUs: not on a shared GPU
@@ -407,7 +409,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             rc = dep_pack_cluster_split_multi(bwd_multi ? 5 : 3, srcs, dsts, kinds, H, s); if (rc) return rc;
         }
         float* gi = W + lo.gi;
-        rc = dep_gemm_internal(0, 1, BTr, G * H, d->F, x, d->F, w0[0], d->F, gi, G * H, w0[2], 0.f, 0, 0, W + lo.gemm, lo.gemm_bytes, s);      // (scratch: the weight's stage image)
+        rc = dep_gemm_internal(0, 1, BTr, G * H, d->F, x, d->F, w0[0], d->F, gi, G * H, w0[2], 0.f, 0, 0, nullptr, 0, s);
         if (rc) return rc;
         dep_fused2_args f{};
         f.B = B; f.T = T; f.training = d->training;
@@ -435,7 +437,7 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
             if (l == 1) {
                 const float* in = lo.drop ? R + lo.ydrop[0] : R + lo.y[0];
                 dep_gemm_set_predicate(soft);
-                rc = dep_gemm_internal(0, 1, BTr, G * H, H, in, H, wl[0], H, gi, G * H, wl[2], 0.f, 0, 0, W + lo.gemm, lo.gemm_bytes, s);
+                rc = dep_gemm_internal(0, 1, BTr, G * H, H, in, H, wl[0], H, gi, G * H, wl[2], 0.f, 0, 0, nullptr, 0, s);
                 dep_gemm_set_predicate(nullptr);
                 if (rc) return rc;
             }
@@ -505,13 +507,13 @@ extern "C" int dep_rnn_forward(const dep_rnn_desc* d, const float* x, const floa
                 bias = tb;
             }
             rc = dep_gemm_internal(0, 1, BTr, G * H, Kl, in, Kl, wl[0], Kl, gi + (size_t)dd * G * H, D * G * H, bias,
-                                   0.f, 0, 0, W + lo.gemm, lo.gemm_bytes, s);
+                                   0.f, 0, 0, nullptr, 0, s);
             if (rc) return rc;
             // the bias scratch is reused by the next direction: stream order keeps this safe
         }
         if (stacked) {
             rc = dep_gemm_internal(0, 1, BTr, D * G * H, Kl, in, Kl, R + lo.wstack[l], Kl, gi, D * G * H, R + lo.bstack[l],
-                                   0.f, 0, 0, W + lo.gemm, lo.gemm_bytes, s);
+                                   0.f, 0, 0, nullptr, 0, s);
             if (rc) return rc;
         }
         dep_sweep_args a{};
@@ -590,6 +592,8 @@ static int rnn_backward_impl(const dep_rnn_desc* d, const float* x, const float*
     const int B = d->B, T = d->T, H = d->H, D = d->dirs, G = lo.G, L = d->L;
     const int BTr = (int)lo.BT;
     void* gws = W + lo.gemm; const size_t gwsb = lo.gemm_bytes;
+    // (dX's weight image shares the region with the split-K partials of the contractions enqueued behind it: stream order keeps them apart)
+    struct ScratchGuard { ScratchGuard(void* q, size_t n) { dep_gemm_set_scratch(q, n); } ~ScratchGuard() { dep_gemm_set_scratch(nullptr, 0); } } scratch_guard(gws, gwsb);
     int rc;
     // The fused two-layer backward (rnn_fused2_bwd.hip; round 5: all-gather form): both layers' BPTT in ONE launch, layer 1's dX -- the gradient
     // entering layer 0 -- formed in-kernel.  It writes the same gate-gradient arrays as the per-layer sweeps (4H-wide rows, PK image when the

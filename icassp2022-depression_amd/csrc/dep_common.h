@@ -110,6 +110,7 @@ void dep_gemm_set_a_colskip(int at, int by);
 // (hi, lo) bf16 image a producer kernel wrote in place of the fp32 array.  Only the bf16x3 kernel reads PK; dep_gemm_internal
 // refuses (DEP_ERR_ARG) a PK operand on any other path.  Reset to (0, 0) after the calls.
 void dep_gemm_set_operand_formats(int fmt_a, int fmt_b);
+void dep_gemm_set_scratch(void* p, size_t bytes);      // per calling thread: scratch of its unsplit contractions (gemm.hip)
 bool dep_gemm_pk_pending();
 bool dep_gemm_bf16x3_pair_ok();
 // true when dep_gemm_internal would run the bf16x3 kernel for a contraction of this size (it is the one that honours the skip)

@@ -327,6 +327,11 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
 static std::atomic<int> g_split_mode{-1};            // process-global (documented in dep_rnn.h)
 static std::atomic<long> g_split_min_macs{1L << 28};
 static thread_local const unsigned* g_only_if = nullptr;
+// Scratch of the calling thread's UNSPLIT contractions (gemm_bf16x3_nt_dma's weight image).  Not the `ws` argument: a workspace turns split-K on for
+// small problems, and the RNN calls' projections must keep summing as they always did (tests/golden/device_bits.json).
+static thread_local void* g_scratch = nullptr;
+static thread_local size_t g_scratch_bytes = 0;
+void dep_gemm_set_scratch(void* p, size_t bytes) { g_scratch = p; g_scratch_bytes = bytes; }
 void dep_gemm_set_predicate(const unsigned* only_if) { g_only_if = only_if; }
 const unsigned* dep_gemm_predicate() { return g_only_if; }
 static thread_local int g_force_exact = 0;       // per calling thread: 1 = this call is exact fp32, 2 = this call is bf16x3 whatever the global mode
@@ -406,7 +411,8 @@ int dep_gemm_internal(int transA, int transB, int M, int N, int K, const float* 
     init_split_mode();
     if (g_force_exact == 2 || (g_force_exact == 0 && g_split_mode >= 1 && (long)M * N * K >= g_split_min_macs))
         return dep_gemm_bf16x3_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, seq_T, shiftB,
-                                      splits, kchunk, p.part, vec, s, (g_force_exact != 2 && g_split_mode >= 2) ? 1 : 3, ws, ws_bytes);     // the public bf16x3 entry is always 3 terms
+                                      splits, kchunk, p.part, vec, s, (g_force_exact != 2 && g_split_mode >= 2) ? 1 : 3,
+                                      (splits == 1 && ws) ? ws : g_scratch, (splits == 1 && ws) ? ws_bytes : g_scratch_bytes);      // an unsplit call may use its workspace as scratch     // the public bf16x3 entry is always 3 terms
 #define LAUNCH(TA, TB)                                                                    \
     do {                                                                                   \
         if (vec) DEP_LAUNCH((gemm_mfma<TA, TB, true>), g, dim3(NT), 0, s, p);      \

@@ -564,6 +564,10 @@ struct NtdP {
     const unsigned* only_if;
 };
 
+// APK (the NN form, dX = dG W): the row operand is the sweeps' PK gate-gradient image -- physical rows 2j / 2j+1 hold the (hi, lo) bf16 of logical rows 2j, 2j+1,
+// word by word -- so a lane reads eight hi words and eight lo words of its row PAIR and keeps its own row's halves (v_perm): nothing to convert.  Same stage
+// geometry (a physical row is 64 bytes per stage either way), same pieces, same swizzle; the weight's stage image is packed from its [k][n] layout.
+template <bool APK>
 __global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
     if (p.only_if && *p.only_if == 0) return;
     extern __shared__ __attribute__((aligned(1024))) unsigned dsm[];
@@ -619,8 +623,8 @@ __global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st) if (iv) issue();
-    const int xrow = 32 * w + l31;
-    const int xs = (xrow >> 2) & 3;
+    const int xrow = APK ? 32 * w + (l31 & ~1) : 32 * w + l31;       // (APK: the hi row of the lane's row pair; its lo row is the next one)
+    const int xs = (xrow >> 2) & 3;                                    // (rows 2j and 2j+1 share the swizzle: (row >> 2) & 3)
     const int xp0 = xrow * 16 + (((2 * half) ^ xs) << 2), xp1 = xrow * 16 + (((2 * half + 1) ^ xs) << 2);      // word offsets of the lane's two chunks inside a stage
     int tc = lo + slot, sc = 0, ccount = 0, since = 100;
     while (tc < hi) {
@@ -635,7 +639,15 @@ __global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
         const unsigned* sx = dsm + (ccount % NST) * STW;
         const unsigned* sw = sx + 2048;
         bf16x8 ah, al, bh[8], bl[8];
-        {
+        if constexpr (APK) {
+            // words k0..k3 / k4..k7 of the pair's hi row and of its lo row; this lane's row is the low (even row) or high (odd row) half of every word
+            const u32x4 hA = *reinterpret_cast<const u32x4*>(sx + xp0), hB = *reinterpret_cast<const u32x4*>(sx + xp1);
+            const u32x4 lA = *reinterpret_cast<const u32x4*>(sx + xp0 + 16), lB = *reinterpret_cast<const u32x4*>(sx + xp1 + 16);
+            const unsigned sel = (l31 & 1) ? 0x07060302u : 0x05040100u;
+            const u32x4 hv = {__builtin_amdgcn_perm(hA.y, hA.x, sel), __builtin_amdgcn_perm(hA.w, hA.z, sel), __builtin_amdgcn_perm(hB.y, hB.x, sel), __builtin_amdgcn_perm(hB.w, hB.z, sel)};
+            const u32x4 lv = {__builtin_amdgcn_perm(lA.y, lA.x, sel), __builtin_amdgcn_perm(lA.w, lA.z, sel), __builtin_amdgcn_perm(lB.y, lB.x, sel), __builtin_amdgcn_perm(lB.w, lB.z, sel)};
+            ah = __builtin_bit_cast(bf16x8, hv); al = __builtin_bit_cast(bf16x8, lv);
+        } else {
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(sx + xp0), x1 = *reinterpret_cast<const f32x4*>(sx + xp1);
             bf16x4 h0, l0, h1, l1;
             split4(x0, h0, l0); split4(x1, h1, l1);
@@ -675,6 +687,25 @@ __global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
         ++ccount;
         if (++sc == nst) { sc = 0; tc += SL; }
     }
+}
+
+// the same image from a weight stored [k][n] (K x N fp32, row stride ldw): the NN form's B operand
+__global__ void pack_w_stage_image_kn(const float* W, int ldw, int N, int K, unsigned* img) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one (k octet, n), n fastest: coalesced reads
+    const int oct = K / 8;
+    if (i >= (long)N * oct) return;
+    const int o = (int)(i / N), n = (int)(i % N);
+    const float* src = W + (size_t)(o * 8) * ldw + n;
+    const f32x4 x0 = {src[0], src[ldw], src[2 * (size_t)ldw], src[3 * (size_t)ldw]};
+    const f32x4 x1 = {src[4 * (size_t)ldw], src[5 * (size_t)ldw], src[6 * (size_t)ldw], src[7 * (size_t)ldw]};
+    bf16x4 h0, l0, h1, l1;
+    split4(x0, h0, l0); split4(x1, h1, l1);
+    const int ntile = n >> 8, nn = n & 255, stage = o >> 1, half = o & 1;
+    unsigned* blk = img + ((size_t)ntile * (K / 16) + stage) * 4096;
+    const u32x2v a = __builtin_bit_cast(u32x2v, h0), b = __builtin_bit_cast(u32x2v, h1), c = __builtin_bit_cast(u32x2v, l0), d = __builtin_bit_cast(u32x2v, l1);
+    u32x4 hv = {a[0], a[1], b[0], b[1]}, lv = {c[0], c[1], d[0], d[1]};
+    *reinterpret_cast<u32x4*>(blk + ((0 * 2 + half) * 256 + nn) * 4) = hv;
+    *reinterpret_cast<u32x4*>(blk + ((1 * 2 + half) * 256 + nn) * 4) = lv;
 }
 
 // W (N x K fp32, row stride ldw) -> the stage image: block (n tile, stage) = [plane][k octet][256 n] x 8 bf16
@@ -798,15 +829,21 @@ static bool nt_dma_ok(int M, int N, int K, int lda, int ldb, int ldc, const floa
            lda % 4 == 0 && ldb % 4 == 0 && a16(A) && a16(B) && C && ws && a16(ws) && ws_bytes >= (size_t)N * K * 4 && dep_gemm_predicate() == nullptr &&
            (size_t)M * lda * 4 < 0xfffffff0ull && (size_t)M * ldc * 4 < 0xfffffff0ull;
 }
-static int nt_dma_launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, void* ws, hipStream_t s) {
+static int nt_dma_launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, void* ws, hipStream_t s, bool nn_pk = false) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_bf16x3_nt_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTD_LDS_BYTES); attr = true; }
-    DEP_LAUNCH(pack_w_stage_image, dim3((unsigned)dep_cdiv((long)N * (K / 8), 256)), dim3(256), 0, s, B, ldb, N, K, (unsigned*)ws);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16x3_nt_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTD_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16x3_nt_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTD_LDS_BYTES);
+        attr = true;
+    }
+    if (nn_pk) DEP_LAUNCH(pack_w_stage_image_kn, dim3((unsigned)dep_cdiv((long)N * (K / 8), 256)), dim3(256), 0, s, B, ldb, N, K, (unsigned*)ws);
+    else DEP_LAUNCH(pack_w_stage_image, dim3((unsigned)dep_cdiv((long)N * (K / 8), 256)), dim3(256), 0, s, B, ldb, N, K, (unsigned*)ws);
     DEP_CHECK_LAUNCH();
     NtdP p{A, lda, (const unsigned*)ws, bias, C, ldc, M, N, K, N / NTD_BN, dep_gemm_predicate()};
     const int per_xcd = dep_cdiv((M / NTD_BM) * p.gx, 8);
     const dim3 g((unsigned)((per_xcd < 64 ? per_xcd : 64) * 8));      // two resident workgroups per CU, 32 CUs per XCD
-    DEP_LAUNCH(gemm_bf16x3_nt_dma, g, dim3(NTD_TH), NTD_LDS_BYTES, s, p);
+    if (nn_pk) DEP_LAUNCH(gemm_bf16x3_nt_dma<true>, g, dim3(NTD_TH), NTD_LDS_BYTES, s, p);
+    else DEP_LAUNCH(gemm_bf16x3_nt_dma<false>, g, dim3(NTD_TH), NTD_LDS_BYTES, s, p);
     DEP_CHECK_LAUNCH();
     return DEP_OK;
 }
@@ -848,6 +885,10 @@ int dep_gemm_bf16x3_launch(int transA, int transB, int M, int N, int K, const fl
     if (!transA && transB && fa == FMT_F32 && fb == FMT_F32 && terms == 3 && vec && !abl && seq_T <= 0 &&
         nt_dma_ok(M, N, K, lda, ldb, ldc, A, B, C, bias, beta, splits, ws, ws_bytes))
         return nt_dma_launch(M, N, K, A, lda, B, ldb, C, ldc, bias, ws, s);      // Round 6: the input projections whose shape fits take the LDS-DMA kernel
+    // ... and so does dX = dG W (NN) over the PK gate-gradient image: the same kernel with the row operand's fragments read, not converted
+    if (!transA && !transB && fa == FMT_PK && fb == FMT_F32 && terms == 3 && vec && !abl && seq_T <= 0 && ldb % 4 == 0 &&
+        nt_dma_ok(M, N, K, lda, ldb, ldc, A, B, C, bias, beta, splits, ws, ws_bytes))
+        return nt_dma_launch(M, N, K, A, lda, B, ldb, C, ldc, bias, ws, s, true);
     if (transA && !transB && fa == FMT_PK && fb == FMT_F32 && terms == 3 && vec && !abl && tn_dma_ok(M, N, K, lda, ldb, splits, kchunk, part, p.skip_at, p.skip_by)) {
         // Round 6: the weight-gradient contractions whose shape fits take the LDS-DMA kernel (bit-identical partial sums); the reduce below is shared
         const int rc = tn_dma_launch(p, p, 1, s);
