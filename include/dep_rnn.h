@@ -201,10 +201,7 @@ int dep_gemm_f32(int transA, int transB, int M, int N, int K,
  * fp32 accumulation (relative error per product ~1e-5, inside the path's 1e-4 parity budget; 5x the MFMA
  * rate of the exact kernel).  dep_rnn_forward/backward use it for their time-parallel contractions of at
  * least `min_macs` multiply-adds when the mode is 1 (default; DEP_GEMM_MODE=f32 or dep_set_gemm_mode(0,-1)
- * selects the exact fp32 kernel everywhere).  dep_gemm_f32 itself is always exact.
- * Round 6: an UNSPLIT projection (transA = 0, transB = 1; M % 128 == 0, N % 256 == 0, N <= 1024, K % 16 == 0, K >= 48, beta == 0) that is given a
- * workspace of at least N*K*4 bytes runs the LDS-DMA kernel (gemm_bf16x3_nt_dma; the workspace holds the weight's pre-split stage image);
- * without one it runs the register-staged kernel.  Same products in the same order: the results are bit-identical. */
+ * selects the exact fp32 kernel everywhere).  dep_gemm_f32 itself is always exact. */
 int dep_gemm_bf16x3(int transA, int transB, int M, int N, int K,
                     const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     const float* bias, float beta, int seq_T, int shiftB,
