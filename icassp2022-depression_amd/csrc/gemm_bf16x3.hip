@@ -443,26 +443,25 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
     int tt0 = 0, tt1 = 0;
     if (p.seqT > 0) { tt0 = (kb + w) % p.seqT; tt1 = (kb + w + 8) % p.seqT; }
     int issued = 0;                                // stages issued so far (they are issued in order)
-    auto issue = [&]() {
+    auto piece = [&](int q) {                      // (q is a compile-time constant at every call site)
         unsigned* base = dsm + (issued % NST) * STW;
         const int k0 = kb + issued * SK;
-#pragma unroll
-        for (int q = 0; q < PPW; ++q) {
-            const bool isA = q < 2;                // compile-time: wave w copies rows w, w + 8 of A's 16 stage rows, then of B's
-            const int r = w + 8 * (q & 1);
-            if (isA) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (dma_ldsp)(base + r * ROWA), 16, (unsigned)lane * 16u, ((unsigned)(k0 + r) * (unsigned)p.lda + (unsigned)mphys) * 4u, 0, 0);
-            } else {
-                const int kr = k0 + r;
-                const int tt = ((q & 1) ? tt1 : tt0) + p.shiftB;
-                const bool ok = p.seqT <= 0 || (tt >= 0 && tt < p.seqT);
-                unsigned* dst = base + SK * ROWA + r * ROWB;
-                if (BN == 256 || lane < 32) {      // (a 512-byte row: the low half of the wave)
-                    if (ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (dma_ldsp)dst, 16, (unsigned)lane * 16u, ((unsigned)(kr + p.shiftB) * (unsigned)p.ldb + (unsigned)n0) * 4u, 0, 0);
-                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (dma_ldsp)dst, 16, (unsigned)lane * 16u, 0u, 0, 0);
-                }
+        const bool isA = q < 2;                    // wave w copies rows w, w + 8 of A's 16 stage rows, then of B's
+        const int r = w + 8 * (q & 1);
+        if (isA) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (dma_ldsp)(base + r * ROWA), 16, (unsigned)lane * 16u, ((unsigned)(k0 + r) * (unsigned)p.lda + (unsigned)mphys) * 4u, 0, 0);
+        } else {
+            const int kr = k0 + r;
+            const int tt = ((q & 1) ? tt1 : tt0) + p.shiftB;
+            const bool ok = p.seqT <= 0 || (tt >= 0 && tt < p.seqT);
+            unsigned* dst = base + SK * ROWA + r * ROWB;
+            if (BN == 256 || lane < 32) {          // (a 512-byte row: the low half of the wave)
+                if (ok) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (dma_ldsp)dst, 16, (unsigned)lane * 16u, ((unsigned)(kr + p.shiftB) * (unsigned)p.ldb + (unsigned)n0) * 4u, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (dma_ldsp)dst, 16, (unsigned)lane * 16u, 0u, 0, 0);
             }
         }
+    };
+    auto stage_issued = [&]() {
         if (p.seqT > 0) {
             tt0 += SK; tt1 += SK;
             while (tt0 >= p.seqT) tt0 -= p.seqT;
@@ -470,6 +469,15 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
         }
         ++issued;
     };
+    auto issue = [&]() {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) piece(q);
+        stage_issued();
+    };
+    // BN = 256: a stage's four pieces are issued BETWEEN the MFMAs of the wave's MFMA slot (an LDS-DMA piece costs ~100 cycles of issue: in the read slot that
+    // is on the slot's critical path, among the MFMAs it mostly is not; prototype: -4 ... -8 %).  BN = 128 (three stages) keeps them at the head of the read
+    // slot: issued a slot later, the next stage would have to be waited for with vmcnt(0).
+    constexpr bool AMONG = BN == 256;
     f32x16 acc[MI][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -484,29 +492,65 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
     if (grp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
     for (int it = 0; it < nst; ++it) {
         const bool more = it + NST - 1 < nst;
-        if (more) issue();                         // stage it + 3, into the buffer of stage it - 1 (both groups finished reading it before the barrier in front of this slot)
+        if (!AMONG && more) issue();               // stage it + NST - 1, into the buffer of stage it - 1 (both groups finished reading it before the barrier in front of this slot)
         const unsigned* sa = dsm + (it % NST) * STW;
         const unsigned* sb = sa + SK * ROWA;
         bf16x8 ah[MI], al[MI], bh[2], bl[2];
+        {
+            // Fragment words by hand-placed ds_read2st64_b32: each instruction fetches the two words of ONE operand register pair (rows e, e + 2 of A's hi / lo
+            // plane; rows e, e + 1 of B), so the results land where the MFMA / the split read them.  Left to the compiler the loads pair words of DIFFERENT
+            // fragments (columns m, m + 32) and ~100 v_mov per stage reassemble the operands: the read slot was VALU-bound and longer than the MFMA slot
+            // (tools/micro/gemm_tn_dma.hip: 1130 -> 845 ticks per stage; profiles/r06_s23_*).
+            typedef unsigned long long u64t;
+            typedef u64t u64x2 __attribute__((ext_vector_type(2)));
+            constexpr int UB = ROWB / 64;              // B's row stride in the instruction's 64-dword offset units (4 | 2); A's is 4
+            u64t ra[MI][2][2], rbx[2][4];
+            const unsigned abase = (unsigned)(unsigned long long)(dma_ldsp)(sa + (half * 8) * ROWA + wm * (DM_BM / WM) + l31);
+            const unsigned bbase = (unsigned)(unsigned long long)(dma_ldsp)(sb + (half * 8) * ROWB + wn * 64 + l31);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const unsigned* q0 = sa + (half * 8) * ROWA + wm * (DM_BM / WM) + i * 32 + l31;
-            u32x4 h = {q0[0], q0[2 * ROWA], q0[4 * ROWA], q0[6 * ROWA]};
-            u32x4 l = {q0[ROWA], q0[3 * ROWA], q0[5 * ROWA], q0[7 * ROWA]};
-            ah[i] = __builtin_bit_cast(bf16x8, h); al[i] = __builtin_bit_cast(bf16x8, l);
-        }
+            for (int i = 0; i < MI; ++i) {
+                const unsigned ad = abase + i * 128;
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:8" : "=v"(ra[i][0][0]) : "v"(ad));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:16 offset1:24" : "=v"(ra[i][0][1]) : "v"(ad));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:4 offset1:12" : "=v"(ra[i][1][0]) : "v"(ad));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:20 offset1:28" : "=v"(ra[i][1][1]) : "v"(ad));
+            }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float* q0 = reinterpret_cast<const float*>(sb) + (half * 8) * ROWB + wn * 64 + j * 32 + l31;
-            f32x4 x0 = {q0[0], q0[ROWB], q0[2 * ROWB], q0[3 * ROWB]}, x1 = {q0[4 * ROWB], q0[5 * ROWB], q0[6 * ROWB], q0[7 * ROWB]};
-            bf16x4 h0, l0, h1, l1;
-            split4(x0, h0, l0); split4(x1, h1, l1);
-            bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-            bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int j = 0; j < 2; ++j) {
+                const unsigned ad = bbase + j * 128;
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(rbx[j][0]) : "v"(ad), "n"(0 * UB), "n"(1 * UB));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(rbx[j][1]) : "v"(ad), "n"(2 * UB), "n"(3 * UB));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(rbx[j][2]) : "v"(ad), "n"(4 * UB), "n"(5 * UB));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(rbx[j][3]) : "v"(ad), "n"(6 * UB), "n"(7 * UB));
+            }
+            // (the registers are operands of the wait: nothing that uses them can be scheduled in front of it)
+            if constexpr (MI == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(ra[0][0][0]), "+v"(ra[0][0][1]), "+v"(ra[0][1][0]), "+v"(ra[0][1][1]), "+v"(ra[1][0][0]), "+v"(ra[1][0][1]), "+v"(ra[1][1][0]), "+v"(ra[1][1][1]),
+                               "+v"(ra[2][0][0]), "+v"(ra[2][0][1]), "+v"(ra[2][1][0]), "+v"(ra[2][1][1]), "+v"(ra[3][0][0]), "+v"(ra[3][0][1]), "+v"(ra[3][1][0]), "+v"(ra[3][1][1]),
+                               "+v"(rbx[0][0]), "+v"(rbx[0][1]), "+v"(rbx[0][2]), "+v"(rbx[0][3]), "+v"(rbx[1][0]), "+v"(rbx[1][1]), "+v"(rbx[1][2]), "+v"(rbx[1][3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(ra[0][0][0]), "+v"(ra[0][0][1]), "+v"(ra[0][1][0]), "+v"(ra[0][1][1]), "+v"(ra[1][0][0]), "+v"(ra[1][0][1]), "+v"(ra[1][1][0]), "+v"(ra[1][1][1]),
+                               "+v"(rbx[0][0]), "+v"(rbx[0][1]), "+v"(rbx[0][2]), "+v"(rbx[0][3]), "+v"(rbx[1][0]), "+v"(rbx[1][1]), "+v"(rbx[1][2]), "+v"(rbx[1][3]));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const u64x2 h = {ra[i][0][0], ra[i][0][1]}, l = {ra[i][1][0], ra[i][1][1]};
+                ah[i] = __builtin_bit_cast(bf16x8, h); al[i] = __builtin_bit_cast(bf16x8, l);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u64x2 a0 = {rbx[j][0], rbx[j][1]}, a1 = {rbx[j][2], rbx[j][3]};
+                bf16x4 h0, l0, h1, l1;
+                split4(__builtin_bit_cast(f32x4, a0), h0, l0); split4(__builtin_bit_cast(f32x4, a1), h1, l1);
+                bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
         }
         // every wave's pieces of stage it + 1 must have landed before the barrier in front of group 0's next read slot: group 1 is in its read slot then,
         // group 0 in its MFMA slot
-        if (grp == 1) { if (more) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>(); }
+        // (AMONG: this wave issues stage it + 3 only in its MFMA slot below -- one stage fewer is in flight at group 1's wait)
+        if (grp == 1) { if (AMONG ? (it + NST - 2 < nst) : more) wait_vm<(NST - 2) * PPW - (AMONG ? PPW : 0)>(); else wait_vm<0>(); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -514,10 +558,15 @@ __global__ __launch_bounds__(DM_NTH) void gemm_bf16x3_tn_dma(GemmP p0, GemmP p1,
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 1 ? bl[j] : bh[j], term == 0 ? al[i] : ah[i], acc[i][j], 0, 0, 0);
+                if constexpr (AMONG) {             // pieces 0..3 behind the 4th, 8th, 12th and 16th MFMA
+                    if (term < 2 && (i & 1) && more) piece(term * 2 + (i >> 1));
+                }
+            }
+        if (AMONG && more) stage_issued();
         __builtin_amdgcn_s_setprio(0);
         if (grp == 0) { if (more) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();

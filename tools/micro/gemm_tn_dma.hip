@@ -30,7 +30,7 @@ struct P {
     const float* B; int ldb;      // fp32, (K rows) x ldb
     float* part;                  // [splits][M][N]
     int M, N, K, kchunk, splits, gx, gy;
-    const float* B1; float* part1; int pair;      // pair: a second problem with the SAME A (dW_ih / dW_hh of a GRU layer): slot parity selects it
+    const float* B1; float* part1; int pair; int noload;      // pair: a second problem with the SAME A (dW_ih / dW_hh of a GRU layer): slot parity selects it
 };
 
 // workgroup -> (problem, tile): an XCD (blockIdx % 8) owns a contiguous share of the tile order, so the tiles that share operand panels run on ONE L2,
@@ -303,42 +303,67 @@ __global__ __launch_bounds__(NTH) void tn_dma_pp2(P p, long long* trace) {
     if (grp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
     long long ts[5] = {0, 0, 0, 0, 0}; long long acc_t[4] = {0, 0, 0, 0};
 #define STAMP(i) do { if (trace) ts[i] = (long long)__builtin_readcyclecounter(); } while (0)
+    bf16x8 ah[4], al[4], bh[2], bl[2];
     for (int it = 0; it < nst; ++it) {
-        const bool more = it + NST - 1 < nst;
+        const bool more = it + NST - 1 < nst && p.noload < 2;      // noload: 1 no fragment reads, 2 neither reads nor DMA, 3 reads but no DMA
         STAMP(0);
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < HEADQ; ++q) piece(it + NST - 1, q);      // the first HEADQ pieces of stage it + 3 at the head of the read slot, the rest among the MFMAs
-        }
         const unsigned* sa = smem + (it % NST) * STW;
         const unsigned* sb = sa + SK * ROWW;
-        bf16x8 ah[4], al[4], bh[2], bl[2];
+        if (!((p.noload == 1 || p.noload == 2) && it > 0)) {
+        // Fragment words by hand-placed ds_read2st64_b32: each instruction fetches the two words of ONE operand register pair (rows e, e + 2 of the hi / lo
+        // plane; rows e, e + 1 of B), so the results land where the MFMA reads them.  Left to the compiler the loads pair words of DIFFERENT fragments
+        // (columns m, m + 32) and ~100 v_mov per stage reassemble the operands: the read slot was VALU-bound (820 cycles) and longer than the MFMA slot.
+        typedef unsigned long long u64t;
+        u64t ra[4][2][2], rbx[2][4];
+        {
+            const unsigned abase = (unsigned)(unsigned long long)(ldsp)(sa + (half * 8) * ROWW + wm * 128 + l31);
+            const unsigned bbase = (unsigned)(unsigned long long)(ldsp)(sb + (half * 8) * ROWW + wn * 64 + l31);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ad = abase + i * 128;
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:8" : "=v"(ra[i][0][0]) : "v"(ad));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:16 offset1:24" : "=v"(ra[i][0][1]) : "v"(ad));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:4 offset1:12" : "=v"(ra[i][1][0]) : "v"(ad));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:20 offset1:28" : "=v"(ra[i][1][1]) : "v"(ad));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned ad = bbase + j * 128;
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:4" : "=v"(rbx[j][0]) : "v"(ad));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:8 offset1:12" : "=v"(rbx[j][1]) : "v"(ad));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:16 offset1:20" : "=v"(rbx[j][2]) : "v"(ad));
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:24 offset1:28" : "=v"(rbx[j][3]) : "v"(ad));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0][0]), "+v"(ra[0][0][1]), "+v"(ra[0][1][0]), "+v"(ra[0][1][1]), "+v"(ra[1][0][0]), "+v"(ra[1][0][1]), "+v"(ra[1][1][0]), "+v"(ra[1][1][1]),
+                           "+v"(ra[2][0][0]), "+v"(ra[2][0][1]), "+v"(ra[2][1][0]), "+v"(ra[2][1][1]), "+v"(ra[3][0][0]), "+v"(ra[3][0][1]), "+v"(ra[3][1][0]), "+v"(ra[3][1][1]),
+                           "+v"(rbx[0][0]), "+v"(rbx[0][1]), "+v"(rbx[0][2]), "+v"(rbx[0][3]), "+v"(rbx[1][0]), "+v"(rbx[1][1]), "+v"(rbx[1][2]), "+v"(rbx[1][3]));
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const unsigned* q0 = sa + (half * 8) * ROWW + wm * 128 + i * 32 + l31;
-            u32x4 h = {q0[0], q0[2 * ROWW], q0[4 * ROWW], q0[6 * ROWW]};
-            u32x4 l = {q0[ROWW], q0[3 * ROWW], q0[5 * ROWW], q0[7 * ROWW]};
+            typedef u64t u64x2 __attribute__((ext_vector_type(2)));
+            const u64x2 h = {ra[i][0][0], ra[i][0][1]}, l = {ra[i][1][0], ra[i][1][1]};
             ah[i] = __builtin_bit_cast(bf16x8, h); al[i] = __builtin_bit_cast(bf16x8, l);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float* q0 = reinterpret_cast<const float*>(sb) + (half * 8) * ROWW + wn * 64 + j * 32 + l31;
-            float x[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = q0[e * ROWW];
             unsigned hw[4], lw[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const f32x2v v = {x[2 * e], x[2 * e + 1]};
+                const float x0 = __uint_as_float((unsigned)rbx[j][e]), x1 = __uint_as_float((unsigned)(rbx[j][e] >> 32));
+                const f32x2v v = {x0, x1};
                 hw[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
-                const f32x2v d = {x[2 * e] - __uint_as_float(hw[e] << 16), x[2 * e + 1] - __uint_as_float(hw[e] & 0xffff0000u)};
+                const f32x2v d = {x0 - __uint_as_float(hw[e] << 16), x1 - __uint_as_float(hw[e] & 0xffff0000u)};
                 lw[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2v));
             }
             u32x4 h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
             bh[j] = __builtin_bit_cast(bf16x8, h); bl[j] = __builtin_bit_cast(bf16x8, l);
         }
-        // every wave's pieces of stage it + 1 must have landed before the barrier in front of group 0's next read slot: group 1 is in its read slot then,
-        // group 0 in its MFMA slot
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < HEADQ; ++q) piece(it + NST - 1, q);      // the first HEADQ pieces of stage it + 3 BEHIND the fragment reads of the read slot, the rest among the MFMAs
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         STAMP(1);
         if (grp == 1) { if (it + NST - 2 < nst) wait_vm<(NST - 3) * PPW + HEADQ>(); else wait_vm<0>(); }      // (stage it + 3: HEADQ pieces so far)
@@ -482,6 +507,8 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     p.A = reinterpret_cast<const float*>(Apk); p.B = B; p.part = part;
     p.pair = argc > 5 ? atoi(argv[5]) : 0;
+    const int hot = argc > 6 ? atoi(argv[6]) : 0;      // 1: every stage row is row 0 of its operand (all pieces hit in L2 / TCP: what does the CU's fill path deliver?)  timing only
+    if (hot) { p.lda = 0; p.ldb = 0; printf("HOT: row strides 0 -- results are garbage, timing only\n"); }
     if (p.pair) {
         float* B1; CK(hipMalloc(&B1, (size_t)K * N * 4)); CK(hipMalloc(&p.part1, (size_t)p.splits * M * N * 4));
         fill_rand<<<(unsigned)(((long)K * N + 255) / 256), 256>>>(B1, (long)K * N, 11u); CK(hipDeviceSynchronize());
@@ -495,17 +522,21 @@ int main(int argc, char** argv) {
     res[6] = {"ping-pong, 4 stages", run_pp<4>(p, 20)};
     res[7] = {"ping-pong, 4 stages, 2 pieces at the head", run_pp2<4, 2>(p, 20)};
     res[8] = {"ping-pong, 4 stages, DMA among the MFMAs", run_pp2<4, 0>(p, 20)};
-    {
+    for (int nl = 0; nl < 4; ++nl) {
+        p.noload = nl;
         long long* tr; CK(hipMalloc(&tr, 64)); CK(hipMemset(tr, 0, 64));
         const size_t lds = (size_t)4 * 2 * 16 * 256 * 4;
         const dim3 g((unsigned)((p.gx * p.gy * p.splits + 7) / 8 * 8 * (p.pair ? 2 : 1)));
         hipLaunchKernelGGL((tn_dma_pp2<4, 2>), g, dim3(NTH), lds, 0, p, tr);
         CK(hipDeviceSynchronize());
         long long h[8]; CK(hipMemcpy(h, tr, 64, hipMemcpyDeviceToHost));
+        printf("(noload %d)\n", p.noload);
         for (int gq = 0; gq < 2; ++gq)
             printf("trace, group %d wave (ticks per stage, stages 50-149): issue + fragment reads + split %lld | vmcnt + barrier %lld | 24 MFMAs (+ DMA issue) %lld | vmcnt + barrier %lld\n",
                    gq, h[gq * 4] / 100, h[gq * 4 + 1] / 100, h[gq * 4 + 2] / 100, h[gq * 4 + 3] / 100);
     }
+    p.noload = 0;
+    (void)run_pp2<4, 0>(p, 1);                    // a clean run of the hand-placed-read variant: this is what the check below verifies
     // check this variant
     reduce_parts<<<(unsigned)(((long)M * N + 255) / 256), 256>>>(part, p.splits, (long)M * N, C);
     const int cnt = 64; std::vector<int> hm(cnt), hn(cnt);
