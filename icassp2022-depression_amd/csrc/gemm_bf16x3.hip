@@ -651,19 +651,22 @@ __global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
     int ti = lo + slot, si = 0, icount = 0;
     bool iv = true;
     unsigned ixoff = (unsigned)(ti / p.gx) * (unsigned)NTD_BM * (unsigned)p.ldx * 4u, iwoff = (unsigned)(ti % p.gx) * (unsigned)nst * 16384u;
-    auto issue = [&]() {
+    auto piece = [&](int q) {                      // (q is a compile-time constant at every call site: two pieces of X, four of the weight image)
         unsigned* base = dsm + (icount % NST) * STW;
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (dma_ldsp)(base + (32 * w + 16 * q) * 16), 16, xrel[q], ixoff + (unsigned)si * 64u, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (dma_ldsp)(base + 2048 + (w * 4 + q) * 256), 16, (unsigned)lane * 16u, iwoff + (unsigned)si * 16384u + (unsigned)(w * 4 + q) * 1024u, 0, 0);
+        if (q < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (dma_ldsp)(base + (32 * w + 16 * q) * 16), 16, xrel[q], ixoff + (unsigned)si * 64u, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (dma_ldsp)(base + 2048 + (w * 4 + q - 2) * 256), 16, (unsigned)lane * 16u, iwoff + (unsigned)si * 16384u + (unsigned)(w * 4 + q - 2) * 1024u, 0, 0);
+    };
+    auto stage_issued = [&]() {
         ++icount;
         if (++si == nst) {
             si = 0; ti += SL; iv = ti < hi;
             if (iv) { ixoff = (unsigned)(ti / p.gx) * (unsigned)NTD_BM * (unsigned)p.ldx * 4u; iwoff = (unsigned)(ti % p.gx) * (unsigned)nst * 16384u; }
         }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) piece(q);
+        stage_issued();
     };
     f32x16 acc[8];
 #pragma unroll
@@ -684,7 +687,8 @@ __global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
         else if (since == 1 || since == 2) wait_vm<PPW + 57>();      // (both stages waited for here were issued in front of the write-out)
         else wait_vm<PPW>();
         __builtin_amdgcn_s_barrier();              // everybody's pieces landed; everybody finished reading the stage before
-        if (iv) issue();                           // into the buffer of the stage before
+        const bool more = iv;                      // the next stage's six pieces go out BETWEEN this stage's MFMAs (into the buffer of the stage before): an LDS-DMA
+                                                   // piece costs ~100 cycles of issue, which the matrix pipe hides there and nothing hides in front of the fragment reads
         const unsigned* sx = dsm + (ccount % NST) * STW;
         const unsigned* sw = sx + 2048;
         bf16x8 ah, al, bh[8], bl[8];
@@ -711,8 +715,11 @@ __global__ __launch_bounds__(NTD_TH, 2) void gemm_bf16x3_nt_dma(NtdP p) {
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j) {
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 0 ? al : ah, term == 1 ? bl[j] : bh[j], acc[j], 0, 0, 0);
+                if ((j & 3) == 3 && more) piece(term * 2 + (j >> 2));
+            }
+        if (more) stage_issued();
         if (sc == nst - 1) {                       // the tile is complete: write it out, start the next from zero
             // lane owns column n = j*32 + l31; register 4 g + e holds row 8 g + 4 half + e
             const int n0 = (tc % p.gx) * NTD_BN, mb = (tc / p.gx) * NTD_BM + 32 * w;
