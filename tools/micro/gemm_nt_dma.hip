@@ -274,6 +274,17 @@ __global__ __launch_bounds__(NTH2, 2) void nt_dma2(P p) {
             if constexpr (SWAP) {
                 // lane owns column n = j*32 + l31; register 4 g + e holds row 8 g + 4 half + e: a store instruction writes 2 rows x 128 contiguous bytes
                 const int mb = (tc / p.gx) * 128 + 32 * w;
+                if (p.nt == 3) {
+                    // TIMING ONLY (wrong placement): what a transposed write-out would cost -- 16-byte stores, a store instruction = 8 rows x 128 contiguous bytes
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) {
+                            const int m = mb + 8 * k4 + (lane >> 3), n = n0 + j * 32 + (lane & 7) * 4;
+                            const u32x4 v = {__float_as_uint(acc[j][4 * k4]), __float_as_uint(acc[j][4 * k4 + 1]), __float_as_uint(acc[j][4 * k4 + 2]), __float_as_uint(acc[j][4 * k4 + 3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rc, ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u, 0, 2);
+                        }
+                } else
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int n = n0 + j * 32 + l31;
@@ -371,8 +382,8 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
     const double flops = 2.0 * M * N * (double)K;
     printf("pack + projection %.4f ms = %.0f TFLOP/s of products (x3) = %.0f TFLOP/s fp32-equivalent\n", ms, 3 * flops / ms / 1e9, flops / ms / 1e9);
-    for (int sw = 2; sw >= 0; --sw) {
-        p.nt = sw == 2;
+    for (int sw = 3; sw >= 0; --sw) {
+        p.nt = sw == 2 ? 1 : (sw == 3 ? 3 : 0);
         const size_t lds2 = (size_t)NST2 * STW2 * 4 + 4096;
         CK(hipFuncSetAttribute((const void*)nt_dma2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         CK(hipFuncSetAttribute((const void*)nt_dma2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -388,7 +399,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 20; ++i) once2();
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms2; CK(hipEventElapsedTime(&ms2, e0, e1)); ms2 /= 20;
-        printf("v2 (128 x 256 tiles, two workgroups per CU%s): pack + projection %.4f ms = %.0f TFLOP/s of products\n", sw == 2 ? ", roles swapped, nt stores" : (sw ? ", roles swapped: dword stores of full lines" : ""), ms2, 3 * flops / ms2 / 1e9);
+        printf("v2 (128 x 256 tiles, two workgroups per CU%s): pack + projection %.4f ms = %.0f TFLOP/s of products\n", sw == 3 ? ", TIMING ONLY: 16-byte full-line nt stores" : sw == 2 ? ", roles swapped, nt stores" : (sw ? ", roles swapped: dword stores of full lines" : ""), ms2, 3 * flops / ms2 / 1e9);
     }
     const int cnt = 256; std::vector<int> hm(cnt), hn(cnt);
     for (int i = 0; i < cnt; ++i) { hm[i] = (int)(((long)i * 7919 + 13) % M); hn[i] = (i * 101 + 3) % N; }
