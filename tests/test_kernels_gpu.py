@@ -315,6 +315,10 @@ RNN_CASES = [
     # round 5: the fused two-layer all-gather backward (H = 256, default) at the edges of its pipeline: layer 0 runs two fused steps behind layer 1,
     # the streaming group one; T = 2 / 3 / 4 (even T: PK write-out in step pairs, odd T: fp32 rows), a ragged tile and a single-step pair
     ('gru', 5, 2, 8, 256, 3), ('gru', 20, 3, 8, 256, 3), ('gru', 33, 4, 16, 256, 3), ('gru', 17, 6, 256, 256, 3),
+    # round 6: mid-size stacks whose contractions take the LDS-DMA kernels (B T = 2048: a multiple of 128, split-K weight gradients) in tilings the full-size
+    # cases do not have: 16 row tiles x 3 column tiles in the projection, 8 K chunks of 256 rows; H = 512: 6 x 2 tiles of the weight gradient; the BiLSTM's
+    # K = 256 projection, its 256 x 128-tile dW_hh pairs and the NN form of dX
+    ('gru', 64, 32, 256, 256, 3), ('gru', 64, 32, 64, 512, 3), ('lstm', 64, 32, 1024, 128, 3),
 ]
 
 
